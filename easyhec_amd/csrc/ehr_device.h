@@ -1,0 +1,312 @@
+// ehr_device.h -- device-side arithmetic shared by the gfx950 kernels (rasterize / antialias / fused mask-loss).
+//
+// Arithmetic contract: every float operation is a single IEEE binary32 op (the library is
+// compiled with -ffp-contract=off; fmaf only where written), coverage is exact integer math on 1/16-pixel snapped
+// vertices, depth/barycentrics come from the unsnapped clip-space vertices.  The semantics restate nvdiffrast's
+// rasterize/interpolate/antialias as called from
+// /root/reference/easyhec/structures/nvdiffrast_renderer.py:39,42,43.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EHR_TILE_W 32
+#define EHR_TILE_H 8
+#define EHR_TILE_THREADS 256
+
+namespace ehr {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ float tri_to_float(int x) {
+    return (x <= 0x01000000) ? (float)x : __int_as_float(0x4a800000 + x);
+}
+__device__ __forceinline__ int float_to_tri(float f) {
+    return (f <= 16777216.f) ? (int)f : (__float_as_int(f) - 0x4a800000);
+}
+__device__ __forceinline__ unsigned ord_key(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_unkey(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float sat01(float x) { return x > 0.f ? (x < 1.f ? x : 1.f) : 0.f; }
+__device__ __forceinline__ bool same_sign(float a, float b) {
+    return (int)(__float_as_uint(a) ^ __float_as_uint(b)) >= 0;
+}
+
+__device__ __forceinline__ int snap_coord(float v, float w, float scale) {
+    float s = v / w;
+    float t = s * scale;
+    if (!(t < 1073741824.f)) t = 1073741824.f;
+    if (t < -1073741824.f) t = -1073741824.f;
+    return (int)rintf(t);
+}
+
+// clip-space vertex = M * [x,y,z,1] as an fma chain (easyhec/utils/nvdiffrast_utils.py:14-18)
+__device__ __forceinline__ float4 transform_vertex(const float* __restrict__ M, float x, float y, float z) {
+    float4 o;
+    o.x = fmaf(M[0], x, fmaf(M[1], y, fmaf(M[2], z, M[3])));
+    o.y = fmaf(M[4], x, fmaf(M[5], y, fmaf(M[6], z, M[7])));
+    o.z = fmaf(M[8], x, fmaf(M[9], y, fmaf(M[10], z, M[11])));
+    o.w = fmaf(M[12], x, fmaf(M[13], y, fmaf(M[14], z, M[15])));
+    return o;
+}
+
+// Sutherland-Hodgman against the near plane (d = z + w >= 0).  Returns 0, 3 or 4 polygon vertices.
+__device__ __forceinline__ int clip_near(const float4 p[3], float4 q[4]) {
+    float d0 = p[0].z + p[0].w, d1 = p[1].z + p[1].w, d2 = p[2].z + p[2].w;
+    bool all_in = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (d0 >= 0.f) && (d1 >= 0.f) && (d2 >= 0.f);
+    if (all_in) {
+        q[0] = p[0];
+        q[1] = p[1];
+        q[2] = p[2];
+        return 3;
+    }
+    float d[3] = {d0, d1, d2};
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        int j = (i == 2) ? 0 : i + 1;
+        bool in_i = d[i] >= 0.f, in_j = d[j] >= 0.f;
+        if (in_i) q[n++] = p[i];
+        if (in_i != in_j) {
+            float t = d[i] / (d[i] - d[j]);
+            float4 r;
+            r.x = p[i].x + t * (p[j].x - p[i].x);
+            r.y = p[i].y + t * (p[j].y - p[i].y);
+            r.z = p[i].z + t * (p[j].z - p[i].z);
+            r.w = p[i].w + t * (p[j].w - p[i].w);
+            q[n++] = r;
+        }
+    }
+    if (n < 3) return 0;
+    for (int i = 0; i < n; i++)
+        if (!(q[i].w > 0.f)) return 0;
+    return n;
+}
+
+// Integer coverage setup of one (sub-)triangle.  Coordinates are 1/16-pixel units relative to the image centre;
+// pixel (ix,iy) has its centre at (16*ix + cx, 16*iy + cy), cx = 8 - 8W, cy = 8 - 8H.
+struct Coverage {
+    int X[3], Y[3];          // snapped vertices, oriented counter-clockwise (y up)
+    int ix0, ix1, iy0, iy1;  // pixel bounding box clamped to the image (empty if ix0 > ix1 or iy0 > iy1)
+    bool valid;
+};
+
+__device__ __forceinline__ Coverage setup_coverage(const float4& a, const float4& b, const float4& c, int W, int H) {
+    Coverage cv;
+    const float sx = (float)(W * 8), sy = (float)(H * 8);
+    cv.X[0] = snap_coord(a.x, a.w, sx);
+    cv.Y[0] = snap_coord(a.y, a.w, sy);
+    cv.X[1] = snap_coord(b.x, b.w, sx);
+    cv.Y[1] = snap_coord(b.y, b.w, sy);
+    cv.X[2] = snap_coord(c.x, c.w, sx);
+    cv.Y[2] = snap_coord(c.y, c.w, sy);
+    i64 area2 = (i64)(cv.X[1] - (i64)cv.X[0]) * (i64)(cv.Y[2] - (i64)cv.Y[0]) -
+                (i64)(cv.X[2] - (i64)cv.X[0]) * (i64)(cv.Y[1] - (i64)cv.Y[0]);
+    cv.valid = area2 != 0;
+    if (area2 < 0) {
+        int tx = cv.X[1], ty = cv.Y[1];
+        cv.X[1] = cv.X[2];
+        cv.Y[1] = cv.Y[2];
+        cv.X[2] = tx;
+        cv.Y[2] = ty;
+    }
+    int xmin = min(cv.X[0], min(cv.X[1], cv.X[2])), xmax = max(cv.X[0], max(cv.X[1], cv.X[2]));
+    int ymin = min(cv.Y[0], min(cv.Y[1], cv.Y[2])), ymax = max(cv.Y[0], max(cv.Y[1], cv.Y[2]));
+    const i64 cx = 8 - 8 * (i64)W, cy = 8 - 8 * (i64)H;
+    i64 ix0 = ((i64)xmin - cx + 15) >> 4, ix1 = ((i64)xmax - cx) >> 4;
+    i64 iy0 = ((i64)ymin - cy + 15) >> 4, iy1 = ((i64)ymax - cy) >> 4;
+    if (ix0 < 0) ix0 = 0;
+    if (iy0 < 0) iy0 = 0;
+    if (ix1 > W - 1) ix1 = W - 1;
+    if (iy1 > H - 1) iy1 = H - 1;
+    cv.ix0 = (int)ix0;
+    cv.ix1 = (int)ix1;
+    cv.iy0 = (int)iy0;
+    cv.iy1 = (int)iy1;
+    if (ix0 > ix1 || iy0 > iy1) cv.valid = false;
+    return cv;
+}
+
+// Edge functions with the tie rule folded in:  inside  <=>  (E0 | E1 | E2) >= 0  where
+// E_k = dX_k*(Py - Y_k) - dY_k*(Px - X_k) - (top_left_k ? 0 : 1),  evaluated at pixel (ix,iy) and stepped by
+// (sx_k per +1 pixel in x, sy_k per +1 pixel in y).
+struct EdgeEval {
+    i64 e[3];
+    i64 sx[3], sy[3];
+};
+
+__device__ __forceinline__ EdgeEval setup_edges(const Coverage& cv, int ix, int iy, int W, int H) {
+    EdgeEval ee;
+    const i64 cx = 8 - 8 * (i64)W, cy = 8 - 8 * (i64)H;
+    i64 Px = 16 * (i64)ix + cx, Py = 16 * (i64)iy + cy;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int j = (k == 2) ? 0 : k + 1;
+        i64 dX = (i64)cv.X[j] - cv.X[k], dY = (i64)cv.Y[j] - cv.Y[k];
+        bool tl = (dY < 0) || (dY == 0 && dX < 0);
+        ee.e[k] = dX * (Py - cv.Y[k]) - dY * (Px - cv.X[k]) - (tl ? 0 : 1);
+        ee.sx[k] = -16 * dY;
+        ee.sy[k] = 16 * dX;
+    }
+    return ee;
+}
+
+// projective barycentric numerators at NDC (fx, fy) from the unsnapped parent triangle
+__device__ __forceinline__ void eval_pixel(const float4 p[3], float fx, float fy, float& a0, float& a1, float& a2) {
+    float p0x = p[0].x - fx * p[0].w, p0y = p[0].y - fy * p[0].w;
+    float p1x = p[1].x - fx * p[1].w, p1y = p[1].y - fy * p[1].w;
+    float p2x = p[2].x - fx * p[2].w, p2y = p[2].y - fy * p[2].w;
+    a0 = p1x * p2y - p1y * p2x;
+    a1 = p2x * p0y - p2y * p0x;
+    a2 = p0x * p1y - p0y * p1x;
+}
+
+__device__ __forceinline__ float eval_zw(const float4 p[3], float a0, float a1, float a2) {
+    float z = (p[0].z * a0 + p[1].z * a1) + p[2].z * a2;
+    float w = (p[0].w * a0 + p[1].w * a1) + p[2].w * a2;
+    return z / w;
+}
+
+// ---- antialias pair analysis (restates nvdiffrast's AntialiasFwdMeshKernel body) --------------------------------
+
+__device__ __forceinline__ bool rational_gt(float n0, float n1, float d0, float d1) {
+    float l = n0 * d1, r = n1 * d0;
+    bool flip = (d0 < 0.f) != (d1 < 0.f);
+    return flip ? (l < r) : (l > r);
+}
+
+__device__ __forceinline__ int max_idx3(float n0, float n1, float n2, float d0, float d1, float d2) {
+    bool g10 = rational_gt(n1, n0, d1, d0);
+    bool g20 = rational_gt(n2, n0, d2, d0);
+    bool g21 = rational_gt(n2, n1, d2, d1);
+    if (g20 && g21) return 2;
+    if (g10) return 1;
+    return 0;
+}
+
+struct AAPair {
+    bool found;
+    int di;      // edge of the chosen triangle: 0 = v1-v2, 1 = v2-v0, 2 = v0-v1
+    int tri1;    // chosen triangle belongs to the neighbour pixel
+    float alpha;
+};
+
+// p[3]: chosen triangle's clip vertices; o[3]: opposite vertices across edge k (== p[k] when there is none).
+// (px,py) is the pixel the chosen triangle was rasterized into, d = 0 horizontal pair / 1 vertical pair,
+// chose0 = the chosen triangle is pixel0's.
+__device__ __forceinline__ AAPair aa_analyze(const float4 p[3], const float4 o[3], int px, int py, int d, bool chose0,
+                                             int W, int H) {
+    AAPair r;
+    r.found = false;
+    r.di = 0;
+    r.tri1 = chose0 ? 0 : 1;
+    r.alpha = 0.f;
+    float xh = .5f * (float)W, yh = .5f * (float)H;
+    float w0 = 1.f / p[0].w, w1 = 1.f / p[1].w, w2 = 1.f / p[2].w;
+    float ow0 = 1.f / o[0].w, ow1 = 1.f / o[1].w, ow2 = 1.f / o[2].w;
+    float fx = (float)px + .5f - xh;
+    float fy = (float)py + .5f - yh;
+    float x0 = p[0].x * w0 * xh - fx, y0 = p[0].y * w0 * yh - fy;
+    float x1 = p[1].x * w1 * xh - fx, y1 = p[1].y * w1 * yh - fy;
+    float x2 = p[2].x * w2 * xh - fx, y2 = p[2].y * w2 * yh - fy;
+    float ox0 = o[0].x * ow0 * xh - fx, oy0 = o[0].y * ow0 * yh - fy;
+    float ox1 = o[1].x * ow1 * xh - fx, oy1 = o[1].y * ow1 * yh - fy;
+    float ox2 = o[2].x * ow2 * xh - fx, oy2 = o[2].y * ow2 * yh - fy;
+
+    float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    float a0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
+    float a1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
+    float a2 = (x0 - ox2) * (y1 - oy2) - (x1 - ox2) * (y0 - oy2);
+    bool s0 = same_sign(a0, bb), s1 = same_sign(a1, bb), s2 = same_sign(a2, bb);
+    if (!(s0 || s1 || s2)) return r;
+
+    if (d) {
+        float s;
+        s = x0; x0 = y0; y0 = s;
+        s = x1; x1 = y1; y1 = s;
+        s = x2; x2 = y2; y2 = s;
+    }
+    float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
+    float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
+    const float F32_MAX = 3.402823466e+38f;
+    float dc = -F32_MAX;
+    float ds = chose0 ? 1.f : -1.f;
+    float d0 = ds * (x1 * dy0 - y1 * dx0);
+    float d1 = ds * (x2 * dy1 - y2 * dx1);
+    float d2 = ds * (x0 * dy2 - y0 * dx2);
+    if (same_sign(y1, y2)) { d0 = -F32_MAX; dy0 = 1.f; }
+    if (same_sign(y2, y0)) { d1 = -F32_MAX; dy1 = 1.f; }
+    if (same_sign(y0, y1)) { d2 = -F32_MAX; dy2 = 1.f; }
+    int di = max_idx3(d0, d1, d2, dy0, dy1, dy2);
+    if (di == 0 && s0 && fabsf(dy0) >= fabsf(dx0)) dc = d0 / dy0;
+    if (di == 1 && s1 && fabsf(dy1) >= fabsf(dx1)) dc = d1 / dy1;
+    if (di == 2 && s2 && fabsf(dy2) >= fabsf(dx2)) dc = d2 / dy2;
+    const float eps = .0625f;
+    if (dc > -eps && dc < 1.f + eps) {
+        dc = fminf(fmaxf(dc, 0.f), 1.f);
+        r.found = true;
+        r.di = di;
+        r.alpha = ds * (.5f - dc);
+    }
+    return r;
+}
+
+// Position gradient of a blended pair for the two vertices of the crossing edge; dd = sum_c dy_c * (c1_c - c0_c).
+// p1, p2: clip-space positions of the edge's vertices; (px,py): chosen pixel; g1/g2 = (d/dx, d/dy, d/dw).
+__device__ __forceinline__ void aa_pos_grad(float4 p1, float4 p2, int px, int py, int d, float alpha, float dd, int W,
+                                            int H, float g1[3], float g2[3]) {
+    float pxh = .5f * (float)W, pyh = .5f * (float)H;
+    float fx = (float)px + .5f - pxh;
+    float fy = (float)py + .5f - pyh;
+    if (d) {
+        float s;
+        s = p1.x; p1.x = p1.y; p1.y = s;
+        s = p2.x; p2.x = p2.y; p2.y = s;
+        s = pxh; pxh = pyh; pyh = s;
+        s = fx; fx = fy; fy = s;
+    }
+    float w1 = 1.f / p1.w, w2 = 1.f / p2.w;
+    float x1 = p1.x * w1 * pxh - fx, y1 = p1.y * w1 * pyh - fy;
+    float x2 = p2.x * w2 * pxh - fx, y2 = p2.y * w2 * pyh - fy;
+    float dx = x2 - x1, dy = y2 - y1;
+    float db = x1 * dy - y1 * dx;
+    float ep = copysignf(1e-3f, dy);
+    float iy = 1.f / (dy + ep);
+    float dby = db * iy;
+    float iw1 = -w1 * iy * dd;
+    float iw2 = w2 * iy * dd;
+    float gp1x = iw1 * pxh * y2;
+    float gp2x = iw2 * pxh * y1;
+    float gp1y = iw1 * pyh * (dby - x2);
+    float gp2y = iw2 * pyh * (dby - x1);
+    float gp1w = -(p1.x * gp1x + p1.y * gp1y) * w1;
+    float gp2w = -(p2.x * gp2x + p2.y * gp2y) * w2;
+    if (d) {
+        float s;
+        s = gp1x; gp1x = gp1y; gp1y = s;
+        s = gp2x; gp2x = gp2y; gp2y = s;
+    }
+    if (fabsf(alpha) >= 0.5f) {
+        gp1x = gp1y = gp1w = 0.f;
+        gp2x = gp2y = gp2w = 0.f;
+    }
+    g1[0] = gp1x; g1[1] = gp1y; g1[2] = gp1w;
+    g2[0] = gp2x; g2[1] = gp2y; g2[2] = gp2w;
+}
+
+// ---- wave helpers ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace ehr

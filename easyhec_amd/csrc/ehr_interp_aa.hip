@@ -1,0 +1,383 @@
+// ehr_interp_aa.hip -- drop-in dr.interpolate (nvdiffrast_renderer.py:42) and dr.antialias (:43), fwd + bwd,
+// plus the edge-topology build that replaces dr.antialias_construct_topology_hash.
+#include <algorithm>
+
+#include "ehr_device.h"
+#include "ehr_host.h"
+
+namespace ehr {
+
+// ---- interpolate -------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) interp_fwd_kernel(const float* __restrict__ attr, const float4* __restrict__ rast,
+                                                         const int32_t* __restrict__ tri, int B, int Ba, int V, int T,
+                                                         int A, size_t P, float* __restrict__ out) {
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P * B) return;
+    int b = (int)(pix / P);
+    float4 r = rast[pix];
+    int t = float_to_tri(r.w) - 1;
+    float* o = out + pix * A;
+    bool ok = t >= 0 && t < T;
+    int v0 = 0, v1 = 0, v2 = 0;
+    if (ok) {
+        v0 = tri[3 * t];
+        v1 = tri[3 * t + 1];
+        v2 = tri[3 * t + 2];
+        ok = (unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V;
+    }
+    if (!ok) {
+        for (int k = 0; k < A; k++) o[k] = 0.f;
+        return;
+    }
+    const float* ab = attr + (Ba == 1 ? 0 : (size_t)b * V * A);
+    float b0 = r.x, b1 = r.y;
+    float b2 = (1.f - b0) - b1;
+    for (int k = 0; k < A; k++)
+        o[k] = fmaf(b2, ab[(size_t)v2 * A + k], fmaf(b1, ab[(size_t)v1 * A + k], b0 * ab[(size_t)v0 * A + k]));
+}
+
+__global__ void __launch_bounds__(256) interp_grad_kernel(const float* __restrict__ attr, const float4* __restrict__ rast,
+                                                          const int32_t* __restrict__ tri, const float* __restrict__ dy,
+                                                          int B, int Ba, int V, int T, int A, size_t P,
+                                                          float* __restrict__ grad_attr, float4* __restrict__ grad_rast) {
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P * B) return;
+    int b = (int)(pix / P);
+    float4 r = rast[pix];
+    int t = float_to_tri(r.w) - 1;
+    float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t >= 0 && t < T) {
+        int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+        if ((unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V) {
+            size_t aoff = (Ba == 1 ? 0 : (size_t)b * V * A);
+            float b0 = r.x, b1 = r.y;
+            float b2 = (1.f - b0) - b1;
+            float g0 = 0.f, g1 = 0.f;
+            for (int k = 0; k < A; k++) {
+                float d = dy[pix * A + k];
+                float a0 = attr[aoff + (size_t)v0 * A + k], a1 = attr[aoff + (size_t)v1 * A + k],
+                      a2 = attr[aoff + (size_t)v2 * A + k];
+                if (d != 0.f) {
+                    atomicAdd(&grad_attr[aoff + (size_t)v0 * A + k], b0 * d);
+                    atomicAdd(&grad_attr[aoff + (size_t)v1 * A + k], b1 * d);
+                    atomicAdd(&grad_attr[aoff + (size_t)v2 * A + k], b2 * d);
+                }
+                g0 += d * (a0 - a2);
+                g1 += d * (a1 - a2);
+            }
+            gr.x = g0;
+            gr.y = g1;
+        }
+    }
+    grad_rast[pix] = gr;
+}
+
+// ---- topology ----------------------------------------------------------------------------------------------------
+// Open-addressing hash of undirected edges.  Each slot keeps the two smallest record ids (3*t + k) that contain
+// the edge, so the result equals "the first two triangles in index order" regardless of insertion order.
+
+struct EdgeSlot {
+    u64 key;        // (min(va,vb) << 32 | max(va,vb)) + 1, 0 = empty
+    unsigned r0;    // smallest record id
+    unsigned r1;    // second smallest record id
+};
+
+__device__ __forceinline__ unsigned edge_hash(u64 k, unsigned mask) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (unsigned)k & mask;
+}
+
+__device__ __forceinline__ u64 edge_key(const int32_t* tri, int t, int k, int& vopp) {
+    int v[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    int va = v[(k + 1) % 3], vb = v[(k + 2) % 3];
+    vopp = v[k];
+    if (va == vb) return 0;
+    unsigned lo = (unsigned)min(va, vb), hi = (unsigned)max(va, vb);
+    return (((u64)lo << 32) | hi) + 1;
+}
+
+// pass 0: claim slot + r0 = min record; pass 1: r1 = min record != r0; pass 2: resolve opp
+__global__ void __launch_bounds__(256) topo_kernel(const int32_t* __restrict__ tri, int T, EdgeSlot* __restrict__ tab,
+                                                   unsigned mask, int pass, int32_t* __restrict__ opp) {
+    int rec = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rec >= 3 * T) return;
+    int t = rec / 3, k = rec - 3 * t;
+    int vopp;
+    u64 key = edge_key(tri, t, k, vopp);
+    if (key == 0) {
+        if (pass == 2) opp[rec] = -1;
+        return;
+    }
+    unsigned h = edge_hash(key, mask);
+    for (;;) {
+        u64 cur = tab[h].key;
+        if (cur == 0 && pass == 0) {
+            u64 prev = atomicCAS(&tab[h].key, 0ull, key);
+            cur = (prev == 0) ? key : prev;
+        }
+        if (cur == key) break;
+        if (cur == 0) {  // cannot happen after pass 0; never spin forever
+            if (pass == 2) opp[rec] = -1;
+            return;
+        }
+        h = (h + 1) & mask;
+    }
+    if (pass == 0) {
+        atomicMin(&tab[h].r0, (unsigned)rec);
+    } else if (pass == 1) {
+        if (tab[h].r0 != (unsigned)rec) atomicMin(&tab[h].r1, (unsigned)rec);
+    } else {
+        unsigned r0 = tab[h].r0, r1 = tab[h].r1;
+        int s0 = tri[r0], s1 = (r1 != 0xffffffffu) ? tri[r1] : -1;  // tri[3t+k] is the record's opposite vertex
+        int r = -1;
+        if (s0 == vopp)
+            r = s1;
+        else if (s1 == vopp)
+            r = s0;
+        opp[rec] = r;
+    }
+}
+
+__global__ void topo_init_kernel(EdgeSlot* tab, unsigned n) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        tab[i].key = 0;
+        tab[i].r0 = 0xffffffffu;
+        tab[i].r1 = 0xffffffffu;
+    }
+}
+
+static unsigned topo_slots(int T) {
+    unsigned need = (unsigned)std::max(3 * (size_t)std::max(T, 1) * 2, (size_t)64);
+    unsigned n = 64;
+    while (n < need) n <<= 1;
+    return n;
+}
+
+// ---- antialias ---------------------------------------------------------------------------------------------------
+
+// work buffer: int4 header {count, 0, 0, 0} followed by int4 items {px, py, flags, alpha bits}
+// flags: bits 0-1 di, bit 2 d (vertical pair), bit 3 chosen triangle is pixel1's, bit 4 blended, bits 16.. image
+#define AA_FLAG_D 4
+#define AA_FLAG_TRI1 8
+#define AA_FLAG_BLEND 16
+
+__global__ void __launch_bounds__(256) aa_discover_kernel(const float4* __restrict__ rast, int B, int H, int W,
+                                                          int4* __restrict__ work) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t P = (size_t)H * W;
+    bool in = idx < P * B;
+    int b = 0, px = 0, py = 0;
+    bool hit0 = false, hit1 = false;
+    if (in) {
+        b = (int)(idx / P);
+        int rem = (int)(idx - (size_t)b * P);
+        py = rem / W;
+        px = rem - py * W;
+        float t0 = rast[idx].w;
+        if (px + 1 < W) hit0 = rast[idx + 1].w != t0;
+        if (py + 1 < H) hit1 = rast[idx + W].w != t0;
+    }
+    // wave-level compaction: ballot + prefix popcount, one atomic per wave
+    u64 m0 = __ballot(hit0), m1 = __ballot(hit1);
+    int n0 = __popcll(m0), n1 = __popcll(m1);
+    int lane = lane_id();
+    int base = 0;
+    if (lane == 0 && (n0 + n1) > 0) base = atomicAdd(&work[0].x, n0 + n1);
+    base = __shfl(base, 0, 64);
+    u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (hit0) work[1 + base + __popcll(m0 & below)] = make_int4(px, py, b << 16, 0);
+    if (hit1) work[1 + base + n0 + __popcll(m1 & below)] = make_int4(px, py, (b << 16) | AA_FLAG_D, 0);
+}
+
+__global__ void __launch_bounds__(256) aa_mesh_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
+                                                      const float4* __restrict__ pos, const int32_t* __restrict__ tri,
+                                                      const int32_t* __restrict__ opp, int range_mode, int V, int T,
+                                                      int H, int W, int C, float* __restrict__ out,
+                                                      int4* __restrict__ work) {
+    const int count = work[0].x;
+    size_t P = (size_t)H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        int4 item = work[1 + i];
+        int px = item.x, py = item.y, b = item.z >> 16, d = (item.z & AA_FLAG_D) ? 1 : 0;
+        size_t pix0 = (size_t)b * P + (size_t)py * W + px;
+        size_t pix1 = pix0 + (d ? (size_t)W : 1);
+        float4 r0 = rast[pix0], r1 = rast[pix1];
+        int tri0 = float_to_tri(r0.w) - 1, tri1 = float_to_tri(r1.w) - 1;
+        int t = (tri0 >= 0) ? tri0 : tri1;
+        if (tri0 >= 0 && tri1 >= 0) t = (r0.z < r1.z) ? tri0 : tri1;
+        bool chose0 = !(t == tri1);
+        int cx = px, cy = py;
+        if (!chose0) {
+            cx += 1 - d;
+            cy += d;
+        }
+        if (t < 0 || t >= T) continue;
+        int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+        if ((unsigned)vi[0] >= (unsigned)V || (unsigned)vi[1] >= (unsigned)V || (unsigned)vi[2] >= (unsigned)V) continue;
+        const float4* pb = pos + (range_mode ? 0 : (size_t)b * V);
+        float4 p[3], o[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p[k] = pb[vi[k]];
+            int ov = opp[3 * t + k];
+            o[k] = ((unsigned)ov < (unsigned)V) ? pb[ov] : p[k];
+        }
+        AAPair a = aa_analyze(p, o, cx, cy, d, chose0, W, H);
+        if (!a.found) continue;
+        const float* c0 = color + pix0 * C;
+        const float* c1 = color + pix1 * C;
+        float* dst = out + (a.alpha > 0.f ? pix0 : pix1) * C;
+        for (int k = 0; k < C; k++) atomicAdd(&dst[k], a.alpha * (c1[k] - c0[k]));
+        item.z |= a.di | (a.tri1 ? AA_FLAG_TRI1 : 0) | AA_FLAG_BLEND;
+        item.w = __float_as_int(a.alpha);
+        work[1 + i] = item;
+    }
+}
+
+__global__ void __launch_bounds__(256) aa_grad_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
+                                                      const float4* __restrict__ pos, const int32_t* __restrict__ tri,
+                                                      const float* __restrict__ dy, const int4* __restrict__ work,
+                                                      int range_mode, int V, int T, int H, int W, int C,
+                                                      float* __restrict__ grad_color, float* __restrict__ grad_pos) {
+    const int count = work[0].x;
+    size_t P = (size_t)H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        int4 item = work[1 + i];
+        if (!(item.z & AA_FLAG_BLEND)) continue;
+        float alpha = __int_as_float(item.w);
+        if (alpha == 0.f) continue;
+        int px = item.x, py = item.y, b = item.z >> 16, d = (item.z & AA_FLAG_D) ? 1 : 0;
+        int di = item.z & 3;
+        bool tri1 = (item.z & AA_FLAG_TRI1) != 0;
+        size_t pix0 = (size_t)b * P + (size_t)py * W + px;
+        size_t pix1 = pix0 + (d ? (size_t)W : 1);
+        const float* c0 = color + pix0 * C;
+        const float* c1 = color + pix1 * C;
+        const float* g = dy + (alpha > 0.f ? pix0 : pix1) * C;
+        float dd = 0.f;
+        for (int k = 0; k < C; k++) {
+            float gk = g[k];
+            if (gk != 0.f) {
+                dd += gk * (c1[k] - c0[k]);
+                float v = alpha * gk;
+                atomicAdd(&grad_color[pix0 * C + k], -v);
+                atomicAdd(&grad_color[pix1 * C + k], v);
+            }
+        }
+        if (dd == 0.f) continue;
+        int t = float_to_tri(rast[tri1 ? pix1 : pix0].w) - 1;
+        if (t < 0 || t >= T) continue;
+        int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+        int i1 = (di < 2) ? di + 1 : 0;
+        int i2 = (i1 < 2) ? i1 + 1 : 0;
+        int v1 = vi[i1], v2 = vi[i2];
+        if ((unsigned)v1 >= (unsigned)V || (unsigned)v2 >= (unsigned)V) continue;
+        size_t voff = range_mode ? 0 : (size_t)b * V;
+        int cx = px, cy = py;
+        if (tri1) {
+            cx += 1 - d;
+            cy += d;
+        }
+        float g1[3], g2[3];
+        aa_pos_grad(pos[voff + v1], pos[voff + v2], cx, cy, d, alpha, dd, W, H, g1, g2);
+        float* gp = grad_pos + 4 * voff;
+        atomicAdd(&gp[4 * v1 + 0], g1[0]); atomicAdd(&gp[4 * v1 + 1], g1[1]); atomicAdd(&gp[4 * v1 + 3], g1[2]);
+        atomicAdd(&gp[4 * v2 + 0], g2[0]); atomicAdd(&gp[4 * v2 + 1], g2[1]); atomicAdd(&gp[4 * v2 + 3], g2[2]);
+    }
+}
+
+}  // namespace ehr
+
+using namespace ehr;
+
+extern "C" {
+
+int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int B, int Ba, int V, int T, int A,
+                        int H, int W, float* out, void* stream_) {
+    if (!attr || !rast || !tri || !out) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: NULL tensor");
+    if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: attr batch %d must be 1 or %d", Ba, B);
+    size_t P = (size_t)H * W, n = P * B;
+    if (n == 0) return EHR_OK;
+    interp_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(attr, (const float4*)rast, tri, B, Ba,
+                                                                                  V, T, A, P, out);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba, int V,
+                         int T, int A, int H, int W, float* grad_attr, float* grad_rast, void* stream_) {
+    if (!attr || !rast || !tri || !dy || !grad_attr || !grad_rast)
+        return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: NULL tensor");
+    if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: attr batch %d must be 1 or %d", Ba, B);
+    size_t P = (size_t)H * W, n = P * B;
+    if (n == 0) return EHR_OK;
+    interp_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(
+        attr, (const float4*)rast, tri, dy, B, Ba, V, T, A, P, grad_attr, (float4*)grad_rast);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+size_t ehr_topology_scratch_bytes(int T) { return (size_t)topo_slots(T) * sizeof(EdgeSlot); }
+
+int ehr_antialias_topology(const int32_t* tri, int T, int32_t* opp, void* scratch, size_t scratch_bytes, void* stream_) {
+    if (!tri || !opp || !scratch) return fail(EHR_ERR_INVALID, "ehr_antialias_topology: NULL tensor");
+    unsigned n = topo_slots(T);
+    if (scratch_bytes < (size_t)n * sizeof(EdgeSlot))
+        return fail(EHR_ERR_INVALID, "ehr_antialias_topology: scratch too small (%zu < %zu)", scratch_bytes,
+                    (size_t)n * sizeof(EdgeSlot));
+    if (T <= 0) return EHR_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    EdgeSlot* tab = (EdgeSlot*)scratch;
+    topo_init_kernel<<<(n + 255) / 256, 256, 0, stream>>>(tab, n);
+    EHR_LAUNCH_CHECK();
+    unsigned grid = (unsigned)((3 * (size_t)T + 255) / 256);
+    for (int pass = 0; pass < 3; pass++) {
+        topo_kernel<<<grid, 256, 0, stream>>>(tri, T, tab, n - 1, pass, opp);
+        EHR_LAUNCH_CHECK();
+    }
+    return EHR_OK;
+}
+
+size_t ehr_antialias_work_bytes(int B, int H, int W) { return ((size_t)2 * B * H * W + 1) * sizeof(int4); }
+
+int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                      int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work, void* stream_) {
+    if (!color || !rast || !pos || !tri || !opp || !out || !work)
+        return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: NULL tensor");
+    if (B >= 32768) return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: batch too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t n = (size_t)B * H * W;
+    if (n == 0) return EHR_OK;
+    if (out != color)
+        EHR_HIP(hipMemcpyAsync(out, color, n * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    EHR_HIP(hipMemsetAsync(work, 0, sizeof(int4), stream));
+    aa_discover_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)rast, B, H, W, (int4*)work);
+    EHR_LAUNCH_CHECK();
+    aa_mesh_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp, range_mode, V, T,
+                                             H, W, C, out, (int4*)work);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+int ehr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
+                       const void* work, int range_mode, int B, int V, int T, int H, int W, int C, float* grad_color,
+                       float* grad_pos, void* stream_) {
+    if (!color || !rast || !pos || !tri || !dy || !work || !grad_color || !grad_pos)
+        return fail(EHR_ERR_INVALID, "ehr_antialias_grad: NULL tensor");
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t n = (size_t)B * H * W;
+    if (n == 0) return EHR_OK;
+    EHR_HIP(hipMemcpyAsync(grad_color, dy, n * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    aa_grad_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, dy, (const int4*)work,
+                                             range_mode, V, T, H, W, C, grad_color, grad_pos);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+// ehr_raster.hip -- drop-in dr.rasterize forward/backward (nvdiffrast_renderer.py:39) + context management.
+#include <stdarg.h>
+
+#include <algorithm>
+
+#include "ehr_host.h"
+#include "ehr_raster_core.h"
+
+namespace ehr {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int Scratch::reserve(size_t bytes) {
+    if (bytes <= cap) return EHR_OK;
+    if (ptr) {
+        EHR_HIP(hipDeviceSynchronize());
+        EHR_HIP(hipFree(ptr));
+        ptr = nullptr;
+        cap = 0;
+    }
+    size_t want = std::max(bytes, (size_t)4096);
+    EHR_HIP(hipMalloc(&ptr, want));
+    cap = want;
+    return EHR_OK;
+}
+
+void Scratch::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+}
+
+// ---- drop-in rasterize tile kernel -------------------------------------------------------------------------------
+
+// One workgroup per (image, tile).  LDS: 256 x 8-byte keys.  Writes rast (and rast_db) for every pixel of the tile.
+template <bool WITH_DB>
+__global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(PosSource src, BinGeom g,
+                                                                      const int* __restrict__ counts,
+                                                                      const int* __restrict__ offsets,
+                                                                      const int* __restrict__ entries, int entries_cap,
+                                                                      float4* __restrict__ rast,
+                                                                      float4* __restrict__ rast_db) {
+    __shared__ u64 key[EHR_TILE_W * EHR_TILE_H];
+    const int tile = blockIdx.x, b = blockIdx.y;
+    const int tx = tile % g.ntx, ty = tile / g.ntx;
+    const int rx0 = tx * EHR_TILE_W, ry0 = ty * EHR_TILE_H;
+    const int tid = threadIdx.x;
+    key[tid] = ~0ull;
+    const int kidx = b * g.nt + tile;
+    const int n = counts[kidx];
+    const int off = offsets[kidx];
+    __syncthreads();
+    for (int base = 0; base < n; base += EHR_TILE_THREADS) {
+        int i = base + tid;
+        bool active = i < n && off + i < entries_cap;
+        float4 p[3];
+        int t = 0, link;
+        if (active) {
+            t = entries[off + i];
+            active = src.fetch(b, t, p, link);
+        }
+        raster_wave<EHR_TILE_W, EHR_TILE_H, 12>(active, p, t, g.W, g.H, rx0, ry0, key);
+    }
+    __syncthreads();
+    // shade: one thread per pixel
+    const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
+    const int ix = rx0 + lx, iy = ry0 + ly;
+    if (ix >= g.W || iy >= g.H) return;
+    const size_t pix = ((size_t)b * g.H + iy) * g.W + ix;
+    u64 k = key[tid];
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k != ~0ull) {
+        int t = (int)(unsigned)(k & 0xffffffffu);
+        float4 p[3];
+        int link;
+        src.fetch(b, t, p, link);
+        const float xs = 2.f / (float)g.W, xo = 1.f / (float)g.W - 1.f;
+        const float ys = 2.f / (float)g.H, yo = 1.f / (float)g.H - 1.f;
+        float fx = (float)ix * xs + xo;
+        float fy = (float)iy * ys + yo;
+        float a0, a1, a2;
+        eval_pixel(p, fx, fy, a0, a1, a2);
+        float at = (a0 + a1) + a2;
+        float iw = 1.f / at;
+        float b0 = sat01(a0 * iw);
+        float b1 = sat01(a1 * iw);
+        float zw = eval_zw(p, a0, a1, a2);
+        zw = fmaxf(fminf(zw, 1.f), -1.f);
+        out = make_float4(b0, b1, zw, tri_to_float(t + 1));
+        if (WITH_DB) {
+            float dfxdx = xs * iw;
+            float dfydy = ys * iw;
+            float da0dx = p[2].y * p[1].w - p[1].y * p[2].w;
+            float da0dy = p[1].x * p[2].w - p[2].x * p[1].w;
+            float da1dx = p[0].y * p[2].w - p[2].y * p[0].w;
+            float da1dy = p[2].x * p[0].w - p[0].x * p[2].w;
+            float da2dx = p[1].y * p[0].w - p[0].y * p[1].w;
+            float da2dy = p[0].x * p[1].w - p[1].x * p[0].w;
+            float datdx = (da0dx + da1dx) + da2dx;
+            float datdy = (da0dy + da1dy) + da2dy;
+            db.x = dfxdx * (b0 * datdx - da0dx);
+            db.y = dfydy * (b0 * datdy - da0dy);
+            db.z = dfxdx * (b1 * datdx - da1dx);
+            db.w = dfydy * (b1 * datdy - da1dy);
+        }
+    }
+    rast[pix] = out;
+    if (WITH_DB) rast_db[pix] = db;
+}
+
+// ---- rasterize backward ------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) raster_grad_kernel(const float4* __restrict__ pos, const int32_t* __restrict__ tri,
+                                                          const float4* __restrict__ rast,
+                                                          const float4* __restrict__ dy, int range_mode, int B, int V,
+                                                          int T, int H, int W, float* __restrict__ grad_pos) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t P = (size_t)H * W;
+    if (idx >= P * B) return;
+    int b = (int)(idx / P);
+    int rem = (int)(idx - (size_t)b * P);
+    int iy = rem / W, ix = rem - iy * W;
+    float4 r = rast[idx];
+    int t = float_to_tri(r.w) - 1;
+    if (t < 0 || t >= T) return;
+    float4 g = dy[idx];
+    if (g.x == 0.f && g.y == 0.f) return;
+    int vi0 = tri[3 * t], vi1 = tri[3 * t + 1], vi2 = tri[3 * t + 2];
+    if ((unsigned)vi0 >= (unsigned)V || (unsigned)vi1 >= (unsigned)V || (unsigned)vi2 >= (unsigned)V) return;
+    size_t voff = range_mode ? 0 : (size_t)b * V;
+    float4 p0 = pos[voff + vi0], p1 = pos[voff + vi1], p2 = pos[voff + vi2];
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    float fx = (float)ix * xs + xo;
+    float fy = (float)iy * ys + yo;
+    float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+    float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+    float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+    float a0 = p1x * p2y - p1y * p2x;
+    float a1 = p2x * p0y - p2y * p0x;
+    float a2 = p0x * p1y - p0y * p1x;
+    float at = (a0 + a1) + a2;
+    float ep = copysignf(1e-6f, at);
+    float iw = 1.f / (at + ep);
+    float b0 = a0 * iw, b1 = a1 * iw;
+    float gb0 = g.x * iw, gb1 = g.y * iw;
+    float gbb = gb0 * b0 + gb1 * b1;
+    float gp0x = gbb * (p2y - p1y) - gb1 * p2y;
+    float gp1x = gbb * (p0y - p2y) + gb0 * p2y;
+    float gp2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+    float gp0y = gbb * (p1x - p2x) + gb1 * p2x;
+    float gp1y = gbb * (p2x - p0x) - gb0 * p2x;
+    float gp2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+    float gp0w = -fx * gp0x - fy * gp0y;
+    float gp1w = -fx * gp1x - fy * gp1y;
+    float gp2w = -fx * gp2x - fy * gp2y;
+    float* gp = grad_pos + 4 * voff;
+    atomicAdd(&gp[4 * vi0 + 0], gp0x); atomicAdd(&gp[4 * vi0 + 1], gp0y); atomicAdd(&gp[4 * vi0 + 3], gp0w);
+    atomicAdd(&gp[4 * vi1 + 0], gp1x); atomicAdd(&gp[4 * vi1 + 1], gp1y); atomicAdd(&gp[4 * vi1 + 3], gp1w);
+    atomicAdd(&gp[4 * vi2 + 0], gp2x); atomicAdd(&gp[4 * vi2 + 1], gp2y); atomicAdd(&gp[4 * vi2 + 3], gp2w);
+}
+
+}  // namespace ehr
+
+using namespace ehr;
+
+// ---- C ABI -------------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int ehr_version(void) { return 1; }
+
+const char* ehr_last_error(void) { return g_last_error.c_str(); }
+
+int ehr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* ehr_device_arch(int dev) {
+    static thread_local char arch[256];
+    hipDeviceProp_t prop;
+    arch[0] = 0;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) snprintf(arch, sizeof(arch), "%s", prop.gcnArchName);
+    return arch;
+}
+
+int ehr_ctx_create(int device, ehr_ctx** out) {
+    if (!out) return fail(EHR_ERR_INVALID, "ehr_ctx_create: out is NULL");
+    int n = ehr_device_count();
+    if (device < 0 || device >= n) return fail(EHR_ERR_INVALID, "ehr_ctx_create: device %d out of range (%d visible)", device, n);
+    int cur = 0;
+    EHR_HIP(hipGetDevice(&cur));
+    EHR_HIP(hipSetDevice(device));
+    ehr_ctx* c = new ehr_ctx();
+    c->device = device;
+    hipError_t e = hipHostMalloc((void**)&c->host_pinned, 4 * sizeof(int), hipHostMallocDefault);
+    (void)hipSetDevice(cur);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(EHR_ERR_HIP, "hipHostMalloc failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return EHR_OK;
+}
+
+int ehr_ctx_destroy(ehr_ctx* c) {
+    if (!c) return EHR_OK;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(c->device);
+    c->counts.release();
+    c->offsets.release();
+    c->entries.release();
+    c->tile_part.release();
+    c->tile_list.release();
+    if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    (void)hipSetDevice(cur);
+    delete c;
+    return EHR_OK;
+}
+
+int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
+                      int T, int H, int W, float* rast, float* rast_db, void* stream_) {
+    if (!ctx) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: ctx is NULL");
+    if (!pos || !tri || !rast) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: NULL tensor");
+    if (B <= 0 || V < 0 || T < 0 || H <= 0 || W <= 0) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: bad sizes");
+    if (H > 32768 || W > 32768) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: resolution above 32768 is unsupported");
+    hipStream_t stream = (hipStream_t)stream_;
+    BinGeom g;
+    g.W = W;
+    g.H = H;
+    g.ntx = (W + EHR_TILE_W - 1) / EHR_TILE_W;
+    g.nty = (H + EHR_TILE_H - 1) / EHR_TILE_H;
+    g.nt = g.ntx * g.nty;
+    g.L = 1;
+    const int nkeys = B * g.nt;
+    int rc;
+    if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + 4 + (ranges_host ? 2 * (size_t)B : 0)) * sizeof(int)))) return rc;
+    if ((rc = ctx->offsets.reserve((size_t)nkeys * sizeof(int)))) return rc;
+    if (ctx->entries_cap == 0) {
+        size_t want = std::max((size_t)1 << 20, (size_t)B * (size_t)std::max(T, 1) * 2);
+        if ((rc = ctx->entries.reserve(want * sizeof(int)))) return rc;
+        ctx->entries_cap = want;
+    }
+    int* counts = (int*)ctx->counts.ptr;
+    int* cursors = counts + nkeys;
+    int* meta = counts + 2 * nkeys;
+    int* offsets = (int*)ctx->offsets.ptr;
+    int2* ranges_dev = nullptr;
+    int tmax = T;
+    if (ranges_host) {
+        ranges_dev = (int2*)(meta + 4);
+        EHR_HIP(hipMemcpyAsync(ranges_dev, ranges_host, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+        tmax = 0;
+        for (int b = 0; b < B; b++) tmax = std::max(tmax, ranges_host[2 * b + 1]);
+        tmax = std::min(tmax, T);
+    }
+    PosSource src;
+    src.pos = (const float4*)pos;
+    src.tri = tri;
+    src.ranges = ranges_dev;
+    src.V = V;
+    src.T = T;
+    src.instance = ranges_host ? 0 : 1;
+
+    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 4) * sizeof(int), stream));
+    dim3 bgrid((tmax + 255) / 256, B);
+    if (tmax > 0) {
+        bin_kernel<PosSource, 0, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
+        EHR_LAUNCH_CHECK();
+    }
+    bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nkeys, meta);
+    EHR_LAUNCH_CHECK();
+    // size read-back (the one synchronisation of this op): grow the queue storage if this frame needs more
+    EHR_HIP(hipMemcpyAsync(ctx->host_pinned, meta, sizeof(int), hipMemcpyDeviceToHost, stream));
+    EHR_HIP(hipStreamSynchronize(stream));
+    size_t total = (size_t)ctx->host_pinned[0];
+    if (total > ctx->entries_cap) {
+        size_t want = total + total / 2;
+        if ((rc = ctx->entries.reserve(want * sizeof(int)))) return rc;
+        ctx->entries_cap = want;
+    }
+    int* entries = (int*)ctx->entries.ptr;
+    if (tmax > 0) {
+        bin_kernel<PosSource, 0, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries,
+                                                                 (int)std::min(ctx->entries_cap, (size_t)0x7fffffff), meta);
+        EHR_LAUNCH_CHECK();
+    }
+    dim3 tgrid(g.nt, B);
+    int ecap = (int)std::min(ctx->entries_cap, (size_t)0x7fffffff);
+    if (rast_db)
+        raster_tile_kernel<true><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, counts, offsets, entries, ecap,
+                                                                        (float4*)rast, (float4*)rast_db);
+    else
+        raster_tile_kernel<false><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, counts, offsets, entries, ecap,
+                                                                         (float4*)rast, nullptr);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+int ehr_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, const float* dy, int range_mode, int B,
+                       int V, int T, int H, int W, float* grad_pos, void* stream_) {
+    if (!pos || !tri || !rast || !dy || !grad_pos) return fail(EHR_ERR_INVALID, "ehr_rasterize_grad: NULL tensor");
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t n = (size_t)B * H * W;
+    if (n == 0) return EHR_OK;
+    raster_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)pos, tri, (const float4*)rast,
+                                                                        (const float4*)dy, range_mode, B, V, T, H, W,
+                                                                        grad_pos);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+"""Drop-in for the four ``nvdiffrast.torch`` entry points EasyHeC uses, backed by hand-written HIP kernels.
+
+The reference does ``import nvdiffrast.torch as dr`` and calls
+(/root/reference/easyhec/structures/nvdiffrast_renderer.py):
+
+    dr.RasterizeCudaContext()                              :23
+    dr.rasterize(glctx, pos, tri, resolution=[H, W])       :39, :64
+    dr.interpolate(attr, rast, tri)                        :42, :67
+    dr.antialias(color, rast, pos, tri)                    :43, :68
+
+``import easyhec_amd.dr as dr`` gives the same names, positional order, return tuples and autograd behaviour.
+Everything runs through the C ABI of include/ehr.h (libehr_hip.so); tensors must live on a HIP device -- there is no
+CPU or PyTorch fallback, a missing library or a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = ["RasterizeCudaContext", "RasterizeGLContext", "rasterize", "interpolate", "antialias",
+           "antialias_construct_topology_hash", "TopologyHash"]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_dev(name, t, dtype):
+    _require(isinstance(t, torch.Tensor), f"{name} must be a torch.Tensor")
+    _require(t.is_cuda, f"{name} must be a CUDA/HIP tensor (easyhec_amd has no CPU path)")
+    _require(t.dtype == dtype, f"{name} must have dtype {dtype}, got {t.dtype}")
+
+
+class RasterizeCudaContext:
+    """Replaces ``dr.RasterizeCudaContext(device=None)``: owns the rasterizer's binning scratch on one device."""
+
+    def __init__(self, device=None):
+        _require(torch.cuda.is_available(), "RasterizeCudaContext: no HIP device is available")
+        if device is None:
+            idx = torch.cuda.current_device()
+        else:
+            dev = torch.device(device)
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.device_index = idx
+        self.device = torch.device("cuda", idx)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib().ehr_ctx_create(idx, ctypes.byref(handle)), "ehr_ctx_create")
+        self._h = handle
+        self._plan = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().ehr_ctx_destroy(h)
+            except Exception:
+                pass
+
+
+# nvdiffrast's OpenGL context plays the same role; there is no GL on this path, the HIP rasterizer serves both.
+RasterizeGLContext = RasterizeCudaContext
+
+
+class _RasterizeFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, glctx, pos, tri, resolution, ranges, grad_db):
+        H, W = int(resolution[0]), int(resolution[1])
+        if ranges is None:
+            B, V = pos.shape[0], pos.shape[1]
+            rptr = None
+        else:
+            B, V = ranges.shape[0], pos.shape[0]
+            ranges = ranges.contiguous()
+            rptr = ctypes.c_void_p(ranges.data_ptr())
+        T = tri.shape[0]
+        rast = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device)
+        db = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device) if grad_db else None
+        with torch.cuda.device(pos.device):
+            _lib.check(_lib.lib().ehr_rasterize_fwd(glctx.handle, _lib.ptr(pos), _lib.ptr(tri), rptr, B, V, T, H, W,
+                                                    _lib.ptr(rast), _lib.ptr(db), _stream()), "rasterize")
+        if db is None:
+            db = torch.empty((B, H, W, 0), dtype=torch.float32, device=pos.device)
+        ctx.save_for_backward(pos, tri, rast)
+        ctx.range_mode = ranges is not None
+        ctx.mark_non_differentiable(db)
+        return rast, db
+
+    @staticmethod
+    def backward(ctx, dy, ddb):
+        pos, tri, rast = ctx.saved_tensors
+        B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+        V, T = pos.shape[-2], tri.shape[0]
+        g = torch.zeros_like(pos)
+        dy = dy.contiguous()
+        with torch.cuda.device(pos.device):
+            _lib.check(_lib.lib().ehr_rasterize_grad(_lib.ptr(pos), _lib.ptr(tri), _lib.ptr(rast), _lib.ptr(dy),
+                                                     int(ctx.range_mode), B, V, T, H, W, _lib.ptr(g), _stream()),
+                       "rasterize backward")
+        return None, g, None, None, None, None
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
+    """``dr.rasterize``: pos [B,V,4] (instance mode) or [V,4] with ``ranges`` [B,2] int32 CPU tensor (range mode);
+    tri [T,3] int32; resolution (H, W).  Returns ``(rast [B,H,W,4] = (u, v, z/w, triangle_id + 1), rast_db)``.
+
+    ``rast_db`` holds the screen-space derivatives of (u, v) when ``grad_db`` is set (its backward is not
+    propagated: EasyHeC never consumes it, nvdiffrast_renderer.py:39 discards it)."""
+    _require(isinstance(glctx, RasterizeCudaContext), "glctx must be a RasterizeCudaContext")
+    _check_dev("pos", pos, torch.float32)
+    _check_dev("tri", tri, torch.int32)
+    _require(len(resolution) == 2, "resolution must be [height, width]")
+    _require(tri.dim() == 2 and tri.shape[1] == 3, "tri must have shape [>0, 3]")
+    _require(int(resolution[0]) > 0 and int(resolution[1]) > 0, "resolution must be [>0, >0]")
+    _require(pos.device.index == glctx.device_index, "pos must be on the context's device")
+    if ranges is None:
+        _require(pos.dim() == 3 and pos.shape[0] > 0 and pos.shape[2] == 4,
+                 "instance mode - pos must have shape [>0, >0, 4]")
+    else:
+        _require(pos.dim() == 2 and pos.shape[1] == 4, "range mode - pos must have shape [>0, 4]")
+        _require(isinstance(ranges, torch.Tensor) and not ranges.is_cuda and ranges.dtype == torch.int32 and
+                 ranges.dim() == 2 and ranges.shape[1] == 2,
+                 "range mode - ranges must be a CPU int32 tensor with shape [>0, 2]")
+    return _RasterizeFunc.apply(glctx, pos.contiguous(), tri.contiguous(), resolution, ranges, bool(grad_db))
+
+
+class _InterpolateFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri):
+        B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+        Ba, V, A = attr.shape
+        out = torch.empty((B, H, W, A), dtype=torch.float32, device=rast.device)
+        with torch.cuda.device(rast.device):
+            _lib.check(_lib.lib().ehr_interpolate_fwd(_lib.ptr(attr), _lib.ptr(rast), _lib.ptr(tri), B, Ba, V,
+                                                      tri.shape[0], A, H, W, _lib.ptr(out), _stream()), "interpolate")
+        ctx.save_for_backward(attr, rast, tri)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        attr, rast, tri = ctx.saved_tensors
+        B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+        Ba, V, A = attr.shape
+        g_attr = torch.zeros_like(attr)
+        g_rast = torch.empty_like(rast)
+        dy = dy.contiguous()
+        with torch.cuda.device(rast.device):
+            _lib.check(_lib.lib().ehr_interpolate_grad(_lib.ptr(attr), _lib.ptr(rast), _lib.ptr(tri), _lib.ptr(dy), B,
+                                                       Ba, V, tri.shape[0], A, H, W, _lib.ptr(g_attr),
+                                                       _lib.ptr(g_rast), _stream()), "interpolate backward")
+        return g_attr, g_rast, None
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """``dr.interpolate``: attr [B or 1, V, A] (or [V, A] in range mode), rast from :func:`rasterize`, tri [T,3].
+    Returns ``(out [B,H,W,A], out_da)``; ``out_da`` is an empty tensor (attribute pixel derivatives are not on
+    EasyHeC's path: nvdiffrast_renderer.py:42 passes neither ``rast_db`` nor ``diff_attrs``)."""
+    _check_dev("attr", attr, torch.float32)
+    _check_dev("rast", rast, torch.float32)
+    _check_dev("tri", tri, torch.int32)
+    if diff_attrs is not None or rast_db is not None:
+        raise NotImplementedError("interpolate: attribute pixel differentials (rast_db / diff_attrs) are not "
+                                  "implemented; the EasyHeC path never requests them")
+    _require(rast.dim() == 4 and rast.shape[3] == 4, "rast must have shape [>0, >0, >0, 4]")
+    _require(tri.dim() == 2 and tri.shape[1] == 3, "tri must have shape [>0, 3]")
+    if attr.dim() == 2:
+        attr = attr[None]
+    _require(attr.dim() == 3, "attr must have shape [>0, >0, >0] or [>0, >0]")
+    _require(attr.shape[0] in (1, rast.shape[0]), "attr batch must be 1 or match rast")
+    out = _InterpolateFunc.apply(attr.contiguous(), rast.contiguous(), tri.contiguous())
+    out_da = torch.empty((out.shape[0], out.shape[1], out.shape[2], 0), dtype=torch.float32, device=out.device)
+    return out, out_da
+
+
+class TopologyHash:
+    """Result of :func:`antialias_construct_topology_hash`: the opposite vertex across every triangle edge."""
+
+    def __init__(self, opp, num_triangles):
+        self.opp = opp
+        self.num_triangles = num_triangles
+
+
+def antialias_construct_topology_hash(tri):
+    """``dr.antialias_construct_topology_hash(tri)``: build once per mesh, pass as ``topology_hash=``."""
+    _check_dev("tri", tri, torch.int32)
+    _require(tri.dim() == 2 and tri.shape[1] == 3, "tri must have shape [>0, 3]")
+    tri = tri.contiguous()
+    T = tri.shape[0]
+    lib = _lib.lib()
+    opp = torch.empty((T, 3), dtype=torch.int32, device=tri.device)
+    nbytes = lib.ehr_topology_scratch_bytes(T)
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=tri.device)
+    with torch.cuda.device(tri.device):
+        _lib.check(lib.ehr_antialias_topology(_lib.ptr(tri), T, _lib.ptr(opp), _lib.ptr(scratch), nbytes, _stream()),
+                   "antialias_construct_topology_hash")
+    return TopologyHash(opp, T)
+
+
+class _AntialiasFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, opp, boost):
+        B, H, W, C = color.shape
+        V, T = pos.shape[-2], tri.shape[0]
+        range_mode = int(pos.dim() == 2)
+        lib = _lib.lib()
+        out = torch.empty_like(color)
+        work = torch.empty((lib.ehr_antialias_work_bytes(B, H, W),), dtype=torch.uint8, device=color.device)
+        with torch.cuda.device(color.device):
+            _lib.check(lib.ehr_antialias_fwd(_lib.ptr(color), _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri),
+                                             _lib.ptr(opp), range_mode, B, V, T, H, W, C, _lib.ptr(out),
+                                             _lib.ptr(work), _stream()), "antialias")
+        ctx.save_for_backward(color, rast, pos, tri, work)
+        ctx.boost = float(boost)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        color, rast, pos, tri, work = ctx.saved_tensors
+        B, H, W, C = color.shape
+        V, T = pos.shape[-2], tri.shape[0]
+        range_mode = int(pos.dim() == 2)
+        dy = dy.contiguous()
+        g_color = torch.empty_like(color)
+        g_pos = torch.zeros_like(pos)
+        with torch.cuda.device(color.device):
+            _lib.check(_lib.lib().ehr_antialias_grad(_lib.ptr(color), _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri),
+                                                     _lib.ptr(dy), _lib.ptr(work), range_mode, B, V, T, H, W, C,
+                                                     _lib.ptr(g_color), _lib.ptr(g_pos), _stream()),
+                       "antialias backward")
+        if ctx.boost != 1.0:
+            g_pos = g_pos * ctx.boost
+        return g_color, None, g_pos, None, None, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    """``dr.antialias``: blends across silhouette edges so that coverage becomes differentiable w.r.t. ``pos``.
+    Without ``topology_hash`` the edge topology is rebuilt on every call, as nvdiffrast does
+    (nvdiffrast_renderer.py:43 passes none)."""
+    _check_dev("color", color, torch.float32)
+    _check_dev("rast", rast, torch.float32)
+    _check_dev("pos", pos, torch.float32)
+    _check_dev("tri", tri, torch.int32)
+    _require(color.dim() == 4 and color.shape[3] > 0, "color must have shape [>0, >0, >0, >0]")
+    _require(rast.dim() == 4 and rast.shape[3] == 4 and rast.shape[:3] == color.shape[:3],
+             "rast must have shape [B, H, W, 4] matching color")
+    _require(tri.dim() == 2 and tri.shape[1] == 3, "tri must have shape [>0, 3]")
+    _require((pos.dim() == 3 and pos.shape[2] == 4 and pos.shape[0] == color.shape[0]) or
+             (pos.dim() == 2 and pos.shape[1] == 4), "pos must have shape [B, >0, 4] or [>0, 4]")
+    tri = tri.contiguous()
+    if topology_hash is None:
+        topology_hash = antialias_construct_topology_hash(tri)
+    _require(isinstance(topology_hash, TopologyHash) and topology_hash.num_triangles == tri.shape[0],
+             "topology_hash does not belong to tri")
+    return _AntialiasFunc.apply(color.contiguous(), rast.contiguous(), pos.contiguous(), tri, topology_hash.opp,
+                                pos_gradient_boost)

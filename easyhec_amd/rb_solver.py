@@ -1,0 +1,122 @@
+"""``RBSolver`` -- the rendering-based pose solver, mirroring
+/root/reference/easyhec/modeling/models/rb_solve/rb_solver.py:15-96 (constructor, ``forward(dps)`` and its
+``(output, loss_dict)`` return, metrics, ``history_ops`` / ``dof`` state-dict names).
+
+forward(dps) consumes the dataset tensors of /root/reference/easyhec/data/datasets/xarm_real.py:69-84
+(``mask [B,H,W]``, ``link_poses [B,L,4,4]``, ``K [B,3,3]``, ``Tc_c2b [B,4,4]``) and renders every frame x link.
+With ``use_fused`` (default) the whole double loop + loss is one HIP kernel chain; with ``use_fused=False`` it is the
+reference's own per-(frame, link) sequence of rasterize / interpolate / antialias calls."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import fused
+from .mesh_io import load_mesh
+from .renderer import NVDiffrastRenderer
+from .se3 import se3_exp_map, se3_log_map
+
+__all__ = ["RBSolver"]
+
+
+class RBSolver(nn.Module):
+    def __init__(self, cfg, meshes=None):
+        """cfg: :class:`easyhec_amd.config.Cfg` (fields of defaults.py ``model.rbsolver``).
+        meshes: optional list of (vertices [V,3], faces [T,3]) replacing ``cfg.model.rbsolver.mesh_paths``."""
+        super().__init__()
+        self.total_cfg = cfg
+        self.cfg = cfg.model.rbsolver
+        self.dbg = cfg.dbg
+        if meshes is None:
+            meshes = [load_mesh(p) for p in self.cfg.mesh_paths]
+        for link_idx, (vertices, faces) in enumerate(meshes):
+            vertices = torch.as_tensor(np.asarray(vertices), dtype=torch.float32)
+            faces = torch.as_tensor(np.asarray(faces), dtype=torch.int32)
+            self.register_buffer(f"vertices_{link_idx}", vertices)
+            self.register_buffer(f"faces_{link_idx}", faces)
+        self.nlinks = len(meshes)
+        # camera parameters (rb_solver.py:30-34)
+        init_Tc_c2b = torch.as_tensor(np.asarray(self.cfg.init_Tc_c2b), dtype=torch.float32)
+        init_dof = se3_log_map(init_Tc_c2b[None].permute(0, 2, 1), eps=1e-5, backend="opencv")[0]
+        self.dof = nn.Parameter(init_dof, requires_grad=True)
+        self.H, self.W = self.cfg.H, self.cfg.W
+        self.renderer = None  # created on first forward, on the parameters' device (needs a HIP device)
+        self._scene = None
+        self.register_buffer("history_ops", torch.zeros(10000, 6))
+        self._hist_n = 0
+
+    # -- device-side lazies -------------------------------------------------------------------------------------
+    def _ensure_renderer(self):
+        dev = self.dof.device
+        if self.renderer is None or self.renderer.device != dev:
+            if dev.type != "cuda":
+                raise RuntimeError("RBSolver renders on a HIP device only: move the module with .cuda() first "
+                                   "(there is no CPU render path)")
+            self.renderer = NVDiffrastRenderer([self.H, self.W], device=dev)
+            self._scene = None
+        return self.renderer
+
+    def _ensure_scene(self):
+        if self._scene is None:
+            vs = [getattr(self, f"vertices_{i}") for i in range(self.nlinks)]
+            fs = [getattr(self, f"faces_{i}") for i in range(self.nlinks)]
+            self._scene = fused.LinkScene(vs, fs, self.dof.device)
+        return self._scene
+
+    def Tc_c2b(self):
+        return se3_exp_map(self.dof[None]).permute(0, 2, 1)[0]
+
+    # -- forward -------------------------------------------------------------------------------------------------
+    def forward(self, dps, with_outputs=True):
+        assert dps.get("global_step", 0) == 0
+        renderer = self._ensure_renderer()
+        if self._hist_n < self.history_ops.shape[0]:  # rb_solver.py:50-51 without the .item() sync
+            self.history_ops[self._hist_n] = self.dof.detach()
+            self._hist_n += 1
+        Tc_c2b = self.Tc_c2b()
+        masks_ref = dps["mask"]
+        link_poses = dps["link_poses"]
+        K = dps["K"][0]
+        batch_size = masks_ref.shape[0]
+
+        if self.cfg.use_fused:
+            scene = self._ensure_scene()
+            mvp = fused.mvp_matrices(K, self.H, self.W, Tc_c2b, link_poses)
+            rendered, losses = fused.render_mask_loss(renderer.glctx, scene, mvp, masks_ref.float(),
+                                                      want_mask=with_outputs)
+            loss = losses.mean()
+            all_frame_all_link_si = rendered if with_outputs else None
+        else:
+            losses, all_frame_all_link_si = [], []
+            for bid in range(batch_size):
+                all_link_si = []
+                for link_idx in range(self.nlinks):
+                    Tc_c2l = Tc_c2b @ link_poses[bid, link_idx]
+                    verts, faces = getattr(self, f"vertices_{link_idx}"), getattr(self, f"faces_{link_idx}")
+                    si = renderer.render_mask(verts, faces, K=K, object_pose=Tc_c2l)
+                    all_link_si.append(si)
+                all_link_si = torch.stack(all_link_si).sum(0).clamp(max=1)
+                all_frame_all_link_si.append(all_link_si)
+                losses.append(torch.sum((all_link_si - masks_ref[bid].float()) ** 2))
+            loss = torch.stack(losses).mean()
+            all_frame_all_link_si = torch.stack(all_frame_all_link_si)
+
+        output = {}
+        if with_outputs:
+            output = {"rendered_masks": all_frame_all_link_si,
+                      "ref_masks": masks_ref,
+                      "error_maps": (all_frame_all_link_si.detach() - masks_ref.float()).abs()}
+        # metrics (rb_solver.py:79-92): differences of log coordinates, cm and degrees
+        gt_dof6 = dps.get("gt_dof6")
+        if gt_dof6 is None and "Tc_c2b" in dps and with_outputs:
+            gt_Tc_c2b = dps["Tc_c2b"][0]
+            if not torch.allclose(gt_Tc_c2b, torch.eye(4, device=gt_Tc_c2b.device)):
+                gt_dof6 = se3_log_map(gt_Tc_c2b[None].permute(0, 2, 1), backend="opencv")[0]
+        if gt_dof6 is not None:
+            trans_err = ((gt_dof6[:3] - self.dof[:3]) * 100).abs()
+            rot_err = (gt_dof6[3:] - self.dof[3:]).abs().max() / np.pi * 180
+            output["metrics"] = {"err_x": trans_err[0], "err_y": trans_err[1], "err_z": trans_err[2],
+                                 "err_trans": trans_err.norm(), "err_rot": rot_err}
+        if with_outputs:
+            output["tsfm"] = se3_exp_map(self.dof[None].detach().cpu()).permute(0, 2, 1)[0]
+        loss_dict = {"mask_loss": loss}
+        return output, loss_dict

@@ -1,0 +1,66 @@
+"""``NVDiffrastRenderer`` -- same class, constructor and methods as
+/root/reference/easyhec/structures/nvdiffrast_renderer.py:10-72, running on the HIP ops of :mod:`easyhec_amd.dr`.
+
+``render_mask`` / ``batch_render_mask`` follow the reference line by line in *behaviour* (K -> GL projection,
+OpenCV -> GL flip, clip transform, rasterize -> interpolate(ones) -> antialias, channel 0, vertical flip); the only
+host-side differences are that nothing forces a device sync and the edge topology of a face tensor is cached while
+that tensor is alive (the reference rebuilds it on every call because it passes no ``topology_hash``)."""
+import torch
+
+from . import dr
+from .nvdiffrast_utils import K_to_projection, opencv2blender, transform_pos
+
+__all__ = ["NVDiffrastRenderer"]
+
+
+class NVDiffrastRenderer:
+    def __init__(self, image_size, device=None):
+        """image_size: H,W"""
+        self.H, self.W = image_size
+        self.resolution = image_size
+        self.glctx = dr.RasterizeCudaContext(device=device)
+        self.device = self.glctx.device
+        blender2opencv = opencv2blender(device=self.device)
+        self.opencv2blender = torch.inverse(blender2opencv)
+        self._topo = {}  # id(faces) -> (faces, version, TopologyHash); holding `faces` keeps the id valid
+
+    def _topology(self, faces):
+        ent = self._topo.get(id(faces))
+        if ent is None or ent[0] is not faces or ent[1] != faces._version:
+            if len(self._topo) > 64:
+                self._topo.clear()
+            ent = (faces, faces._version, dr.antialias_construct_topology_hash(faces))
+            self._topo[id(faces)] = ent
+        return ent[2]
+
+    def render_mask(self, verts, faces, K, object_pose, anti_aliasing=True):
+        """
+        @param verts: N,3, torch.tensor, float, cuda
+        @param faces: M,3, torch.tensor, int32, cuda
+        @param K: 3,3 torch.tensor, float ,cuda
+        @param object_pose: 4,4 torch.tensor, float, cuda
+        @return: mask: 0 to 1, HxW torch.cuda.FloatTensor
+        """
+        proj = K_to_projection(K, self.H, self.W).to(verts.device)
+        pose = self.opencv2blender @ object_pose
+        pos_clip = transform_pos(proj @ pose, verts)
+        return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
+
+    def batch_render_mask(self, verts, faces, K, anti_aliasing=True):
+        """Vertices already in the camera frame (nvdiffrast_renderer.py:49-72)."""
+        proj = K_to_projection(K, self.H, self.W).to(verts.device)
+        pose = self.opencv2blender
+        pos_clip = transform_pos(proj @ pose, verts)
+        return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
+
+    def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing):
+        rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution)
+        if anti_aliasing:
+            vtx_color = torch.ones(verts.shape, dtype=torch.float, device=verts.device)
+            color, _ = dr.interpolate(vtx_color[None, ...], rast_out, faces)
+            color = dr.antialias(color, rast_out, pos_clip, faces, topology_hash=self._topology(faces))
+            mask = color[0, :, :, 0]
+        else:
+            mask = rast_out[0, :, :, 2] > 0
+        mask = torch.flip(mask, dims=[0])
+        return mask

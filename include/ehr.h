@@ -1,0 +1,108 @@
+/*
+ * ehr.h -- C ABI of libehr_hip.so, the MI355X (gfx950) silhouette-rasterizer behind EasyHeC's mask-render hot path.
+ *
+ * Drop-in boundary: the reference reaches its renderer only through four nvdiffrast.torch entry points
+ *     dr.RasterizeCudaContext()                      /root/reference/easyhec/structures/nvdiffrast_renderer.py:23
+ *     dr.rasterize(glctx, pos, tri, resolution)      .../nvdiffrast_renderer.py:39  (and :64)
+ *     dr.interpolate(attr, rast, tri)                .../nvdiffrast_renderer.py:42  (and :67)
+ *     dr.antialias(color, rast, pos, tri)            .../nvdiffrast_renderer.py:43  (and :68)
+ * nvdiffrast's own torch plugin binds those to C++ functions taking torch tensors; this header is what a
+ * ctypes / pybind stub binds instead (easyhec_amd/_lib.py).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the ctx's / current HIP device unless the name ends in _host;
+ *   - all floats are fp32, all indices int32, tensors are dense row-major ("contiguous");
+ *   - every call enqueues on `stream` (a hipStream_t; NULL = the null stream) and never blocks, EXCEPT where a
+ *     function's comment says "synchronises";
+ *   - return value: 0 = ok, negative = error; ehr_last_error() returns the message for the calling thread;
+ *   - image rows follow nvdiffrast (row 0 = bottom) for the three drop-in ops; the fused op takes and returns
+ *     images in the reference's final convention (row 0 = top, i.e. after nvdiffrast_renderer.py:47's flip).
+ */
+#ifndef EHR_H
+#define EHR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EHR_OK 0
+#define EHR_ERR_INVALID (-1)   /* bad argument */
+#define EHR_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define EHR_ERR_OVERFLOW (-3)  /* internal work buffer overflow (reported, never silent) */
+
+typedef struct ehr_ctx ehr_ctx;
+
+/* library / device --------------------------------------------------------------------------------------------- */
+int ehr_version(void);                 /* ABI version, currently 1 */
+const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
+int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
+const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+
+/* replaces dr.RasterizeCudaContext() -- nvdiffrast_renderer.py:23.  Owns binning scratch, grown on demand. */
+int ehr_ctx_create(int device, ehr_ctx** out);
+int ehr_ctx_destroy(ehr_ctx* ctx);
+
+/* replaces dr.rasterize -- nvdiffrast_renderer.py:39.
+ * instance mode (ranges_host == NULL): pos [B,V,4], every image draws all T triangles.
+ * range mode: pos [V,4], image b draws triangles ranges_host[2b] .. +ranges_host[2b+1] (HOST int32 [B,2]).
+ * rast [B,H,W,4] = (u, v, z/w, triangle_id+1); rast_db [B,H,W,4] = (du/dx, du/dy, dv/dx, dv/dy) or NULL.
+ * Synchronises once (reads back the bin-queue size to grow scratch if needed), like nvdiffrast's own rasterizer. */
+int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
+                      int T, int H, int W, float* rast, float* rast_db, void* stream);
+
+/* backward of dr.rasterize w.r.t. pos through (u,v); dy = grad of rast [B,H,W,4] (z/w and id carry no gradient).
+ * grad_pos (pos's shape) is ACCUMULATED into: the caller zero-fills it. */
+int ehr_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, const float* dy, int range_mode, int B,
+                       int V, int T, int H, int W, float* grad_pos, void* stream);
+
+/* replaces dr.interpolate -- nvdiffrast_renderer.py:42.  attr [Ba,V,A] with Ba == B or 1; out [B,H,W,A]. */
+int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int B, int Ba, int V, int T, int A,
+                        int H, int W, float* out, void* stream);
+/* grad_attr [Ba,V,A] is ACCUMULATED into (caller zero-fills); grad_rast [B,H,W,4] is overwritten. */
+int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba, int V,
+                         int T, int A, int H, int W, float* grad_attr, float* grad_rast, void* stream);
+
+/* replaces dr.antialias_construct_topology_hash(tri).  Writes opp [T,3] int32: for triangle t and edge k
+ * (k=0: v1-v2, k=1: v2-v0, k=2: v0-v1) the third vertex of the other triangle sharing that edge, or -1.
+ * scratch: ehr_topology_scratch_bytes(T) bytes of device memory. */
+size_t ehr_topology_scratch_bytes(int T);
+int ehr_antialias_topology(const int32_t* tri, int T, int32_t* opp, void* scratch, size_t scratch_bytes, void* stream);
+
+/* replaces dr.antialias -- nvdiffrast_renderer.py:43.  color/out [B,H,W,C]; pos [B,V,4] or [V,4] (range_mode).
+ * work: ehr_antialias_work_bytes(B,H,W) bytes, filled by fwd and consumed by grad (nvdiffrast's work buffer). */
+size_t ehr_antialias_work_bytes(int B, int H, int W);
+int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                      int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work, void* stream);
+/* grad_color [B,H,W,C] is overwritten; grad_pos (pos's shape) is ACCUMULATED into (caller zero-fills). */
+int ehr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
+                       const void* work, int range_mode, int B, int V, int T, int H, int W, int C, float* grad_color,
+                       float* grad_pos, void* stream);
+
+/* Fused hot path: what RBSolver.forward + loss.backward() compute per optimisation step
+ * (/root/reference/easyhec/modeling/models/rb_solve/rb_solver.py:60-72 through nvdiffrast_renderer.py:33-47),
+ * for B views x L links in one pass:
+ *     si[b,l]  = flip_y(antialias(interpolate(1, rasterize(MVP[b,l] * verts_l, tri_l))))
+ *     mask[b]  = min(sum_l si[b,l], 1)                 -> mask [B,H,W] (may be NULL)
+ *     loss[b]  = sum_pixels (mask[b] - ref[b])^2       -> loss [B]
+ *     grad_mvp[b,l] = d loss[b] / d MVP[b,l]           -> grad_mvp [B,L,16] (may be NULL: forward only)
+ * Scene = all links concatenated: verts [V,3]; tris [T,3] with GLOBAL vertex indices, sorted by link;
+ * tri_link [T] int32 link of each triangle; opp [T,3] from ehr_antialias_topology on the concatenated mesh
+ * (links share no vertices, so the per-link topology is preserved); vert ranges are implied by the indices.
+ * ehr_fused_plan sizes the ctx scratch for (B,L,T,H,W) and must be called (it synchronises) before the first
+ * ehr_render_mask_loss of that shape; ehr_render_mask_loss itself never synchronises or allocates, so it can be
+ * captured in a hipGraph.  If a bin queue overflows at run time, loss[] is set to NaN (never a silently wrong
+ * image) and ehr_fused_status() returns EHR_ERR_OVERFLOW after the stream is synchronised; re-plan with a larger
+ * `slack`. */
+int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack);
+int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
+                         const int32_t* opp, const float* mvp, const float* ref, int B, int L, int V, int T, int H,
+                         int W, float* mask, float* loss, float* grad_mvp, void* stream);
+int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVERFLOW */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EHR_H */

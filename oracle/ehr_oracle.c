@@ -1,0 +1,888 @@
+/*
+ * ehr_oracle.c -- CPU ORACLE for the EasyHeC mask-render hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (easyhec_amd/) never imports, links or calls anything in oracle/.
+ *
+ * PARITY STATUS: **parity unpinned**.  The arithmetic of this path lives in the third-party package
+ * nvdiffrast (NVlabs), which the reference installs un-pinned from git HEAD
+ * (/root/reference/requirements.txt:29) and which is NOT present in /root/reference; the reference
+ * ships no tests or golden vectors for it.  What follows is a restatement of
+ * nvdiffrast's published algorithm (Laine et al. 2020, "Modular Primitives for High-Performance
+ * Differentiable Rendering", sections 3.2-3.5, and the documented behaviour of nvdiffrast 0.3.x), anchored
+ * on the reference's own call sites:
+ *     dr.rasterize    easyhec/structures/nvdiffrast_renderer.py:39
+ *     dr.interpolate  easyhec/structures/nvdiffrast_renderer.py:42
+ *     dr.antialias    easyhec/structures/nvdiffrast_renderer.py:43
+ *     transform_pos   easyhec/utils/nvdiffrast_utils.py:14-18
+ *     link composite  easyhec/modeling/models/rb_solve/rb_solver.py:60-72
+ * and pinned by analytic known answers + finite differences (tests/test_oracle_*.py).
+ *
+ * Arithmetic contract shared with the HIP kernels -- every float operation below is a
+ * single IEEE-754 binary32 operation, compiled with -ffp-contract=off, fmaf() only where written:
+ *   - coverage: vertices are snapped to 1/16-pixel fixed point (round-half-even), coverage is decided by
+ *     exact integer edge functions at pixel centres with a top-left tie rule, no back-face culling;
+ *   - depth / barycentrics: evaluated in float from the UNSNAPPED clip-space vertices at the pixel centre
+ *     (homogeneous edge functions); nearest z/w wins, ties go to the lower triangle index;
+ *   - rast = (u, v, z/w, tri_id+1), row 0 = bottom (GL convention).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define EHRO_SUBPIX 16 /* 1/16 pixel snapping */
+
+typedef struct {
+    float x, y, z, w;
+} f4;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* small helpers                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+
+static inline float tri_to_float(int x) {
+    if (x <= 0x01000000) return (float)x;
+    int32_t v = 0x4a800000 + x;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+static inline int float_to_tri(float f) {
+    if (f <= 16777216.f) return (int)f;
+    int32_t v;
+    memcpy(&v, &f, 4);
+    return v - 0x4a800000;
+}
+
+static inline uint32_t f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+/* monotone map float -> uint32 (smaller float -> smaller key) */
+static inline uint32_t ord_key(float f) {
+    uint32_t u = f2u(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+static inline float ord_unkey(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+static inline float sat01(float x) { return x > 0.f ? (x < 1.f ? x : 1.f) : 0.f; /* NaN -> 0 */ }
+
+static inline int same_sign(float a, float b) { return (int32_t)(f2u(a) ^ f2u(b)) >= 0; }
+
+static inline int64_t snap_coord(float v, float w, float scale) {
+    float s = v / w;
+    float t = s * scale;
+    if (!(t < 1073741824.f)) t = 1073741824.f; /* also catches NaN */
+    if (t < -1073741824.f) t = -1073741824.f;
+    return (int64_t)rintf(t); /* round half to even (default rounding mode) */
+}
+
+static inline int64_t floor_div16(int64_t a) { return a >> 4; }
+static inline int64_t ceil_div16(int64_t a) { return (a + 15) >> 4; }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* rasterize: one image                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* Near-plane clip of one triangle in homogeneous clip space (Sutherland-Hodgman on d = z + w >= 0).
+ * Returns the number of polygon vertices written to q (0, 3 or 4). */
+static int clip_near(const f4 p[3], f4 q[4]) {
+    int all_in = 1;
+    float d[3];
+    for (int i = 0; i < 3; i++) {
+        d[i] = p[i].z + p[i].w;
+        if (!(p[i].w > 0.f) || !(d[i] >= 0.f)) all_in = 0;
+    }
+    if (all_in) {
+        q[0] = p[0];
+        q[1] = p[1];
+        q[2] = p[2];
+        return 3;
+    }
+    int n = 0;
+    for (int i = 0; i < 3; i++) {
+        int j = (i + 1) % 3;
+        int in_i = d[i] >= 0.f, in_j = d[j] >= 0.f;
+        if (in_i) q[n++] = p[i];
+        if (in_i != in_j) {
+            float t = d[i] / (d[i] - d[j]);
+            f4 r;
+            r.x = p[i].x + t * (p[j].x - p[i].x);
+            r.y = p[i].y + t * (p[j].y - p[i].y);
+            r.z = p[i].z + t * (p[j].z - p[i].z);
+            r.w = p[i].w + t * (p[j].w - p[i].w);
+            q[n++] = r;
+        }
+    }
+    if (n < 3) return 0;
+    for (int i = 0; i < n; i++)
+        if (!(q[i].w > 0.f)) return 0;
+    return n;
+}
+
+/* depth + projective barycentric numerators at a pixel centre, from the UNSNAPPED parent triangle */
+static inline void eval_pixel(const f4 p[3], float fx, float fy, float* a0, float* a1, float* a2) {
+    float p0x = p[0].x - fx * p[0].w;
+    float p0y = p[0].y - fy * p[0].w;
+    float p1x = p[1].x - fx * p[1].w;
+    float p1y = p[1].y - fy * p[1].w;
+    float p2x = p[2].x - fx * p[2].w;
+    float p2y = p[2].y - fy * p[2].w;
+    *a0 = p1x * p2y - p1y * p2x;
+    *a1 = p2x * p0y - p2y * p0x;
+    *a2 = p0x * p1y - p0y * p1x;
+}
+
+static inline float eval_zw(const f4 p[3], float a0, float a1, float a2) {
+    float z = (p[0].z * a0 + p[1].z * a1) + p[2].z * a2;
+    float w = (p[0].w * a0 + p[1].w * a1) + p[2].w * a2;
+    return z / w;
+}
+
+/* Rasterize triangles [t0, t1) of `tri` into the 64-bit key buffer (min of (ord(z/w) << 32 | tri index)).
+ * bbox (x0, y0, x1, y1 inclusive) is grown to the pixels touched; may be NULL. */
+static void raster_image(const float* pos, int V, const int32_t* tri, int t0, int t1, int W, int H, uint64_t* key,
+                         int* bbox) {
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    const float sx = (float)(W * (EHRO_SUBPIX / 2)), sy = (float)(H * (EHRO_SUBPIX / 2));
+    const int64_t cx = 8 - 8 * (int64_t)W, cy = 8 - 8 * (int64_t)H; /* pixel centre: 16*i + c */
+
+    for (int t = t0; t < t1; t++) {
+        int vi0 = tri[3 * t + 0], vi1 = tri[3 * t + 1], vi2 = tri[3 * t + 2];
+        if (vi0 < 0 || vi0 >= V || vi1 < 0 || vi1 >= V || vi2 < 0 || vi2 >= V) continue;
+        f4 p[3];
+        memcpy(&p[0], pos + 4 * (size_t)vi0, 16);
+        memcpy(&p[1], pos + 4 * (size_t)vi1, 16);
+        memcpy(&p[2], pos + 4 * (size_t)vi2, 16);
+        f4 q[4];
+        int n = clip_near(p, q);
+        for (int s = 0; s + 2 < n; s++) {
+            const f4* v[3] = {&q[0], &q[s + 1], &q[s + 2]};
+            int64_t X[3], Y[3];
+            for (int k = 0; k < 3; k++) {
+                X[k] = snap_coord(v[k]->x, v[k]->w, sx);
+                Y[k] = snap_coord(v[k]->y, v[k]->w, sy);
+            }
+            int64_t area2 = (X[1] - X[0]) * (Y[2] - Y[0]) - (X[2] - X[0]) * (Y[1] - Y[0]);
+            if (area2 == 0) continue;
+            if (area2 < 0) { /* orient counter-clockwise (y up) for the coverage test only */
+                int64_t tx = X[1], ty = Y[1];
+                X[1] = X[2];
+                Y[1] = Y[2];
+                X[2] = tx;
+                Y[2] = ty;
+            }
+            int64_t xmin = X[0], xmax = X[0], ymin = Y[0], ymax = Y[0];
+            for (int k = 1; k < 3; k++) {
+                if (X[k] < xmin) xmin = X[k];
+                if (X[k] > xmax) xmax = X[k];
+                if (Y[k] < ymin) ymin = Y[k];
+                if (Y[k] > ymax) ymax = Y[k];
+            }
+            int64_t ix0 = ceil_div16(xmin - cx), ix1 = floor_div16(xmax - cx);
+            int64_t iy0 = ceil_div16(ymin - cy), iy1 = floor_div16(ymax - cy);
+            if (ix0 < 0) ix0 = 0;
+            if (iy0 < 0) iy0 = 0;
+            if (ix1 > W - 1) ix1 = W - 1;
+            if (iy1 > H - 1) iy1 = H - 1;
+            if (ix0 > ix1 || iy0 > iy1) continue;
+            /* edge k: from vertex k to vertex (k+1)%3; E = dX*(Py-Ya) - dY*(Px-Xa); inside if E>0 or tie&top-left */
+            int64_t dX[3], dY[3];
+            int tl[3];
+            for (int k = 0; k < 3; k++) {
+                int j = (k + 1) % 3;
+                dX[k] = X[j] - X[k];
+                dY[k] = Y[j] - Y[k];
+                tl[k] = (dY[k] < 0) || (dY[k] == 0 && dX[k] < 0);
+            }
+            for (int64_t iy = iy0; iy <= iy1; iy++) {
+                int64_t Py = 16 * iy + cy;
+                for (int64_t ix = ix0; ix <= ix1; ix++) {
+                    int64_t Px = 16 * ix + cx;
+                    int inside = 1;
+                    for (int k = 0; k < 3; k++) {
+                        int64_t E = dX[k] * (Py - Y[k]) - dY[k] * (Px - X[k]);
+                        if (!(E > 0 || (E == 0 && tl[k]))) {
+                            inside = 0;
+                            break;
+                        }
+                    }
+                    if (!inside) continue;
+                    float fx = (float)ix * xs + xo;
+                    float fy = (float)iy * ys + yo;
+                    float a0, a1, a2;
+                    eval_pixel(p, fx, fy, &a0, &a1, &a2);
+                    float zw = eval_zw(p, a0, a1, a2);
+                    if (!(zw >= -1.f && zw <= 1.f)) continue;
+                    uint64_t k64 = ((uint64_t)ord_key(zw) << 32) | (uint32_t)t;
+                    size_t pix = (size_t)iy * W + ix;
+                    if (k64 < key[pix]) key[pix] = k64;
+                    if (bbox) {
+                        if (ix < bbox[0]) bbox[0] = (int)ix;
+                        if (iy < bbox[1]) bbox[1] = (int)iy;
+                        if (ix > bbox[2]) bbox[2] = (int)ix;
+                        if (iy > bbox[3]) bbox[3] = (int)iy;
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* per-pixel outputs from the winning triangle (nvdiffrast's "shader" stage) */
+static void shade_pixel(const float* pos, const int32_t* tri, int t, int ix, int iy, int W, int H, float* out4,
+                        float* db4) {
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    f4 p[3];
+    for (int k = 0; k < 3; k++) memcpy(&p[k], pos + 4 * (size_t)tri[3 * t + k], 16);
+    float fx = (float)ix * xs + xo;
+    float fy = (float)iy * ys + yo;
+    float a0, a1, a2;
+    eval_pixel(p, fx, fy, &a0, &a1, &a2);
+    float at = (a0 + a1) + a2;
+    float iw = 1.f / at;
+    float b0 = sat01(a0 * iw);
+    float b1 = sat01(a1 * iw);
+    float zw = eval_zw(p, a0, a1, a2);
+    zw = fmaxf(fminf(zw, 1.f), -1.f);
+    out4[0] = b0;
+    out4[1] = b1;
+    out4[2] = zw;
+    out4[3] = tri_to_float(t + 1);
+    if (db4) {
+        float dfxdx = xs * iw;
+        float dfydy = ys * iw;
+        float da0dx = p[2].y * p[1].w - p[1].y * p[2].w;
+        float da0dy = p[1].x * p[2].w - p[2].x * p[1].w;
+        float da1dx = p[0].y * p[2].w - p[2].y * p[0].w;
+        float da1dy = p[2].x * p[0].w - p[0].x * p[2].w;
+        float da2dx = p[1].y * p[0].w - p[0].y * p[1].w;
+        float da2dy = p[0].x * p[1].w - p[1].x * p[0].w;
+        float datdx = (da0dx + da1dx) + da2dx;
+        float datdy = (da0dy + da1dy) + da2dy;
+        db4[0] = dfxdx * (b0 * datdx - da0dx);
+        db4[1] = dfydy * (b0 * datdy - da0dy);
+        db4[2] = dfxdx * (b1 * datdx - da1dx);
+        db4[3] = dfydy * (b1 * datdy - da1dy);
+    }
+}
+
+/* dr.rasterize forward.  instance mode: pos [B,V,4], every image draws all T triangles.
+ * range mode (ranges != NULL): pos [V,4], image b draws triangles ranges[2b] .. ranges[2b]+ranges[2b+1]. */
+int ehro_rasterize_fwd(const float* pos, const int32_t* tri, const int32_t* ranges, int B, int V, int T, int H, int W,
+                       float* rast, float* rast_db) {
+    size_t P = (size_t)H * W;
+    uint64_t* key = (uint64_t*)malloc(P * sizeof(uint64_t));
+    if (!key) return -1;
+    for (int b = 0; b < B; b++) {
+        const float* pb = ranges ? pos : pos + (size_t)b * V * 4;
+        int t0 = 0, t1 = T;
+        if (ranges) {
+            t0 = ranges[2 * b];
+            t1 = t0 + ranges[2 * b + 1];
+            if (t0 < 0) t0 = 0;
+            if (t1 > T) t1 = T;
+        }
+        memset(key, 0xff, P * sizeof(uint64_t));
+        raster_image(pb, V, tri, t0, t1, W, H, key, NULL);
+        float* rb = rast + (size_t)b * P * 4;
+        float* db = rast_db ? rast_db + (size_t)b * P * 4 : NULL;
+        for (int iy = 0; iy < H; iy++)
+            for (int ix = 0; ix < W; ix++) {
+                size_t pix = (size_t)iy * W + ix;
+                if (key[pix] == UINT64_MAX) {
+                    memset(rb + 4 * pix, 0, 16);
+                    if (db) memset(db + 4 * pix, 0, 16);
+                } else {
+                    int t = (int)(uint32_t)(key[pix] & 0xffffffffu);
+                    shade_pixel(pb, tri, t, ix, iy, W, H, rb + 4 * pix, db ? db + 4 * pix : NULL);
+                }
+            }
+    }
+    free(key);
+    return 0;
+}
+
+/* dr.rasterize backward: d(u,v)/d(pos).  dy = gradient w.r.t. rast [B,H,W,4] (only .x/.y are used; z/w and the
+ * triangle id carry no gradient).  grad_pos has pos's shape and is ACCUMULATED into (caller zeroes). */
+int ehro_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, const float* dy, int range_mode,
+                        int B, int V, int T, int H, int W, float* grad_pos) {
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        const float* pb = range_mode ? pos : pos + (size_t)b * V * 4;
+        float* gb = range_mode ? grad_pos : grad_pos + (size_t)b * V * 4;
+        for (int iy = 0; iy < H; iy++)
+            for (int ix = 0; ix < W; ix++) {
+                size_t pix = (size_t)b * P + (size_t)iy * W + ix;
+                int t = float_to_tri(rast[4 * pix + 3]) - 1;
+                if (t < 0 || t >= T) continue;
+                float gy0 = dy[4 * pix + 0], gy1 = dy[4 * pix + 1];
+                if (gy0 == 0.f && gy1 == 0.f) continue;
+                int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+                if (vi[0] < 0 || vi[0] >= V || vi[1] < 0 || vi[1] >= V || vi[2] < 0 || vi[2] >= V) continue;
+                f4 p[3];
+                for (int k = 0; k < 3; k++) memcpy(&p[k], pb + 4 * (size_t)vi[k], 16);
+                float fx = (float)ix * xs + xo;
+                float fy = (float)iy * ys + yo;
+                float p0x = p[0].x - fx * p[0].w, p0y = p[0].y - fy * p[0].w;
+                float p1x = p[1].x - fx * p[1].w, p1y = p[1].y - fy * p[1].w;
+                float p2x = p[2].x - fx * p[2].w, p2y = p[2].y - fy * p[2].w;
+                float a0 = p1x * p2y - p1y * p2x;
+                float a1 = p2x * p0y - p2y * p0x;
+                float a2 = p0x * p1y - p0y * p1x;
+                float at = (a0 + a1) + a2;
+                float ep = copysignf(1e-6f, at);
+                float iw = 1.f / (at + ep);
+                float b0 = a0 * iw, b1 = a1 * iw;
+                float gb0 = gy0 * iw, gb1 = gy1 * iw;
+                float gbb = gb0 * b0 + gb1 * b1;
+                float gp0x = gbb * (p2y - p1y) - gb1 * p2y;
+                float gp1x = gbb * (p0y - p2y) + gb0 * p2y;
+                float gp2x = gbb * (p1y - p0y) - gb0 * p1y + gb1 * p0y;
+                float gp0y = gbb * (p1x - p2x) + gb1 * p2x;
+                float gp1y = gbb * (p2x - p0x) - gb0 * p2x;
+                float gp2y = gbb * (p0x - p1x) + gb0 * p1x - gb1 * p0x;
+                float gp0w = -fx * gp0x - fy * gp0y;
+                float gp1w = -fx * gp1x - fy * gp1y;
+                float gp2w = -fx * gp2x - fy * gp2y;
+                gb[4 * vi[0] + 0] += gp0x; gb[4 * vi[0] + 1] += gp0y; gb[4 * vi[0] + 3] += gp0w;
+                gb[4 * vi[1] + 0] += gp1x; gb[4 * vi[1] + 1] += gp1y; gb[4 * vi[1] + 3] += gp1w;
+                gb[4 * vi[2] + 0] += gp2x; gb[4 * vi[2] + 1] += gp2y; gb[4 * vi[2] + 3] += gp2w;
+            }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* interpolate                                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* dr.interpolate forward.  attr [Ba,V,A] with Ba == B or Ba == 1 (broadcast); out [B,H,W,A]. */
+int ehro_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int B, int Ba, int V, int T, int A,
+                         int H, int W, float* out) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        const float* ab = attr + (Ba == 1 ? 0 : (size_t)b * V * A);
+        for (size_t i = 0; i < P; i++) {
+            size_t pix = (size_t)b * P + i;
+            float* o = out + pix * A;
+            int t = float_to_tri(rast[4 * pix + 3]) - 1;
+            int ok = t >= 0 && t < T;
+            int v0 = 0, v1 = 0, v2 = 0;
+            if (ok) {
+                v0 = tri[3 * t];
+                v1 = tri[3 * t + 1];
+                v2 = tri[3 * t + 2];
+                ok = v0 >= 0 && v0 < V && v1 >= 0 && v1 < V && v2 >= 0 && v2 < V;
+            }
+            if (!ok) {
+                for (int k = 0; k < A; k++) o[k] = 0.f;
+                continue;
+            }
+            float b0 = rast[4 * pix], b1 = rast[4 * pix + 1];
+            float b2 = (1.f - b0) - b1;
+            for (int k = 0; k < A; k++)
+                o[k] = fmaf(b2, ab[(size_t)v2 * A + k], fmaf(b1, ab[(size_t)v1 * A + k], b0 * ab[(size_t)v0 * A + k]));
+        }
+    }
+    return 0;
+}
+
+/* dr.interpolate backward.  grad_attr [Ba,V,A] and grad_rast [B,H,W,4]; grad_attr is ACCUMULATED (caller zeroes),
+ * grad_rast is overwritten. */
+int ehro_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba,
+                          int V, int T, int A, int H, int W, float* grad_attr, float* grad_rast) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        size_t aoff = (Ba == 1 ? 0 : (size_t)b * V * A);
+        for (size_t i = 0; i < P; i++) {
+            size_t pix = (size_t)b * P + i;
+            float* gr = grad_rast + 4 * pix;
+            gr[0] = gr[1] = gr[2] = gr[3] = 0.f;
+            int t = float_to_tri(rast[4 * pix + 3]) - 1;
+            if (t < 0 || t >= T) continue;
+            int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+            if (v0 < 0 || v0 >= V || v1 < 0 || v1 >= V || v2 < 0 || v2 >= V) continue;
+            float b0 = rast[4 * pix], b1 = rast[4 * pix + 1];
+            float b2 = (1.f - b0) - b1;
+            float g0 = 0.f, g1 = 0.f;
+            for (int k = 0; k < A; k++) {
+                float d = dy[pix * A + k];
+                float a0 = attr[aoff + (size_t)v0 * A + k], a1 = attr[aoff + (size_t)v1 * A + k],
+                      a2 = attr[aoff + (size_t)v2 * A + k];
+                grad_attr[aoff + (size_t)v0 * A + k] += b0 * d;
+                grad_attr[aoff + (size_t)v1 * A + k] += b1 * d;
+                grad_attr[aoff + (size_t)v2 * A + k] += b2 * d;
+                g0 += d * (a0 - a2);
+                g1 += d * (a1 - a2);
+            }
+            gr[0] = g0;
+            gr[1] = g1;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* antialias                                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* Edge -> opposite-vertex topology ("topology hash" in nvdiffrast).  For triangle t and its edge k
+ * (k=0: v1-v2, opposite v0; k=1: v2-v0, opposite v1; k=2: v0-v1, opposite v2) opp[3t+k] is the third vertex of the
+ * OTHER triangle on that edge, or -1.  An edge keeps the opposite vertices of the first two triangles (in index
+ * order) that contain it; lookup returns the stored one that is not the asking triangle's own opposite vertex. */
+typedef struct {
+    int32_t a, b, o, t, k;
+} edge_rec;
+
+static int edge_cmp(const void* pa, const void* pb) {
+    const edge_rec* x = (const edge_rec*)pa;
+    const edge_rec* y = (const edge_rec*)pb;
+    if (x->a != y->a) return x->a < y->a ? -1 : 1;
+    if (x->b != y->b) return x->b < y->b ? -1 : 1;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->k - y->k;
+}
+
+int ehro_topology(const int32_t* tri, int T, int32_t* opp) {
+    edge_rec* e = (edge_rec*)malloc((size_t)3 * T * sizeof(edge_rec));
+    if (!e && T) return -1;
+    for (int t = 0; t < T; t++) {
+        int v[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+        for (int k = 0; k < 3; k++) {
+            int va = v[(k + 1) % 3], vb = v[(k + 2) % 3];
+            edge_rec* r = &e[3 * t + k];
+            r->a = va < vb ? va : vb;
+            r->b = va < vb ? vb : va;
+            r->o = v[k];
+            r->t = t;
+            r->k = k;
+            opp[3 * t + k] = -1;
+        }
+    }
+    qsort(e, (size_t)3 * T, sizeof(edge_rec), edge_cmp);
+    size_t n = (size_t)3 * T;
+    for (size_t i = 0; i < n;) {
+        size_t j = i;
+        while (j < n && e[j].a == e[i].a && e[j].b == e[i].b) j++;
+        if (e[i].a != e[i].b) {
+            /* stored pair: opposite vertices of the first (and second) record of the group */
+            int s0 = e[i].o;
+            int s1 = (j - i >= 2) ? e[i + 1].o : -1;
+            for (size_t m = i; m < j; m++) {
+                int vr = e[m].o, r = -1;
+                if (s0 == vr)
+                    r = s1;
+                else if (s1 == vr)
+                    r = s0;
+                opp[3 * e[m].t + e[m].k] = r;
+            }
+        }
+        i = j;
+    }
+    free(e);
+    return 0;
+}
+
+/* n0/d0 > n1/d1 without dividing */
+static inline int rational_gt(float n0, float n1, float d0, float d1) {
+    float l = n0 * d1, r = n1 * d0;
+    int flip = (d0 < 0.f) != (d1 < 0.f);
+    return flip ? (l < r) : (l > r);
+}
+
+static inline int max_idx3(float n0, float n1, float n2, float d0, float d1, float d2) {
+    int g10 = rational_gt(n1, n0, d1, d0);
+    int g20 = rational_gt(n2, n0, d2, d0);
+    int g21 = rational_gt(n2, n1, d2, d1);
+    if (g20 && g21) return 2;
+    if (g10) return 1;
+    return 0;
+}
+
+typedef struct {
+    int found;   /* edge crossing found: the pair blends */
+    int di;      /* which edge of the chosen triangle (0: v1-v2, 1: v2-v0, 2: v0-v1) */
+    int tri1;    /* 1 if the chosen (nearer) triangle is the neighbour pixel's */
+    int tri;     /* chosen triangle */
+    float alpha; /* blend weight, sign selects the destination pixel */
+} aa_pair;
+
+/* Analyse the pixel pair (px,py) / (px+1-d, py+d).  zt0/zt1 = (z/w, tri_id+1 as float) of the two pixels. */
+static aa_pair aa_analyze(const float* pos, const int32_t* tri, const int32_t* opp, int V, int T, int W, int H, int px,
+                          int py, int d, float zw0, float ft0, float zw1, float ft1) {
+    aa_pair r;
+    memset(&r, 0, sizeof(r));
+    int tri0 = float_to_tri(ft0) - 1;
+    int tri1 = float_to_tri(ft1) - 1;
+    int t = (tri0 >= 0) ? tri0 : tri1;
+    if (tri0 >= 0 && tri1 >= 0) t = (zw0 < zw1) ? tri0 : tri1;
+    if (t == tri1) {
+        px += 1 - d;
+        py += d;
+    }
+    if (t < 0 || t >= T) return r;
+    int vi0 = tri[3 * t], vi1 = tri[3 * t + 1], vi2 = tri[3 * t + 2];
+    if (vi0 < 0 || vi0 >= V || vi1 < 0 || vi1 >= V || vi2 < 0 || vi2 >= V) return r;
+    int op0 = opp[3 * t + 0], op1 = opp[3 * t + 1], op2 = opp[3 * t + 2];
+    f4 p0, p1, p2, o0, o1, o2;
+    memcpy(&p0, pos + 4 * (size_t)vi0, 16);
+    memcpy(&p1, pos + 4 * (size_t)vi1, 16);
+    memcpy(&p2, pos + 4 * (size_t)vi2, 16);
+    o0 = p0;
+    o1 = p1;
+    o2 = p2;
+    if (op0 >= 0 && op0 < V) memcpy(&o0, pos + 4 * (size_t)op0, 16);
+    if (op1 >= 0 && op1 < V) memcpy(&o1, pos + 4 * (size_t)op1, 16);
+    if (op2 >= 0 && op2 < V) memcpy(&o2, pos + 4 * (size_t)op2, 16);
+
+    float xh = .5f * (float)W, yh = .5f * (float)H;
+    float w0 = 1.f / p0.w, w1 = 1.f / p1.w, w2 = 1.f / p2.w;
+    float ow0 = 1.f / o0.w, ow1 = 1.f / o1.w, ow2 = 1.f / o2.w;
+    float fx = (float)px + .5f - xh;
+    float fy = (float)py + .5f - yh;
+    float x0 = p0.x * w0 * xh - fx, y0 = p0.y * w0 * yh - fy;
+    float x1 = p1.x * w1 * xh - fx, y1 = p1.y * w1 * yh - fy;
+    float x2 = p2.x * w2 * xh - fx, y2 = p2.y * w2 * yh - fy;
+    float ox0 = o0.x * ow0 * xh - fx, oy0 = o0.y * ow0 * yh - fy;
+    float ox1 = o1.x * ow1 * xh - fx, oy1 = o1.y * ow1 * yh - fy;
+    float ox2 = o2.x * ow2 * xh - fx, oy2 = o2.y * ow2 * yh - fy;
+
+    /* signs to kill non-silhouette edges */
+    float bb = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    float a0 = (x1 - ox0) * (y2 - oy0) - (x2 - ox0) * (y1 - oy0);
+    float a1 = (x2 - ox1) * (y0 - oy1) - (x0 - ox1) * (y2 - oy1);
+    float a2 = (x0 - ox2) * (y1 - oy2) - (x1 - ox2) * (y0 - oy2);
+    if (!(same_sign(a0, bb) || same_sign(a1, bb) || same_sign(a2, bb))) return r;
+
+    if (d) { /* XY flip for vertical pairs */
+        float s;
+        s = x0; x0 = y0; y0 = s;
+        s = x1; x1 = y1; y1 = s;
+        s = x2; x2 = y2; y2 = s;
+    }
+    float dx0 = x2 - x1, dx1 = x0 - x2, dx2 = x1 - x0;
+    float dy0 = y2 - y1, dy1 = y0 - y2, dy2 = y1 - y0;
+
+    float dc = -FLT_MAX;
+    float ds = (t == tri0) ? 1.f : -1.f;
+    float d0 = ds * (x1 * dy0 - y1 * dx0);
+    float d1 = ds * (x2 * dy1 - y2 * dx1);
+    float d2 = ds * (x0 * dy2 - y0 * dx2);
+    if (same_sign(y1, y2)) d0 = -FLT_MAX, dy0 = 1.f;
+    if (same_sign(y2, y0)) d1 = -FLT_MAX, dy1 = 1.f;
+    if (same_sign(y0, y1)) d2 = -FLT_MAX, dy2 = 1.f;
+
+    int di = max_idx3(d0, d1, d2, dy0, dy1, dy2);
+    if (di == 0 && same_sign(a0, bb) && fabsf(dy0) >= fabsf(dx0)) dc = d0 / dy0;
+    if (di == 1 && same_sign(a1, bb) && fabsf(dy1) >= fabsf(dx1)) dc = d1 / dy1;
+    if (di == 2 && same_sign(a2, bb) && fabsf(dy2) >= fabsf(dx2)) dc = d2 / dy2;
+    const float eps = .0625f; /* expect no more than 1/16 pixel inaccuracy */
+    if (dc > -eps && dc < 1.f + eps) {
+        dc = fminf(fmaxf(dc, 0.f), 1.f);
+        r.found = 1;
+        r.di = di;
+        r.tri1 = (t == tri0) ? 0 : 1;
+        r.tri = t;
+        r.alpha = ds * (.5f - dc);
+    }
+    return r;
+}
+
+/* dr.antialias forward.  color/out [B,H,W,C]; rast [B,H,W,4]; pos [B,V,4] (instance) or [V,4] (range mode);
+ * opp from ehro_topology.  Contributions are applied in pixel-index order, horizontal pair before vertical. */
+int ehro_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                       int range_mode, int B, int V, int T, int H, int W, int C, float* out) {
+    size_t P = (size_t)H * W;
+    memcpy(out, color, (size_t)B * P * C * sizeof(float));
+    for (int b = 0; b < B; b++) {
+        const float* pb = range_mode ? pos : pos + (size_t)b * V * 4;
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++) {
+                size_t pix0 = (size_t)b * P + (size_t)py * W + px;
+                for (int d = 0; d < 2; d++) {
+                    if (d == 0 && px + 1 >= W) continue;
+                    if (d == 1 && py + 1 >= H) continue;
+                    size_t pix1 = pix0 + (d ? (size_t)W : 1);
+                    float ft0 = rast[4 * pix0 + 3], ft1 = rast[4 * pix1 + 3];
+                    if (ft0 == ft1) continue;
+                    aa_pair a = aa_analyze(pb, tri, opp, V, T, W, H, px, py, d, rast[4 * pix0 + 2], ft0,
+                                           rast[4 * pix1 + 2], ft1);
+                    if (!a.found) continue;
+                    const float* c0 = color + pix0 * C;
+                    const float* c1 = color + pix1 * C;
+                    float* o = out + (a.alpha > 0.f ? pix0 : pix1) * C;
+                    for (int i = 0; i < C; i++) o[i] += a.alpha * (c1[i] - c0[i]);
+                }
+            }
+    }
+    return 0;
+}
+
+/* position-gradient of one blended pair: writes gp1 / gp2 = (d/dx, d/dy, d/dw) for the two edge vertices */
+static void aa_pos_grad(const float* pos, const int32_t* tri, int W, int H, int px, int py, int d, const aa_pair* a,
+                        float dd, int* v1, int* v2, float g1[3], float g2[3]) {
+    if (a->tri1) {
+        px += 1 - d;
+        py += d;
+    }
+    int vi[3] = {tri[3 * a->tri], tri[3 * a->tri + 1], tri[3 * a->tri + 2]};
+    int i1 = (a->di < 2) ? a->di + 1 : 0;
+    int i2 = (i1 < 2) ? i1 + 1 : 0;
+    *v1 = vi[i1];
+    *v2 = vi[i2];
+    f4 p1, p2;
+    memcpy(&p1, pos + 4 * (size_t)*v1, 16);
+    memcpy(&p2, pos + 4 * (size_t)*v2, 16);
+    float pxh = .5f * (float)W, pyh = .5f * (float)H;
+    float fx = (float)px + .5f - pxh;
+    float fy = (float)py + .5f - pyh;
+    if (d) {
+        float s;
+        s = p1.x; p1.x = p1.y; p1.y = s;
+        s = p2.x; p2.x = p2.y; p2.y = s;
+        s = pxh; pxh = pyh; pyh = s;
+        s = fx; fx = fy; fy = s;
+    }
+    float w1 = 1.f / p1.w, w2 = 1.f / p2.w;
+    float x1 = p1.x * w1 * pxh - fx, y1 = p1.y * w1 * pyh - fy;
+    float x2 = p2.x * w2 * pxh - fx, y2 = p2.y * w2 * pyh - fy;
+    float dx = x2 - x1, dy = y2 - y1;
+    float db = x1 * dy - y1 * dx;
+    float ep = copysignf(1e-3f, dy); /* ~1/1000 pixel */
+    float iy = 1.f / (dy + ep);
+    float dby = db * iy;
+    float iw1 = -w1 * iy * dd;
+    float iw2 = w2 * iy * dd;
+    float gp1x = iw1 * pxh * y2;
+    float gp2x = iw2 * pxh * y1;
+    float gp1y = iw1 * pyh * (dby - x2);
+    float gp2y = iw2 * pyh * (dby - x1);
+    float gp1w = -(p1.x * gp1x + p1.y * gp1y) * w1;
+    float gp2w = -(p2.x * gp2x + p2.y * gp2y) * w2;
+    if (d) {
+        float s;
+        s = gp1x; gp1x = gp1y; gp1y = s;
+        s = gp2x; gp2x = gp2y; gp2y = s;
+    }
+    if (fabsf(a->alpha) >= 0.5f) { /* saturated: crossing was clamped */
+        gp1x = gp1y = gp1w = 0.f;
+        gp2x = gp2y = gp2w = 0.f;
+    }
+    g1[0] = gp1x; g1[1] = gp1y; g1[2] = gp1w;
+    g2[0] = gp2x; g2[1] = gp2y; g2[2] = gp2w;
+}
+
+/* dr.antialias backward.  dy = grad of output [B,H,W,C].  grad_color [B,H,W,C] is overwritten,
+ * grad_pos (pos's shape) is ACCUMULATED (caller zeroes). */
+int ehro_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri,
+                        const int32_t* opp, const float* dy, int range_mode, int B, int V, int T, int H, int W, int C,
+                        float* grad_color, float* grad_pos) {
+    size_t P = (size_t)H * W;
+    memcpy(grad_color, dy, (size_t)B * P * C * sizeof(float));
+    for (int b = 0; b < B; b++) {
+        const float* pb = range_mode ? pos : pos + (size_t)b * V * 4;
+        float* gpb = range_mode ? grad_pos : grad_pos + (size_t)b * V * 4;
+        for (int py = 0; py < H; py++)
+            for (int px = 0; px < W; px++) {
+                size_t pix0 = (size_t)b * P + (size_t)py * W + px;
+                for (int d = 0; d < 2; d++) {
+                    if (d == 0 && px + 1 >= W) continue;
+                    if (d == 1 && py + 1 >= H) continue;
+                    size_t pix1 = pix0 + (d ? (size_t)W : 1);
+                    float ft0 = rast[4 * pix0 + 3], ft1 = rast[4 * pix1 + 3];
+                    if (ft0 == ft1) continue;
+                    aa_pair a = aa_analyze(pb, tri, opp, V, T, W, H, px, py, d, rast[4 * pix0 + 2], ft0,
+                                           rast[4 * pix1 + 2], ft1);
+                    if (!a.found || a.alpha == 0.f) continue;
+                    const float* c0 = color + pix0 * C;
+                    const float* c1 = color + pix1 * C;
+                    const float* g = dy + (a.alpha > 0.f ? pix0 : pix1) * C;
+                    float dd = 0.f;
+                    for (int i = 0; i < C; i++) {
+                        float gi = g[i];
+                        if (gi != 0.f) {
+                            dd += gi * (c1[i] - c0[i]);
+                            float v = a.alpha * gi;
+                            grad_color[pix0 * C + i] -= v;
+                            grad_color[pix1 * C + i] += v;
+                        }
+                    }
+                    if (dd == 0.f) continue;
+                    int v1, v2;
+                    float g1[3], g2[3];
+                    aa_pos_grad(pb, tri, W, H, px, py, d, &a, dd, &v1, &v2, g1, g2);
+                    gpb[4 * v1 + 0] += g1[0]; gpb[4 * v1 + 1] += g1[1]; gpb[4 * v1 + 3] += g1[2];
+                    gpb[4 * v2 + 0] += g2[0]; gpb[4 * v2 + 1] += g2[1]; gpb[4 * v2 + 3] += g2[2];
+                }
+            }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* transform_pos                                                                                    */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* pos[v] = M * [x,y,z,1]  (easyhec/utils/nvdiffrast_utils.py:14-18), evaluated as an fma chain. */
+static inline void transform_vertex(const float* M, const float* v, float* o) {
+    for (int r = 0; r < 4; r++)
+        o[r] = fmaf(M[4 * r + 0], v[0], fmaf(M[4 * r + 1], v[1], fmaf(M[4 * r + 2], v[2], M[4 * r + 3])));
+}
+
+int ehro_transform_pos(const float* M, const float* verts, int V, float* pos) {
+    for (int v = 0; v < V; v++) transform_vertex(M, verts + 3 * (size_t)v, pos + 4 * (size_t)v);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* fused hot path: B views x L links -> composite mask, per-frame SSE loss, d(loss_b)/d(MVP[b,l])    */
+/* ------------------------------------------------------------------------------------------------ */
+
+/*
+ * Restates, as a straight composition of the ops above, what RBSolver.forward + backward compute per step
+ * (rb_solver.py:60-72 with nvdiffrast_renderer.py:33-47):
+ *   for view b, link l:  pos = transform_pos(MVP[b,l], verts_l); rast = rasterize(pos, tri_l);
+ *                        color = 1 where covered (interpolate of all-ones attributes; see `exact_interp`);
+ *                        si_l = flip_y(antialias(color, rast, pos, tri_l))
+ *   mask_b = min(sum_l si_l, 1);  loss_b = sum_pixels (mask_b - ref_b)^2
+ *   grad_mvp[b,l] = d loss_b / d MVP[b,l]   (through antialias' position gradient only; the clamp passes gradient
+ *                                            where the sum is <= 1, like torch.clamp)
+ * verts [V,3]; tris [T,3] with GLOBAL vertex indices, sorted by link; tri_off/vert_off [L+1] link offsets.
+ * ref/mask are in image convention (row 0 = top).  exact_interp != 0 evaluates colour through the
+ * interpolate arithmetic (b0 + b1 + b2 in float, may be 1 +- 1ulp); 0 uses exactly 1.0.
+ */
+int ehro_render_mask_loss(const float* verts, const int32_t* tris, const int32_t* tri_off, const int32_t* vert_off,
+                          const float* mvp, const float* ref, int B, int L, int V, int T, int H, int W,
+                          int exact_interp, float* mask, float* loss, float* grad_mvp) {
+    (void)T;
+    (void)V;
+    size_t P = (size_t)H * W;
+    int rc = 0;
+    /* topology per link (local vertex indices) */
+    int32_t** opp = (int32_t**)calloc(L, sizeof(int32_t*));
+    int32_t** ltri = (int32_t**)calloc(L, sizeof(int32_t*));
+    for (int l = 0; l < L; l++) {
+        int Tl = tri_off[l + 1] - tri_off[l];
+        ltri[l] = (int32_t*)malloc((size_t)(Tl > 0 ? Tl : 1) * 3 * sizeof(int32_t));
+        opp[l] = (int32_t*)malloc((size_t)(Tl > 0 ? Tl : 1) * 3 * sizeof(int32_t));
+        for (int i = 0; i < 3 * Tl; i++) ltri[l][i] = tris[3 * (size_t)tri_off[l] + i] - vert_off[l];
+        ehro_topology(ltri[l], Tl, opp[l]);
+    }
+    if (grad_mvp) memset(grad_mvp, 0, (size_t)B * L * 16 * sizeof(float));
+
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; b++) {
+        float* si = (float*)malloc((size_t)L * P * sizeof(float)); /* per-link AA masks, GL row order */
+        float* rast = (float*)malloc(P * 4 * sizeof(float));
+        float* color = (float*)malloc(P * sizeof(float));
+        float* acc = (float*)malloc(P * sizeof(float));
+        float* gimg = (float*)malloc(P * sizeof(float));
+        float* gcol = (float*)malloc(P * sizeof(float));
+        int Vmax = 1;
+        for (int l = 0; l < L; l++)
+            if (vert_off[l + 1] - vert_off[l] > Vmax) Vmax = vert_off[l + 1] - vert_off[l];
+        float* pos = (float*)malloc((size_t)Vmax * 4 * sizeof(float));
+        float* gpos = (float*)malloc((size_t)Vmax * 4 * sizeof(float));
+        float* ones = (float*)malloc((size_t)Vmax * sizeof(float));
+        for (int i = 0; i < Vmax; i++) ones[i] = 1.f;
+
+        for (int l = 0; l < L; l++) {
+            int Vl = vert_off[l + 1] - vert_off[l], Tl = tri_off[l + 1] - tri_off[l];
+            const float* M = mvp + ((size_t)b * L + l) * 16;
+            ehro_transform_pos(M, verts + 3 * (size_t)vert_off[l], Vl, pos);
+            ehro_rasterize_fwd(pos, ltri[l], NULL, 1, Vl, Tl, H, W, rast, NULL);
+            if (exact_interp)
+                ehro_interpolate_fwd(ones, rast, ltri[l], 1, 1, Vl, Tl, 1, H, W, color);
+            else
+                for (size_t i = 0; i < P; i++) color[i] = rast[4 * i + 3] != 0.f ? 1.f : 0.f;
+            ehro_antialias_fwd(color, rast, pos, ltri[l], opp[l], 0, 1, Vl, Tl, H, W, 1, si + (size_t)l * P);
+        }
+        /* composite (link order), clamp, loss; image row r = H-1-iy */
+        double lsum = 0.0;
+        for (int iy = 0; iy < H; iy++)
+            for (int ix = 0; ix < W; ix++) {
+                size_t gl = (size_t)iy * W + ix, im = (size_t)(H - 1 - iy) * W + ix;
+                float s = 0.f;
+                for (int l = 0; l < L; l++) s += si[(size_t)l * P + gl];
+                acc[gl] = s;
+                float m = s > 1.f ? 1.f : s;
+                if (mask) mask[(size_t)b * P + im] = m;
+                float e = m - ref[(size_t)b * P + im];
+                lsum += (double)e * (double)e;
+                gimg[gl] = (s <= 1.f) ? 2.f * e : 0.f;
+            }
+        if (loss) loss[b] = (float)lsum;
+
+        if (grad_mvp) {
+            for (int l = 0; l < L; l++) {
+                int Vl = vert_off[l + 1] - vert_off[l], Tl = tri_off[l + 1] - tri_off[l];
+                const float* M = mvp + ((size_t)b * L + l) * 16;
+                const float* vl = verts + 3 * (size_t)vert_off[l];
+                ehro_transform_pos(M, vl, Vl, pos);
+                ehro_rasterize_fwd(pos, ltri[l], NULL, 1, Vl, Tl, H, W, rast, NULL);
+                if (exact_interp)
+                    ehro_interpolate_fwd(ones, rast, ltri[l], 1, 1, Vl, Tl, 1, H, W, color);
+                else
+                    for (size_t i = 0; i < P; i++) color[i] = rast[4 * i + 3] != 0.f ? 1.f : 0.f;
+                memset(gpos, 0, (size_t)Vl * 4 * sizeof(float));
+                ehro_antialias_grad(color, rast, pos, ltri[l], opp[l], gimg, 0, 1, Vl, Tl, H, W, 1, gcol, gpos);
+                /* transform_pos backward: dL/dM[r][c] = sum_v gpos[v][r] * [x,y,z,1][c] (accumulated in double) */
+                double G[16];
+                for (int i = 0; i < 16; i++) G[i] = 0.0;
+                for (int v = 0; v < Vl; v++) {
+                    const float* g = gpos + 4 * (size_t)v;
+                    if (g[0] == 0.f && g[1] == 0.f && g[3] == 0.f) continue;
+                    double h[4] = {vl[3 * v], vl[3 * v + 1], vl[3 * v + 2], 1.0};
+                    for (int r = 0; r < 4; r++)
+                        for (int c = 0; c < 4; c++) G[4 * r + c] += (double)g[r] * h[c];
+                }
+                float* out = grad_mvp + ((size_t)b * L + l) * 16;
+                for (int i = 0; i < 16; i++) out[i] = (float)G[i];
+            }
+        }
+        free(si); free(rast); free(color); free(acc); free(gimg); free(gcol); free(pos); free(gpos); free(ones);
+    }
+    for (int l = 0; l < L; l++) {
+        free(opp[l]);
+        free(ltri[l]);
+    }
+    free(opp);
+    free(ltri);
+    return rc;
+}
+
+int ehro_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void ehro_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
