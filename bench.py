@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""bench.py -- mask-render fwd+bwd frames/s of the EasyHeC pose-optimisation step on MI355X.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): xArm7 (8 links, 41 096 triangles) at 1280x720,
+8 synthetic views per GPU, antialias on, multi-view mask loss.  One "step" = one optimisation iteration of
+/root/reference/easyhec/trainer/rbsolver.py:29-43 over that batch: dof -> Tc_c2b -> per-(view, link) clip matrices ->
+fused render / composite / SSE loss / gradient -> 6-DoF gradient -> [one 8-float all-reduce when N > 1] -> Adam.
+A "frame" = one camera view with all its links, forward + backward.  Inputs are resident in HBM before timing.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 200 --warmup 20
+
+Rank 0 prints ONE JSON line (driver contract) with two extra objects: "roofline" (dominant kernel vs HBM peak,
+hipEvent-timed on the launch stream) and "cpu_baseline" (the CPU oracle timed on this box's host cores; a reported
+baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+WORKLOAD = "xarm7_1280x720_8view"
+VIEWS_PER_GPU = 8
+
+
+def algorithmic_bytes_per_frame(robot, H, W):
+    """2*G + 16*P + 128*L  (geometry read fwd+bwd; per pixel: write mask, read ref, read both again)."""
+    G = 12 * robot.num_verts + 12 * robot.num_tris
+    return 2 * G + 16 * H * W + 128 * robot.num_links
+
+
+def build_problem(rank, world, dev):
+    from easyhec_amd import dr, fused
+    from easyhec_amd.config import Cfg
+    from easyhec_amd.rb_solver import RBSolver
+    from easyhec_amd.robot import load_robot
+    from easyhec_amd.synthetic import WORKLOADS, camera_Tc_c2b, make_views, perturb_pose
+    from easyhec_amd.trainer import RBSolverTrainer, shard_views
+
+    wl = WORKLOADS[WORKLOAD]
+    robot = load_robot(wl["robot"])
+    H, W, K = wl["H"], wl["W"], np.asarray(wl["K"], dtype=np.float64)
+    n_views = VIEWS_PER_GPU * world
+    _, link_poses = make_views(robot, n_views, seed=0)
+    lo, hi = shard_views(n_views, rank, world)
+    link_poses = link_poses[lo:hi]
+    B = hi - lo
+    Tc_gt = camera_Tc_c2b(radius=wl["radius"], lift=wl["lift"])
+    Tc_init = perturb_pose(Tc_gt)
+
+    cfg = Cfg()
+    cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
+    cfg.model.rbsolver.init_Tc_c2b = Tc_init.tolist()
+    model = RBSolver(cfg, meshes=robot.meshes).to(dev)
+    lp = torch.tensor(link_poses, dtype=torch.float32, device=dev)
+    Kt = torch.tensor(K, dtype=torch.float32, device=dev)
+    Tgt = torch.tensor(Tc_gt, dtype=torch.float32, device=dev)
+    # reference masks = binarised ground-truth silhouettes rendered by the HIP path (no dataset offline)
+    renderer = model._ensure_renderer()
+    scene = model._ensure_scene()
+    with torch.no_grad():
+        mvp_gt = fused.mvp_matrices(Kt, H, W, Tgt, lp)
+        gt_mask, _ = fused.render_mask_loss(renderer.glctx, scene, mvp_gt, torch.zeros((B, H, W), device=dev))
+    ref = (gt_mask > 0.5).float().contiguous()
+    batch = {"mask": ref, "link_poses": lp, "K": Kt[None].repeat(B, 1, 1), "Tc_c2b": Tgt[None].repeat(B, 1, 1)}
+    trainer = RBSolverTrainer(cfg, model, batch)
+    return dict(robot=robot, H=H, W=W, K=K, B=B, model=model, trainer=trainer, link_poses=link_poses, Tc_gt=Tc_gt,
+                Tc_init=Tc_init, ref=ref, glctx=renderer.glctx, n_views=n_views)
+
+
+def cpu_baseline(p, budget_s=12.0):
+    """The CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on the same 8-view batch
+    at the initial pose, fwd+bwd, OpenMP over views.  Bounded sample: repeats until ~budget_s of wall time."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    from oracle import oracle
+    verts, tris, toff, voff = helpers.scene_arrays(p["robot"])
+    mvp = helpers.mvp_numpy(p["K"], p["H"], p["W"], p["Tc_init"], p["link_poses"])
+    ref = p["ref"].cpu().numpy()
+    cores = min(oracle.num_threads(), mvp.shape[0])
+    oracle.render_mask_loss(verts, tris, toff, voff, mvp, ref)  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle.render_mask_loss(verts, tris, toff, voff, mvp, ref)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 200:
+            break
+    fps = reps * mvp.shape[0] / el
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "sample": f"{reps} x ({mvp.shape[0]} views 1280x720, fwd+bwd) of the same batch at the initial pose, "
+                      f"{el:.1f} s wall, OpenMP over views"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph capture of the step")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from easyhec_amd import fused
+    p = build_problem(rank, world, dev)
+    tr = p["trainer"]
+    if world > 1:
+        tr.distributed = True
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = tr.step
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    fused.check_status(p["glctx"])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(tr.last_loss)
+
+    # roofline leg: hipEvents around each kernel of the fused op, same K steps again (continuing the optimisation)
+    fused.set_timing(p["glctx"], True)
+    for _ in range(args.steps):
+        step()
+    stage_ms, ncalls = fused.read_timing(p["glctx"])
+    fused.set_timing(p["glctx"], False)
+
+    if rank == 0:
+        frames = p["n_views"] * args.steps
+        fps = frames / elapsed
+        bytes_frame = algorithmic_bytes_per_frame(p["robot"], p["H"], p["W"])
+        tile_ms = stage_ms["tile"] / max(ncalls, 1)
+        bytes_launch = bytes_frame * p["B"]
+        achieved = bytes_launch / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "mask-render fwd+bwd frames/sec, xArm7 50k-tri @1280x720x8-view",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD, "robot": "xarm7 link0-7 (41096 tris, 20525 verts)",
+                       "resolution": [p["H"], p["W"]], "views_per_gpu": p["B"], "global_views": p["n_views"],
+                       "links": p["robot"].num_links, "antialias": True, "optimizer": "Adam lr 3e-3 wd 5e-4",
+                       "parallelism": f"dp{world} over views, one 8-float all-reduce/step" if world > 1 else "single GPU",
+                       "final_mask_loss": round(final_loss, 3)},
+            "roofline": {"bound": "hbm", "kernel": "fused_tile_kernel", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_launch,
+                         "kernel_ms": round(tile_ms, 5),
+                         "stage_ms": {k: round(v / max(ncalls, 1), 5) for k, v in stage_ms.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,6 +36,8 @@ SIGNATURES = {
     "ehr_render_mask_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ehr_fused_status": (c_int, [c_void_p]),
+    "ehr_fused_timing": (c_int, [c_void_p, c_int]),
+    "ehr_fused_timing_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int)]),
 }
 
 

@@ -421,25 +421,43 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
     src.T = T;
     src.L = L;
 
+    // optional per-stage events (measurement hook)
+    hipEvent_t* ev = nullptr;
+    if (ctx->timing) {
+        const size_t need = ctx->ev_used + EHR_FUSED_STAGES + 1;
+        while (ctx->ev.size() < need) {
+            hipEvent_t e;
+            EHR_HIP(hipEventCreate(&e));
+            ctx->ev.push_back(e);
+        }
+        ev = ctx->ev.data() + ctx->ev_used;
+        ctx->ev_used = need;
+        EHR_HIP(hipEventRecord(ev[0], stream));
+    }
     EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 4) * sizeof(int), stream));
     dim3 bgrid((T + 255) / 256, B);
     if (T > 0) {
         bin_kernel<MvpSource, 1, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
         EHR_LAUNCH_CHECK();
     }
+    if (ev) EHR_HIP(hipEventRecord(ev[1], stream));
     bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nkeys, meta);
     EHR_LAUNCH_CHECK();
+    if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
     if (T > 0) {
         bin_kernel<MvpSource, 1, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries, ecap, meta);
         EHR_LAUNCH_CHECK();
     }
+    if (ev) EHR_HIP(hipEventRecord(ev[3], stream));
     dim3 tgrid(g.nt, B);
     fused_tile_kernel<<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, counts, offsets, entries, ecap, opp, ref, mask,
                                                              (float*)ctx->tile_part.ptr, grad_mvp ? 1 : 0, meta);
     EHR_LAUNCH_CHECK();
+    if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
     dim3 rgrid(L + 1, B);
     fused_reduce_kernel<<<rgrid, 256, 0, stream>>>(g, counts, (const float*)ctx->tile_part.ptr, loss, grad_mvp, meta);
     EHR_LAUNCH_CHECK();
+    if (ev) EHR_HIP(hipEventRecord(ev[5], stream));
     return EHR_OK;
 }
 
@@ -454,6 +472,30 @@ int ehr_fused_status(ehr_ctx* ctx) {
     if (meta[1])
         return fail(EHR_ERR_OVERFLOW, "fused path: a bin queue or a tile's blend list overflowed (%d queued, capacity %zu); "
                                       "re-plan with a larger slack", meta[0], ctx->entries_cap);
+    return EHR_OK;
+}
+
+int ehr_fused_timing(ehr_ctx* ctx, int enable) {
+    if (!ctx) return fail(EHR_ERR_INVALID, "ehr_fused_timing: ctx is NULL");
+    ctx->timing = enable != 0;
+    ctx->ev_used = 0;
+    return EHR_OK;
+}
+
+int ehr_fused_timing_read(ehr_ctx* ctx, float* ms, int* ncalls) {
+    if (!ctx || !ms || !ncalls) return fail(EHR_ERR_INVALID, "ehr_fused_timing_read: NULL argument");
+    EHR_HIP(hipDeviceSynchronize());
+    const size_t per = EHR_FUSED_STAGES + 1;
+    const size_t n = ctx->ev_used / per;
+    for (int s = 0; s < EHR_FUSED_STAGES; s++) ms[s] = 0.f;
+    for (size_t c = 0; c < n; c++)
+        for (int s = 0; s < EHR_FUSED_STAGES; s++) {
+            float t = 0.f;
+            EHR_HIP(hipEventElapsedTime(&t, ctx->ev[c * per + s], ctx->ev[c * per + s + 1]));
+            ms[s] += t;
+        }
+    *ncalls = (int)n;
+    ctx->ev_used = 0;
     return EHR_OK;
 }
 

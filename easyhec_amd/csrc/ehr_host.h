@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/ehr.h"
 
@@ -50,4 +51,8 @@ struct ehr_ctx {
     int pB = 0, pL = 0, pT = 0, pH = 0, pW = 0;
     ehr::Scratch tile_part;  // float [B * NT * (1 + 12 * L)] per-tile partial loss + MVP gradients
     ehr::Scratch tile_list;  // int32 [B * NT] worklist of non-empty tiles
+    // measurement hook (ehr_fused_timing): EHR_FUSED_STAGES + 1 events per recorded call
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
 };

@@ -228,6 +228,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->tile_part.release();
     c->tile_list.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipSetDevice(cur);
     delete c;
     return EHR_OK;

@@ -119,3 +119,20 @@ def mvp_matrices(K, H, W, Tc_c2b, link_poses, n=0.001, f=10.0):
     o2b = opencv2blender(device=Tc_c2b.device)
     Tc_c2l = Tc_c2b[None, None] @ link_poses          # rb_solver.py:63
     return proj @ (o2b @ Tc_c2l)                      # nvdiffrast_renderer.py:35,37 (same association)
+
+
+STAGES = ("bin_count", "bin_alloc", "bin_fill", "tile", "reduce")
+
+
+def set_timing(glctx, enable):
+    """Measurement hook (include/ehr.h ``ehr_fused_timing``): hipEvents around each kernel of the fused op."""
+    _lib.check(_lib.lib().ehr_fused_timing(glctx.handle, int(bool(enable))), "ehr_fused_timing")
+
+
+def read_timing(glctx):
+    """-> ({stage: accumulated ms}, number of calls); synchronises and resets."""
+    ms = (ctypes.c_float * len(STAGES))()
+    n = ctypes.c_int(0)
+    with torch.cuda.device(glctx.device):
+        _lib.check(_lib.lib().ehr_fused_timing_read(glctx.handle, ms, ctypes.byref(n)), "ehr_fused_timing_read")
+    return {s: float(ms[i]) for i, s in enumerate(STAGES)}, int(n.value)

@@ -102,6 +102,14 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
                          int W, float* mask, float* loss, float* grad_mvp, void* stream);
 int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVERFLOW */
 
+/* Measurement hook (bench.py's roofline leg): when enabled, every ehr_render_mask_loss call records hipEvents
+ * around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED milliseconds
+ * per stage since the last read -- ms[0] memset + bin count, ms[1] queue alloc, ms[2] bin fill, ms[3] tile kernel
+ * (the dominant one), ms[4] reduce -- and the number of calls covered, then resets.  Not for use under graph capture. */
+#define EHR_FUSED_STAGES 5
+int ehr_fused_timing(ehr_ctx* ctx, int enable);
+int ehr_fused_timing_read(ehr_ctx* ctx, float* ms, int* ncalls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,3 +72,14 @@ def mvp_numpy(K, H, W, Tc_c2b, link_poses):
     o2b = np.diag([1.0, -1.0, -1.0, 1.0])
     return (proj @ o2b @ np.asarray(Tc_c2b, dtype=np.float64) @ np.asarray(link_poses, dtype=np.float64)).astype(
         np.float32)
+
+
+def box_mesh(v):
+    """Axis-aligned bounding box of a vertex set as a closed 12-triangle mesh (coarse stand-in for a link)."""
+    lo, hi = np.asarray(v).min(0), np.asarray(v).max(0)
+    c = np.array([[lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]],
+                  [lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]],
+                 np.float32)
+    f = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4], [1, 2, 6], [1, 6, 5],
+                  [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]], np.int32)
+    return c, f

@@ -1,0 +1,188 @@
+"""GPU parity of the fused mask-loss path (ehr_render_mask_loss through the C ABI) against the CPU oracle, the
+committed fixtures, the three-op composition, and size-independent properties at BASELINE's full sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def env(xarm7):
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from easyhec_amd import dr, fused
+    dev = torch.device("cuda:0")
+    ctx = dr.RasterizeCudaContext()
+    scene = fused.LinkScene([v for v, _ in xarm7.meshes], [f for _, f in xarm7.meshes], dev)
+    return fused, ctx, scene, dev
+
+
+def run(fused, ctx, scene, mvp, ref, dev):
+    tm = torch.tensor(mvp, device=dev, requires_grad=True)
+    tr = torch.tensor(ref, device=dev)
+    mask, loss = fused.render_mask_loss(ctx, scene, tm, tr)
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    fused.check_status(ctx)
+    return mask.cpu().numpy(), loss.detach().cpu().numpy(), tm.grad.cpu().numpy()
+
+
+def workload(xarm7, H, W, scale, B, seed, perturb=True):
+    from easyhec_amd.config import XARM7_K_1280x720
+    from easyhec_amd.synthetic import camera_Tc_c2b, make_views, perturb_pose, scaled_K
+    K = scaled_K(XARM7_K_1280x720, scale, W, H, scale != 1.0)
+    _, lp = make_views(xarm7, B, seed=seed)
+    Tc = camera_Tc_c2b()
+    return K, lp, Tc, helpers.mvp_numpy(K, H, W, perturb_pose(Tc) if perturb else Tc, lp)
+
+
+@pytest.mark.parametrize("H,W,scale,B", [(120, 160, 0.125, 2), (480, 640, 0.5, 1), (720, 1280, 1.0, 8),
+                                         (100, 150, 0.12, 3)])
+def test_fused_matches_oracle(env, oracle, xarm7, H, W, scale, B):
+    fused, ctx, scene, dev = env
+    K, lp, Tc, mvp = workload(xarm7, H, W, scale, B, seed=H)
+    rng = np.random.default_rng(H)
+    ref = (rng.uniform(size=(B, H, W)) > 0.85).astype(np.float32)
+    verts, tris, toff, voff = helpers.scene_arrays(xarm7)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(verts, tris, toff, voff, mvp, ref)
+    mask, loss, grad = run(fused, ctx, scene, mvp, ref, dev)
+    assert (mask == m_ref).all()                                   # rendered masks: bit-exact (<= 1e-4 L-inf bar)
+    assert np.abs(loss - l_ref).max() <= 1e-6 * np.abs(l_ref).max()  # float vs double accumulation
+    assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+    assert (grad[:, :, 2, :] == 0).all()
+
+
+def test_fused_golden_fixtures(env, xarm7):
+    fused, ctx, scene, dev = env
+    g = np.load(os.path.join(GOLD, "fused_xarm7_160x120.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    ref = np.unpackbits(g["ref"])[:2 * H * W].reshape(2, H, W).astype(np.float32)
+    mask, loss, grad = run(fused, ctx, scene, g["mvp"], ref, dev)
+    assert (mask == g["mask"]).all()
+    assert np.allclose(loss, g["loss"], rtol=1e-6)
+    assert np.abs(grad - g["grad_mvp"]).max() <= 1e-5 * np.abs(g["grad_mvp"]).max()
+    # BASELINE configs[0] on the GPU: zero-pose PLY as a single link
+    z = np.load(os.path.join(GOLD, "xarm7_zeropos.npz"))
+    c1 = np.load(os.path.join(GOLD, "config1_zeropos_320x240.npz"))
+    sc1 = fused.LinkScene([z["vertices"]], [z["faces"]], dev)
+    mask, loss, grad = run(fused, ctx, sc1, c1["mvp"], np.zeros((1, 240, 320), np.float32), dev)
+    assert (mask == c1["mask"]).all() and np.allclose(loss, c1["loss"], rtol=1e-6)
+    assert np.abs(grad - c1["grad_mvp"]).max() <= 1e-5 * np.abs(c1["grad_mvp"]).max()
+
+
+def test_fused_is_bit_reproducible_and_forward_only_agrees(env, xarm7):
+    fused, ctx, scene, dev = env
+    H, W, B = 720, 1280, 8
+    K, lp, Tc, mvp = workload(xarm7, H, W, 1.0, B, seed=0)
+    ref = np.zeros((B, H, W), np.float32)
+    a = run(fused, ctx, scene, mvp, ref, dev)
+    b = run(fused, ctx, scene, mvp, ref, dev)
+    assert all((x == y).all() for x, y in zip(a, b))   # no float atomics anywhere on the fused path
+    with torch.no_grad():
+        m2, l2 = fused.render_mask_loss(ctx, scene, torch.tensor(mvp, device=dev), torch.tensor(ref, device=dev))
+    assert (m2.cpu().numpy() == a[0]).all() and (l2.cpu().numpy() == a[1]).all()
+
+
+def test_fused_equals_three_op_composition(env, xarm7):
+    """RBSolver(use_fused=True) vs RBSolver(use_fused=False): the reference's own per-(frame, link) op sequence."""
+    fused, ctx, scene, dev = env
+    from easyhec_amd.config import Cfg
+    from easyhec_amd.rb_solver import RBSolver
+    from easyhec_amd.synthetic import perturb_pose
+    H, W, B = 240, 320, 2
+    K, lp, Tc, _ = workload(xarm7, H, W, 0.25, B, seed=5)
+    rng = np.random.default_rng(1)
+    ref = torch.tensor((rng.uniform(size=(B, H, W)) > 0.9).astype(np.float32), device=dev)
+    batch = {"mask": ref, "link_poses": torch.tensor(lp, device=dev),
+             "K": torch.tensor(K, dtype=torch.float32, device=dev)[None].repeat(B, 1, 1),
+             "Tc_c2b": torch.tensor(Tc, dtype=torch.float32, device=dev)[None].repeat(B, 1, 1)}
+    res = []
+    for use_fused in (True, False):
+        cfg = Cfg()
+        cfg.model.rbsolver.H, cfg.model.rbsolver.W, cfg.model.rbsolver.use_fused = H, W, use_fused
+        cfg.model.rbsolver.init_Tc_c2b = perturb_pose(Tc).tolist()
+        model = RBSolver(cfg, meshes=xarm7.meshes).to(dev)
+        out, ld = model(batch)
+        ld["mask_loss"].backward()
+        res.append((out["rendered_masks"].detach().cpu().numpy(), float(ld["mask_loss"]),
+                    model.dof.grad.cpu().numpy(), out))
+    (m0, l0, g0, o0), (m1, l1, g1, _) = res
+    assert np.abs(m0 - m1).max() <= 1e-6          # colour 1.0 vs interpolate(ones) = 1 +- 1 ulp, clip-matrix rounding
+    assert abs(l0 - l1) <= 1e-4 * abs(l1)
+    assert np.abs(g0 - g1).max() <= 2e-3 * np.abs(g1).max()
+    assert set(o0) >= {"rendered_masks", "ref_masks", "error_maps", "metrics", "tsfm"}
+    assert set(o0["metrics"]) == {"err_x", "err_y", "err_z", "err_trans", "err_rot"}
+
+
+def test_full_size_properties(env, xarm7):
+    """BASELINE configs[2] size (1280x720 x 8 views): properties that do not need the oracle."""
+    fused, ctx, scene, dev = env
+    H, W, B = 720, 1280, 8
+    K, lp, Tc, mvp_gt = workload(xarm7, H, W, 1.0, B, seed=0, perturb=False)
+    zeros = np.zeros((B, H, W), np.float32)
+    mask, loss, _ = run(fused, ctx, scene, mvp_gt, zeros, dev)
+    assert mask.min() >= 0 and mask.max() <= 1
+    assert np.allclose(loss, (mask.astype(np.float64) ** 2).sum(axis=(1, 2)), rtol=1e-6)   # loss vs its own mask
+    ref = (mask > 0.5).astype(np.float32)
+    m2, l2, g2 = run(fused, ctx, scene, mvp_gt, ref, dev)
+    assert (m2 == mask).all()                                # the reference mask does not influence the render
+    frac = ((mask > 0) & (mask < 1)).sum()
+    assert l2.sum() <= frac                                  # at the GT pose only antialiased pixels contribute
+    # view permutation equivariance (independent shards: SURVEY 8e)
+    perm = np.array([3, 0, 7, 1, 6, 2, 5, 4])
+    m3, l3, g3 = run(fused, ctx, scene, mvp_gt[perm], ref[perm], dev)
+    assert (m3 == m2[perm]).all() and (l3 == l2[perm]).all() and (g3 == g2[perm]).all()
+    # a view is unchanged by what else is in the batch
+    m4, l4, g4 = run(fused, ctx, scene, mvp_gt[:1], ref[:1], dev)
+    assert (m4[0] == m2[0]).all() and l4[0] == l2[0] and (g4[0] == g2[0]).all()
+    # link additivity below the clamp: rendering links {0..3} and {4..7} separately sums to the joint render wherever
+    # the joint sum stays <= 1
+    from easyhec_amd import fused as F
+    sA = F.LinkScene([v for v, _ in xarm7.meshes[:4]], [f for _, f in xarm7.meshes[:4]], dev)
+    sB = F.LinkScene([v for v, _ in xarm7.meshes[4:]], [f for _, f in xarm7.meshes[4:]], dev)
+    mA, _, _ = run(fused, ctx, sA, mvp_gt[:2, :4], zeros[:2], dev)
+    mB, _, _ = run(fused, ctx, sB, mvp_gt[:2, 4:], zeros[:2], dev)
+    s = mA + mB
+    ok = s <= 1.0
+    assert np.abs(np.minimum(s, 1.0) - mask[:2])[ok].max() <= 2.4e-7
+
+
+def test_overflow_is_reported_not_silent(env):
+    """More blended pairs in one tile than its LDS list holds (a pathological checkerboard of pixel-sized quads in
+    every one of 10 links): the loss becomes NaN and the status call raises -- never a silently wrong gradient."""
+    fused, _, _, dev = env
+    from easyhec_amd import dr
+    H, W, L = 8, 32, 10
+    vs, fs = [], []
+    for l in range(L):
+        v, f = [], []
+        for y in range(H):
+            for x in range(W):
+                if (x + y) % 2 == 0:
+                    cx, cy = (x + 0.5) / W * 2 - 1, (y + 0.5) / H * 2 - 1
+                    hx, hy = 0.6 / W, 0.6 / H
+                    n = len(v)
+                    v += [[cx - hx, cy - hy, 0], [cx + hx, cy - hy, 0], [cx + hx, cy + hy, 0], [cx - hx, cy + hy, 0]]
+                    f += [[n, n + 1, n + 2], [n, n + 2, n + 3]]
+        vs.append(np.array(v, np.float32))
+        fs.append(np.array(f, np.int32))
+    ctx2 = dr.RasterizeCudaContext()
+    scene = fused.LinkScene(vs, fs, dev)
+    mvp = torch.eye(4, device=dev)[None, None].repeat(1, L, 1, 1).contiguous().requires_grad_(True)
+    mask, loss = fused.render_mask_loss(ctx2, scene, mvp, torch.zeros((1, H, W), device=dev))
+    torch.cuda.synchronize()
+    assert torch.isnan(loss).all()
+    with pytest.raises(RuntimeError, match="overflow"):
+        fused.check_status(ctx2)
+    # the same scene with 2 links fits and is finite
+    sc2 = fused.LinkScene(vs[:2], fs[:2], dev)
+    ctx3 = dr.RasterizeCudaContext()
+    m2, l2 = fused.render_mask_loss(ctx3, sc2, mvp[:, :2].detach().contiguous().requires_grad_(True),
+                                    torch.zeros((1, H, W), device=dev))
+    assert torch.isfinite(l2).all() and float(m2.max()) <= 1.0
+    fused.check_status(ctx3)
