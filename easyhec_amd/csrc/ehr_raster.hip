@@ -237,7 +237,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
 int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
                       int T, int H, int W, float* rast, float* rast_db, void* stream_) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: ctx is NULL");
-    if (!pos || !tri || !rast) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: NULL tensor");
+    if (!pos || (!tri && T > 0) || !rast) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: NULL tensor");
     if (B <= 0 || V < 0 || T < 0 || H <= 0 || W <= 0) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: bad sizes");
     if (H > 32768 || W > 32768) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: resolution above 32768 is unsupported");
     hipStream_t stream = (hipStream_t)stream_;

@@ -109,10 +109,12 @@ def test_fused_equals_three_op_composition(env, xarm7):
         model = RBSolver(cfg, meshes=xarm7.meshes).to(dev)
         out, ld = model(batch)
         ld["mask_loss"].backward()
-        res.append((out["rendered_masks"].detach().cpu().numpy(), float(ld["mask_loss"]),
+        res.append((out["rendered_masks"].detach().cpu().numpy(), float(ld["mask_loss"].detach()),
                     model.dof.grad.cpu().numpy(), out))
     (m0, l0, g0, o0), (m1, l1, g1, _) = res
-    assert np.abs(m0 - m1).max() <= 1e-6          # colour 1.0 vs interpolate(ones) = 1 +- 1 ulp, clip-matrix rounding
+    # the three-op path forms clip positions with torch.matmul (nvdiffrast_utils.py:18), the fused kernel with an fma
+    # chain: positions differ by ~1 ulp, i.e. ~1e-5 pixel, which moves antialias blends by ~1e-5 (north_star bar: 1e-4)
+    assert np.abs(m0 - m1).max() <= 1e-4
     assert abs(l0 - l1) <= 1e-4 * abs(l1)
     assert np.abs(g0 - g1).max() <= 2e-3 * np.abs(g1).max()
     assert set(o0) >= {"rendered_masks", "ref_masks", "error_maps", "metrics", "tsfm"}
