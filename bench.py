@@ -39,7 +39,7 @@ def algorithmic_bytes_per_frame(robot, H, W):
     return 2 * G + 16 * H * W + 128 * robot.num_links
 
 
-def build_problem(rank, world, dev):
+def build_problem(rank, world, dev, eager=False, graph=True):
     from easyhec_amd import dr, fused
     from easyhec_amd.config import Cfg
     from easyhec_amd.rb_solver import RBSolver
@@ -73,7 +73,7 @@ def build_problem(rank, world, dev):
         gt_mask, _ = fused.render_mask_loss(renderer.glctx, scene, mvp_gt, torch.zeros((B, H, W), device=dev))
     ref = (gt_mask > 0.5).float().contiguous()
     batch = {"mask": ref, "link_poses": lp, "K": Kt[None].repeat(B, 1, 1), "Tc_c2b": Tgt[None].repeat(B, 1, 1)}
-    trainer = RBSolverTrainer(cfg, model, batch)
+    trainer = RBSolverTrainer(cfg, model, batch, fast=not eager, graph=graph)
     return dict(robot=robot, H=H, W=W, K=K, B=B, model=model, trainer=trainer, link_poses=link_poses, Tc_gt=Tc_gt,
                 Tc_init=Tc_init, ref=ref, glctx=renderer.glctx, n_views=n_views)
 
@@ -108,7 +108,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="no hipGraph capture of the step")
+    ap.add_argument("--eager", action="store_true", help="reference-shaped torch autograd step instead of the HIP launch chain")
+    ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,10 +125,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from easyhec_amd import fused
-    p = build_problem(rank, world, dev)
+    p = build_problem(rank, world, dev, eager=args.eager, graph=(not args.no_graph) and world == 1)
     tr = p["trainer"]
-    if world > 1:
-        tr.distributed = True
 
     def barrier():
         if world > 1:
@@ -152,6 +151,8 @@ def main():
 
     # roofline leg: hipEvents around each kernel of the fused op, same K steps again (continuing the optimisation)
     fused.set_timing(p["glctx"], True)
+    if tr.fast is not None:
+        tr.fast._graph = None  # hipEvents between kernels need eager launches
     for _ in range(args.steps):
         step()
     stage_ms, ncalls = fused.read_timing(p["glctx"])
@@ -179,6 +180,7 @@ def main():
             "config": {"workload": WORKLOAD, "robot": "xarm7 link0-7 (41096 tris, 20525 verts)",
                        "resolution": [p["H"], p["W"]], "views_per_gpu": p["B"], "global_views": p["n_views"],
                        "links": p["robot"].num_links, "antialias": True, "optimizer": "Adam lr 3e-3 wd 5e-4",
+                       "step": "torch autograd" if args.eager else ("HIP launch chain" + (", hipGraph replay" if tr.fast is not None and (not args.no_graph) and world == 1 else "")),
                        "parallelism": f"dp{world} over views, one 8-float all-reduce/step" if world > 1 else "single GPU",
                        "final_mask_loss": round(final_loss, 3)},
             "roofline": {"bound": "hbm", "kernel": "fused_tile_kernel", "achieved": round(achieved, 2),

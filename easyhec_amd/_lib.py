@@ -33,9 +33,16 @@ SIGNATURES = {
     "ehr_antialias_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ehr_fused_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float]),
-    "ehr_render_mask_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                     c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ehr_render_mask_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_void_p]),
     "ehr_fused_status": (c_int, [c_void_p]),
+    "ehr_pose_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ehr_pose_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                  c_float, c_float, c_void_p, c_void_p]),
+    "ehr_pose_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                              c_float, c_void_p, c_void_p, c_void_p]),
     "ehr_fused_timing": (c_int, [c_void_p, c_int]),
     "ehr_fused_timing_read": (c_int, [c_void_p, ctypes.POINTER(c_float), ctypes.POINTER(c_int)]),
 }

@@ -31,7 +31,8 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libehr_hip.so (the HIP path has no fallback)")
-    cmd = [hipcc, f"--offload-arch={ARCH}"] + FLAGS + sources() + ["-o", LIB]
+    extra = os.environ.get("EHR_HIPCC_FLAGS", "").split()  # e.g. -DEHR_PHASE_TIMING for tools/phase_profile.py
+    cmd = [hipcc, f"--offload-arch={ARCH}"] + FLAGS + extra + sources() + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -23,7 +23,7 @@ constexpr int RW = EHR_TILE_W + 2;  // region = tile + 1-pixel halo
 constexpr int RH = EHR_TILE_H + 2;
 constexpr int RN = RW * RH;          // 340
 constexpr int CAND_PER_THREAD = (2 * RN + EHR_TILE_THREADS - 1) / EHR_TILE_THREADS;  // 3
-constexpr int MAX_ITEMS = 1536;      // blended pairs kept per tile (all links); overflow is reported, never silent
+constexpr int MAX_ITEMS = 1024;      // blended pairs kept per tile (all links); overflow is reported, never silent
 constexpr int MAX_LINKS = 64;
 
 struct Item {
@@ -56,247 +56,313 @@ __device__ __forceinline__ int block_offset(int cnt, int* wave_tot, int& total) 
     return base + incl - cnt;
 }
 
+// clip-space vertices of every (view, vertex): posc[b][v] = MVP[b, vert_link[v]] * [x, y, z, 1]
+// (easyhec/utils/nvdiffrast_utils.py:14-18 for all links of a view at once)
+__global__ void __launch_bounds__(256) fused_vertex_kernel(const float* __restrict__ verts,
+                                                           const int32_t* __restrict__ vert_link,
+                                                           const float* __restrict__ mvp, int V, int L,
+                                                           float4* __restrict__ posc) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (v >= V) return;
+    const int l = vert_link[v];
+    float4 o = make_float4(0.f, 0.f, 0.f, -1.f);  // invalid link -> behind the camera, never drawn
+    if ((unsigned)l < (unsigned)L) o = transform_vertex(mvp + ((size_t)b * L + l) * 16, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
+    posc[(size_t)b * V + v] = o;
+}
+
+// Streaming pass over the tiles no triangle touches (~90 % of the image): mask = 0, loss += ref^2.
+// grid = (tile rows, views); one wave handles one 32x8 tile as 64 float4 accesses (full 128-byte lines).
+__global__ void __launch_bounds__(256) fused_empty_kernel(BinGeom g, const int* __restrict__ tile_total,
+                                                          const float* __restrict__ ref, float* __restrict__ mask,
+                                                          float* __restrict__ tile_part, int part_stride) {
+    const int ty = blockIdx.x, b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ly = lane >> 3, lx4 = (lane & 7) * 4;  // 8 rows x 8 float4
+    const int iy = ty * EHR_TILE_H + ly;
+    const bool vec_ok = (g.W & 3) == 0;
+    for (int tx = wave; tx < g.ntx; tx += 4) {
+        const int tile = ty * g.ntx + tx;
+        if (tile_total[b * g.nt + tile] != 0) continue;  // wave-uniform
+        const int ix = tx * EHR_TILE_W + lx4;
+        float s = 0.f;
+        if (iy < g.H && ix < g.W) {
+            const size_t im = ((size_t)b * g.H + (g.H - 1 - iy)) * g.W + ix;
+            if (vec_ok) {
+                float4 r = *reinterpret_cast<const float4*>(ref + im);
+                s = ((r.x * r.x + r.y * r.y) + r.z * r.z) + r.w * r.w;
+                if (mask) *reinterpret_cast<float4*>(mask + im) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int k = 0; k < 4 && ix + k < g.W; k++) {
+                    float r = ref[im + k];
+                    s += r * r;
+                    if (mask) mask[im + k] = 0.f;
+                }
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) tile_part[(size_t)(b * g.nt + tile) * part_stride] = s;
+    }
+}
+
+// Heavy tiles: persistent workgroups walk the work list of non-empty tiles.
 __global__ void __launch_bounds__(EHR_TILE_THREADS)
-fused_tile_kernel(MvpSource src, BinGeom g, const int* __restrict__ counts, const int* __restrict__ offsets,
-                  const int* __restrict__ entries, int entries_cap, const int32_t* __restrict__ opp,
-                  const float* __restrict__ ref, float* __restrict__ mask, float* __restrict__ tile_part,
-                  int want_grad, int* __restrict__ meta) {
+fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, const int* __restrict__ counts,
+                  const int* __restrict__ offsets, const int4* __restrict__ entries, int entries_cap,
+                  const int* __restrict__ worklist, const int32_t* __restrict__ opp, const float* __restrict__ ref,
+                  float* __restrict__ mask, float* __restrict__ tile_part, int want_grad, int* __restrict__ meta) {
     __shared__ u64 key[RN];
     __shared__ float pairA[2][RN];
     __shared__ unsigned short hits[2 * RN];
     __shared__ Item items[MAX_ITEMS];
+    __shared__ WaveRaster wscratch[EHR_TILE_THREADS / 64];
     __shared__ int seg_end[MAX_LINKS];
     __shared__ int cnt_l[MAX_LINKS];
     __shared__ float gpix[EHR_TILE_W * EHR_TILE_H];
     __shared__ int wave_tot[4];
     __shared__ float wred[4][12];
 
-    const int tile = blockIdx.x, b = blockIdx.y;
-    const int tx = tile % g.ntx, ty = tile / g.ntx;
-    const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
     const int tid = threadIdx.x;
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
-    const int ix = tx * EHR_TILE_W + lx, iy = ty * EHR_TILE_H + ly;
-    const bool in_img = ix < g.W && iy < g.H;
     const int L = g.L, W = g.W, H = g.H;
-    const int kidx = (b * g.nt + tile) * L;
     const int part_stride = 1 + 12 * L;
-    float* part = tile_part + (size_t)(b * g.nt + tile) * part_stride;
-
-    if (tid < L) cnt_l[tid] = counts[kidx + tid];
-    __syncthreads();
-
-    float acc = 0.f;
-    int nitems = 0;  // uniform across the block
     const int myq = (ly + 1) * RW + (lx + 1);
+    const int nwork = meta[EHR_META_NWORK];
+#ifdef EHR_PHASE_TIMING
+    // profiling build only (tools/phase_profile.sh): cycles spent up to each phase marker, summed over workgroups
+    long long ph_last = __builtin_readcyclecounter();
+    if (tid == 0) ehr_dbg_cycles = (unsigned long long*)(meta + 8) + 7;
+#define EHR_PHASE(i)                                                                   \
+    do {                                                                               \
+        long long now_ = __builtin_readcyclecounter();                                 \
+        if (tid == 0) atomicAdd((unsigned long long*)(meta + 8) + (i), (unsigned long long)(now_ - ph_last)); \
+        ph_last = now_;                                                                \
+    } while (0)
+#else
+#define EHR_PHASE(i) do { } while (0)
+#endif
 
-    for (int l = 0; l < L; l++) {
-        const int n = cnt_l[l];
-        if (n == 0) {
-            if (tid == 0) seg_end[l] = nitems;
-            continue;
-        }
-        const int off = offsets[kidx + l];
-        for (int i = tid; i < RN; i += EHR_TILE_THREADS) key[i] = ~0ull;
+    for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const int gt = worklist[wi];  // b * nt + tile
+        const int b = gt / g.nt, tile = gt - b * g.nt;
+        const int tx = tile % g.ntx, ty = tile / g.ntx;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        const int ix = tx * EHR_TILE_W + lx, iy = ty * EHR_TILE_H + ly;
+        const bool in_img = ix < W && iy < H;
+        const int kidx = gt * L;
+        float* part = tile_part + (size_t)gt * part_stride;
+        const float4* pv = src.verts(b);
+
+        __syncthreads();  // previous tile's LDS users are done
+        if (tid < L) cnt_l[tid] = counts[kidx + tid];
         __syncthreads();
-        // ---- coverage + z-test of the link's queued triangles
-        for (int base = 0; base < n; base += EHR_TILE_THREADS) {
-            int i = base + tid;
-            bool active = i < n && off + i < entries_cap;
-            float4 p[3];
-            int t = 0, link;
-            if (active) {
-                t = entries[off + i];
-                active = src.fetch(b, t, p, link);
+
+        float acc = 0.f;
+        int nitems = 0;  // uniform across the block
+
+        for (int l = 0; l < L; l++) {
+            int n = cnt_l[l];
+            if (n == 0) {
+                if (tid == 0) seg_end[l] = nitems;
+                continue;
             }
-            raster_wave<RW, RH, 12>(active, p, t, W, H, rx0, ry0, key);
-        }
-        __syncthreads();
-        // ---- pixel pairs with different triangle ids -> dense hit list (deterministic order)
-        unsigned short myhit[CAND_PER_THREAD];
-        int nh = 0;
+            const int off = offsets[kidx + l];
+            if (off + n > entries_cap) n = max(entries_cap - off, 0);
+            for (int i = tid; i < RN; i += EHR_TILE_THREADS) key[i] = ~0ull;
+            __syncthreads();
+            // ---- coverage + z-test of the link's queued triangles
+            EHR_PHASE(0);
+            raster_queue<RW, RH>(src, b, entries + off, n, W, H, rx0, ry0, key, wscratch);
+            __syncthreads();
+            EHR_PHASE(1);
+            // ---- pixel pairs with different triangle ids -> dense hit list (deterministic order)
+            unsigned myhit[CAND_PER_THREAD];
+            int nh = 0;
 #pragma unroll
-        for (int j = 0; j < CAND_PER_THREAD; j++) {
-            int c = tid + j * EHR_TILE_THREADS;
-            if (c < 2 * RN) {
-                int d = c >= RN ? 1 : 0;
-                int q = c - d * RN;
-                int qx = q % RW, qy = q / RW;
-                int nx = qx + 1 - d, ny = qy + d;
-                pairA[d][q] = 0.f;
-                bool ok = nx < RW && ny < RH;
-                // both pixels inside the image
-                int ax = rx0 + qx, ay = ry0 + qy, bx = rx0 + nx, by = ry0 + ny;
-                ok = ok && ax >= 0 && ay >= 0 && bx < W && by < H;
-                // at least one of them interior to the tile (only those can receive or own a blend we need)
-                bool qi = qx >= 1 && qx <= EHR_TILE_W && qy >= 1 && qy <= EHR_TILE_H;
-                bool ni = nx >= 1 && nx <= EHR_TILE_W && ny >= 1 && ny <= EHR_TILE_H;
-                ok = ok && (qi || ni);
-                if (ok) {
-                    u64 k0 = key[q], k1 = key[ny * RW + nx];
-                    unsigned t0 = (k0 == ~0ull) ? 0xffffffffu : (unsigned)k0;
-                    unsigned t1 = (k1 == ~0ull) ? 0xffffffffu : (unsigned)k1;
-                    if (t0 != t1) myhit[nh++] = (unsigned short)(q | (d << 15));
-                }
-            }
-        }
-        int nhits;
-        int hoff = block_offset(nh, wave_tot, nhits);
-        for (int j = 0; j < nh; j++) hits[hoff + j] = myhit[j];
-        __syncthreads();
-        // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel)
-        Item mine[CAND_PER_THREAD];
-        int nm = 0;
-#pragma unroll
-        for (int j = 0; j < CAND_PER_THREAD; j++) {
-            int h = tid + j * EHR_TILE_THREADS;
-            if (h < nhits) {
-                int hq = hits[h];
-                int d = hq >> 15, q = hq & 0x7fff;
-                int qx = q % RW, qy = q / RW;
-                int nq = q + (d ? RW : 1);
-                u64 k0 = key[q], k1 = key[nq];
-                int tri0 = (k0 == ~0ull) ? -1 : (int)(unsigned)k0;
-                int tri1 = (k1 == ~0ull) ? -1 : (int)(unsigned)k1;
-                float zw0 = ord_unkey((unsigned)(k0 >> 32)), zw1 = ord_unkey((unsigned)(k1 >> 32));
-                int t = (tri0 >= 0) ? tri0 : tri1;
-                if (tri0 >= 0 && tri1 >= 0) t = (zw0 < zw1) ? tri0 : tri1;
-                bool chose0 = !(t == tri1);
-                int px = rx0 + qx, py = ry0 + qy;
-                if (!chose0) {
-                    px += 1 - d;
-                    py += d;
-                }
-                int vi[3] = {src.tri[3 * t], src.tri[3 * t + 1], src.tri[3 * t + 2]};
-                float4 p[3], o[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) p[k] = src.vertex(b, l, vi[k]);
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    int ov = opp[3 * t + k];
-                    o[k] = ((unsigned)ov < (unsigned)src.V) ? src.vertex(b, l, ov) : p[k];
-                }
-                AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
-                if (a.found) {
-                    pairA[d][q] = a.alpha;
-                    // keep for the backward pass if the destination pixel is interior to this tile
-                    int oq = (a.alpha > 0.f) ? q : nq;
-                    int ox = oq % RW, oy = oq / RW;
-                    bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
-                    if (oi && a.alpha != 0.f) {
-                        float c0 = (tri0 >= 0) ? 1.f : 0.f, c1 = (tri1 >= 0) ? 1.f : 0.f;
-                        if (c0 != c1) {
-                            Item it;
-                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((c1 > c0 ? 1 : 0) << 14);
-                            it.tri = t;
-                            it.alpha = a.alpha;
-                            mine[nm++] = it;
+            for (int j = 0; j < CAND_PER_THREAD; j++) {
+                myhit[j] = 0xffffffffu;
+                int c = tid + j * EHR_TILE_THREADS;
+                if (c < 2 * RN) {
+                    int d = c >= RN ? 1 : 0;
+                    int q = c - d * RN;
+                    int qx = q % RW, qy = q / RW;
+                    int nx = qx + 1 - d, ny = qy + d;
+                    pairA[d][q] = 0.f;
+                    bool ok = nx < RW && ny < RH;
+                    int ax = rx0 + qx, ay = ry0 + qy, bx = rx0 + nx, by = ry0 + ny;
+                    ok = ok && ax >= 0 && ay >= 0 && bx < W && by < H;  // both pixels inside the image
+                    bool qi = qx >= 1 && qx <= EHR_TILE_W && qy >= 1 && qy <= EHR_TILE_H;
+                    bool ni = nx >= 1 && nx <= EHR_TILE_W && ny >= 1 && ny <= EHR_TILE_H;
+                    ok = ok && (qi || ni);  // at least one of them interior to the tile
+                    if (ok) {
+                        u64 k0 = key[q], k1 = key[ny * RW + nx];
+                        unsigned t0 = (k0 == ~0ull) ? 0xffffffffu : (unsigned)k0;
+                        unsigned t1 = (k1 == ~0ull) ? 0xffffffffu : (unsigned)k1;
+                        if (t0 != t1) {
+                            myhit[j] = (unsigned)(q | (d << 15));
+                            nh++;
                         }
                     }
                 }
             }
-        }
-        int nfound;
-        int ioff = block_offset(want_grad ? nm : 0, wave_tot, nfound);
-        if (want_grad) {
-            for (int j = 0; j < nm; j++) {
-                int at = nitems + ioff + j;
-                if (at < MAX_ITEMS)
-                    items[at] = mine[j];
-                else
-                    meta[1] = 1;  // item overflow: reported through loss = NaN
+            int nhits;
+            int hoff = block_offset(nh, wave_tot, nhits);
+#pragma unroll
+            for (int j = 0; j < CAND_PER_THREAD; j++)
+                if (myhit[j] != 0xffffffffu) hits[hoff++] = (unsigned short)myhit[j];
+            __syncthreads();
+            EHR_PHASE(2);
+            // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 256 per round
+            for (int hbase = 0; hbase < nhits; hbase += EHR_TILE_THREADS) {
+                const int h = hbase + tid;
+                Item it;
+                it.packed = 0;
+                it.tri = 0;
+                it.alpha = 0.f;
+                int keep = 0;
+                if (h < nhits) {
+                    int hq = hits[h];
+                    int d = hq >> 15, q = hq & 0x7fff;
+                    int qx = q % RW, qy = q / RW;
+                    int nq = q + (d ? RW : 1);
+                    u64 k0 = key[q], k1 = key[nq];
+                    int tri0 = (k0 == ~0ull) ? -1 : (int)(unsigned)k0;
+                    int tri1 = (k1 == ~0ull) ? -1 : (int)(unsigned)k1;
+                    float zw0 = ord_unkey((unsigned)(k0 >> 32)), zw1 = ord_unkey((unsigned)(k1 >> 32));
+                    int t = (tri0 >= 0) ? tri0 : tri1;
+                    if (tri0 >= 0 && tri1 >= 0) t = (zw0 < zw1) ? tri0 : tri1;
+                    bool chose0 = !(t == tri1);
+                    int px = rx0 + qx, py = ry0 + qy;
+                    if (!chose0) {
+                        px += 1 - d;
+                        py += d;
+                    }
+                    float4 p[3], o[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) p[k] = pv[src.tri[3 * t + k]];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        int ov = opp[3 * t + k];
+                        o[k] = ((unsigned)ov < (unsigned)src.V) ? pv[ov] : p[k];
+                    }
+                    AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
+                    if (a.found) {
+                        pairA[d][q] = a.alpha;
+                        // keep for the backward pass if the destination pixel is interior to this tile
+                        int oq = (a.alpha > 0.f) ? q : nq;
+                        int ox = oq % RW, oy = oq / RW;
+                        bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
+                        if (oi && a.alpha != 0.f && (tri0 >= 0) != (tri1 >= 0)) {
+                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((tri1 >= 0 ? 1 : 0) << 14);
+                            it.tri = t;
+                            it.alpha = a.alpha;
+                            keep = want_grad;
+                        }
+                    }
+                }
+                int nfound;
+                int ioff = block_offset(keep, wave_tot, nfound);
+                if (keep) {
+                    int at = nitems + ioff;
+                    if (at < MAX_ITEMS)
+                        items[at] = it;
+                    else
+                        meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN
+                }
+                nitems = min(nitems + nfound, MAX_ITEMS);
             }
+            if (tid == 0) seg_end[l] = nitems;
+            __syncthreads();
+            EHR_PHASE(3);
+            // ---- gather the antialiased value of this link at my pixel (fixed order: down, left, right, up pair)
+            {
+                float cq = (key[myq] != ~0ull) ? 1.f : 0.f;
+                float val = cq;
+                float a;
+                a = pairA[1][myq - RW];
+                if (a < 0.f) val += a * (cq - ((key[myq - RW] != ~0ull) ? 1.f : 0.f));
+                a = pairA[0][myq - 1];
+                if (a < 0.f) val += a * (cq - ((key[myq - 1] != ~0ull) ? 1.f : 0.f));
+                a = pairA[0][myq];
+                if (a > 0.f) val += a * (((key[myq + 1] != ~0ull) ? 1.f : 0.f) - cq);
+                a = pairA[1][myq];
+                if (a > 0.f) val += a * (((key[myq + RW] != ~0ull) ? 1.f : 0.f) - cq);
+                acc += val;
+            }
+            __syncthreads();
+            EHR_PHASE(4);
         }
-        nitems = min(nitems + nfound, MAX_ITEMS);
-        if (tid == 0) seg_end[l] = nitems;
-        __syncthreads();
-        // ---- gather the antialiased value of this link at my pixel (fixed order: down, left, right, up pair)
+
+        // ---- composite, loss, mask write (image convention: row 0 = top)
+        float e2 = 0.f, gval = 0.f;
+        if (in_img) {
+            size_t im = ((size_t)b * H + (H - 1 - iy)) * W + ix;
+            float m = acc > 1.f ? 1.f : acc;
+            float e = m - ref[im];
+            e2 = e * e;
+            gval = (acc <= 1.f) ? 2.f * e : 0.f;
+            if (mask) mask[im] = m;
+        }
+        gpix[tid] = gval;
         {
-            float cq = (key[myq] != ~0ull) ? 1.f : 0.f;
-            float val = cq;
-            float a;
-            a = pairA[1][myq - RW];
-            if (a < 0.f) val += a * (cq - ((key[myq - RW] != ~0ull) ? 1.f : 0.f));
-            a = pairA[0][myq - 1];
-            if (a < 0.f) val += a * (cq - ((key[myq - 1] != ~0ull) ? 1.f : 0.f));
-            a = pairA[0][myq];
-            if (a > 0.f) val += a * (((key[myq + 1] != ~0ull) ? 1.f : 0.f) - cq);
-            a = pairA[1][myq];
-            if (a > 0.f) val += a * (((key[myq + RW] != ~0ull) ? 1.f : 0.f) - cq);
-            acc += val;
+            float s = wave_sum(e2);
+            if ((tid & 63) == 0) wred[tid >> 6][0] = s;
+            __syncthreads();
+            if (tid == 0) part[0] = ((wred[0][0] + wred[1][0]) + wred[2][0]) + wred[3][0];
+            __syncthreads();
         }
-        __syncthreads();
-    }
+        EHR_PHASE(5);
+        if (!want_grad) continue;
 
-    // ---- composite, loss, mask write (image convention: row 0 = top)
-    float e2 = 0.f, gval = 0.f;
-    if (in_img) {
-        size_t im = ((size_t)b * H + (H - 1 - iy)) * W + ix;
-        float m = acc > 1.f ? 1.f : acc;
-        float e = m - ref[im];
-        e2 = e * e;
-        gval = (acc <= 1.f) ? 2.f * e : 0.f;
-        if (mask) mask[im] = m;
-    }
-    gpix[tid] = gval;
-    {
-        float s = wave_sum(e2);
-        if ((tid & 63) == 0) wred[tid >> 6][0] = s;
-        __syncthreads();
-        if (tid == 0) part[0] = ((wred[0][0] + wred[1][0]) + wred[2][0]) + wred[3][0];
-        __syncthreads();
-    }
-    if (!want_grad) return;
-
-    // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
-    int seg0 = 0;
-    for (int l = 0; l < L; l++) {
-        if (cnt_l[l] == 0) continue;
-        const int seg1 = seg_end[l];
-        float G[12];
+        // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
+        int seg0 = 0;
+        for (int l = 0; l < L; l++) {
+            if (cnt_l[l] == 0) continue;
+            const int seg1 = seg_end[l];
+            float G[12];
 #pragma unroll
-        for (int k = 0; k < 12; k++) G[k] = 0.f;
-        for (int it = seg0 + tid; it < seg1; it += EHR_TILE_THREADS) {
-            Item im = items[it];
-            int q = im.packed & 1023, d = (im.packed >> 10) & 1, di = (im.packed >> 11) & 3;
-            int tri1 = (im.packed >> 13) & 1;
-            float dc = ((im.packed >> 14) & 1) ? 1.f : -1.f;
-            int nq = q + (d ? RW : 1);
-            int oq = (im.alpha > 0.f) ? q : nq;
-            int ox = oq % RW - 1, oy = oq / RW - 1;
-            float gi = gpix[oy * EHR_TILE_W + ox];
-            float dd = gi * dc;
-            if (gi == 0.f || dd == 0.f) continue;
-            int t = im.tri;
-            int vi[3] = {src.tri[3 * t], src.tri[3 * t + 1], src.tri[3 * t + 2]};
-            int i1 = (di < 2) ? di + 1 : 0;
-            int i2 = (i1 < 2) ? i1 + 1 : 0;
-            int v1 = vi[i1], v2 = vi[i2];
-            int qx = q % RW, qy = q / RW;
-            int px = rx0 + qx, py = ry0 + qy;
-            if (tri1) {
-                px += 1 - d;
-                py += d;
+            for (int k = 0; k < 12; k++) G[k] = 0.f;
+            for (int it = seg0 + tid; it < seg1; it += EHR_TILE_THREADS) {
+                Item im = items[it];
+                int q = im.packed & 1023, d = (im.packed >> 10) & 1, di = (im.packed >> 11) & 3;
+                int tri1 = (im.packed >> 13) & 1;
+                float dc = ((im.packed >> 14) & 1) ? 1.f : -1.f;
+                int nq = q + (d ? RW : 1);
+                int oq = (im.alpha > 0.f) ? q : nq;
+                int ox = oq % RW - 1, oy = oq / RW - 1;
+                float gi = gpix[oy * EHR_TILE_W + ox];
+                float dd = gi * dc;
+                if (gi == 0.f || dd == 0.f) continue;
+                int t = im.tri;
+                int i1 = (di < 2) ? di + 1 : 0;
+                int i2 = (i1 < 2) ? i1 + 1 : 0;
+                int v1 = src.tri[3 * t + i1], v2 = src.tri[3 * t + i2];
+                int qx = q % RW, qy = q / RW;
+                int px = rx0 + qx, py = ry0 + qy;
+                if (tri1) {
+                    px += 1 - d;
+                    py += d;
+                }
+                float g1[3], g2[3];
+                aa_pos_grad(pv[v1], pv[v2], px, py, d, im.alpha, dd, W, H, g1, g2);
+                const float* a1 = verts + 3 * (size_t)v1;
+                const float* a2 = verts + 3 * (size_t)v2;
+                float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) G[4 * r + c] += g1[r] * h1[c] + g2[r] * h2[c];
             }
-            float g1[3], g2[3];
-            aa_pos_grad(src.vertex(b, l, v1), src.vertex(b, l, v2), px, py, d, im.alpha, dd, W, H, g1, g2);
-            const float* a1 = src.verts + 3 * (size_t)v1;
-            const float* a2 = src.verts + 3 * (size_t)v2;
-            float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
+            seg0 = seg1;
 #pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) G[4 * r + c] += g1[r] * h1[c] + g2[r] * h2[c];
+            for (int k = 0; k < 12; k++) {
+                float s = wave_sum(G[k]);
+                if ((tid & 63) == 0) wred[tid >> 6][k] = s;
+            }
+            __syncthreads();
+            if (tid < 12) part[1 + 12 * l + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
+            __syncthreads();
         }
-        seg0 = seg1;
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-            float s = wave_sum(G[k]);
-            if ((tid & 63) == 0) wred[tid >> 6][k] = s;
-        }
-        __syncthreads();
-        if (tid < 12) part[1 + 12 * l + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
-        __syncthreads();
+        EHR_PHASE(6);
     }
 }
 
@@ -336,7 +402,7 @@ __global__ void __launch_bounds__(256) fused_reduce_kernel(BinGeom g, const int*
     if (j == L) {
         if (tid == 0) {
             float v = (float)red[0][0];
-            if (meta[1]) v = __int_as_float(0x7fc00000);  // overflow => NaN, never a silently wrong loss
+            if (meta[EHR_META_OVERFLOW]) v = __int_as_float(0x7fc00000);  // overflow => NaN, never a silently wrong loss
             loss[b] = v;
         }
     } else if (tid < 16) {
@@ -368,27 +434,34 @@ static BinGeom make_geom(int H, int W, int L) {
 }
 
 int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack) {
-    (void)V;
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_fused_plan: ctx is NULL");
-    if (B <= 0 || L <= 0 || L > MAX_LINKS || T < 0 || H <= 0 || W <= 0 || H > 32768 || W > 32768)
+    if (B <= 0 || L <= 0 || L > MAX_LINKS || V < 0 || T < 0 || H <= 0 || W <= 0 || H > 32768 || W > 32768)
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: bad sizes (1 <= L <= %d)", MAX_LINKS);
     if (!(slack >= 1.f)) slack = 4.f;
     BinGeom g = make_geom(H, W, L);
     size_t nkeys = (size_t)B * g.nt * L;
     if (nkeys > 0x3fffffff) return fail(EHR_ERR_INVALID, "ehr_fused_plan: too many (view, tile, link) queues");
     int rc;
-    if ((rc = ctx->counts.reserve((2 * nkeys + 4) * sizeof(int)))) return rc;
+    if ((rc = ctx->counts.reserve((2 * nkeys + 8 + 32) * sizeof(int)))) return rc;
     if ((rc = ctx->offsets.reserve(nkeys * sizeof(int)))) return rc;
-    // queue storage: every triangle lands in >= 1 tile; micro-triangles average ~1.3 tiles, big ones more.
+    // queue storage: a triangle is queued once per tile its bounding box (+1 pixel) touches
     size_t want = (size_t)((double)slack * (double)B * (double)std::max(T, 1)) + 65536;
-    want = std::min(want, (size_t)0x7fffffff);
+    want = std::min(want, (size_t)0x7fffffff / sizeof(int4));
     if (want > ctx->entries_cap) {
-        if ((rc = ctx->entries.reserve(want * sizeof(int)))) return rc;
+        if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
         ctx->entries_cap = want;
     }
     if ((rc = ctx->tile_part.reserve((size_t)B * g.nt * (1 + 12 * (size_t)L) * sizeof(float)))) return rc;
+    if ((rc = ctx->tile_list.reserve((size_t)2 * B * g.nt * sizeof(int)))) return rc;  // tile totals | work list
+    if ((rc = ctx->posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
+    int dev = 0;
+    EHR_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    EHR_HIP(hipGetDeviceProperties(&prop, dev));
+    ctx->num_cus = prop.multiProcessorCount;
     ctx->pB = B;
     ctx->pL = L;
+    ctx->pV = V;
     ctx->pT = T;
     ctx->pH = H;
     ctx->pW = W;
@@ -396,30 +469,36 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
 }
 
 int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
-                         const int32_t* opp, const float* mvp, const float* ref, int B, int L, int V, int T, int H,
-                         int W, float* mask, float* loss, float* grad_mvp, void* stream_) {
+                         const int32_t* vert_link, const int32_t* opp, const float* mvp, const float* ref, int B,
+                         int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream_) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_render_mask_loss: ctx is NULL");
-    if (!verts || !tris || !tri_link || !opp || !mvp || !ref || !loss)
+    if (!verts || !tris || !tri_link || !vert_link || !opp || !mvp || !ref || !loss)
         return fail(EHR_ERR_INVALID, "ehr_render_mask_loss: NULL tensor");
-    if (ctx->pB != B || ctx->pL != L || ctx->pT != T || ctx->pH != H || ctx->pW != W)
+    if (ctx->pB != B || ctx->pL != L || ctx->pV != V || ctx->pT != T || ctx->pH != H || ctx->pW != W)
         return fail(EHR_ERR_INVALID, "ehr_render_mask_loss: shape differs from the planned one; call ehr_fused_plan first");
     hipStream_t stream = (hipStream_t)stream_;
     BinGeom g = make_geom(H, W, L);
-    const int nkeys = B * g.nt * L;
+    const int ntiles = B * g.nt;
+    const int nkeys = ntiles * L;
     int* counts = (int*)ctx->counts.ptr;
     int* cursors = counts + nkeys;
     int* meta = counts + 2 * nkeys;
     int* offsets = (int*)ctx->offsets.ptr;
-    int* entries = (int*)ctx->entries.ptr;
+    int4* entries = (int4*)ctx->entries.ptr;
+    int* tile_total = (int*)ctx->tile_list.ptr;
+    int* worklist = tile_total + ntiles;
+    float4* posc = (float4*)ctx->posc.ptr;
+    float* tile_part = (float*)ctx->tile_part.ptr;
     const int ecap = (int)std::min(ctx->entries_cap, (size_t)0x7fffffff);
-    MvpSource src;
-    src.verts = verts;
+    ClipSource src;
+    src.pos = posc;
     src.tri = tris;
     src.tri_link = tri_link;
-    src.mvp = mvp;
+    src.ranges = nullptr;
     src.V = V;
     src.T = T;
     src.L = L;
+    src.image_stride = V;
 
     // optional per-stage events (measurement hook)
     hipEvent_t* ev = nullptr;
@@ -434,28 +513,43 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
         ctx->ev_used = need;
         EHR_HIP(hipEventRecord(ev[0], stream));
     }
-    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 4) * sizeof(int), stream));
+    // stage 0: clear queues, transform vertices, count
+    #ifdef EHR_PHASE_TIMING
+    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 8) * sizeof(int), stream));  // phase counters accumulate
+#else
+    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 8) * sizeof(int), stream));
+#endif
+    if (V > 0) {
+        fused_vertex_kernel<<<dim3((V + 255) / 256, B), 256, 0, stream>>>(verts, vert_link, mvp, V, L, posc);
+        EHR_LAUNCH_CHECK();
+    }
     dim3 bgrid((T + 255) / 256, B);
     if (T > 0) {
-        bin_kernel<MvpSource, 1, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
+        bin_kernel<1, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
         EHR_LAUNCH_CHECK();
     }
     if (ev) EHR_HIP(hipEventRecord(ev[1], stream));
-    bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nkeys, meta);
+    // stage 1: queue allocation + work list
+    bin_alloc_kernel<<<(ntiles + 255) / 256, 256, 0, stream>>>(counts, offsets, tile_total, worklist, ntiles, L, meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
+    // stage 2: fill
     if (T > 0) {
-        bin_kernel<MvpSource, 1, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries, ecap, meta);
+        bin_kernel<1, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries, ecap, meta);
         EHR_LAUNCH_CHECK();
     }
     if (ev) EHR_HIP(hipEventRecord(ev[3], stream));
-    dim3 tgrid(g.nt, B);
-    fused_tile_kernel<<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, counts, offsets, entries, ecap, opp, ref, mask,
-                                                             (float*)ctx->tile_part.ptr, grad_mvp ? 1 : 0, meta);
+    // stage 3: tiles -- streaming pass over the empty ones, persistent workgroups over the work list
+    fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
+    EHR_LAUNCH_CHECK();
+    const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * 3));
+    fused_tile_kernel<<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, verts, counts, offsets, entries, ecap, worklist,
+                                                             opp, ref, mask, tile_part, grad_mvp ? 1 : 0, meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
+    // stage 4: fixed-order reduction
     dim3 rgrid(L + 1, B);
-    fused_reduce_kernel<<<rgrid, 256, 0, stream>>>(g, counts, (const float*)ctx->tile_part.ptr, loss, grad_mvp, meta);
+    fused_reduce_kernel<<<rgrid, 256, 0, stream>>>(g, counts, tile_part, loss, grad_mvp, meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[5], stream));
     return EHR_OK;
@@ -469,7 +563,19 @@ int ehr_fused_status(ehr_ctx* ctx) {
     const size_t nkeys = (size_t)ctx->pB * g.nt * ctx->pL;
     int meta[4] = {0, 0, 0, 0};
     EHR_HIP(hipMemcpy(meta, (int*)ctx->counts.ptr + 2 * nkeys, sizeof(meta), hipMemcpyDeviceToHost));
-    if (meta[1])
+#ifdef EHR_PHASE_TIMING
+    {
+        unsigned long long ph[8];
+        EHR_HIP(hipMemcpy(ph, (int*)ctx->counts.ptr + 2 * nkeys + 8, sizeof(ph), hipMemcpyDeviceToHost));
+        const char* names[8] = {"pre-raster", "raster", "hit-discovery", "analysis", "gather", "composite", "backward", "(raster_wave)"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 7; i++) tot += ph[i];
+        for (int i = 0; i < 8; i++)
+            fprintf(stderr, "[ehr phase] %-14s %12llu cycles  %5.1f %%\n", names[i], ph[i], tot ? 100.0 * ph[i] / tot : 0.0);
+        EHR_HIP(hipMemset((int*)ctx->counts.ptr + 2 * nkeys + 8, 0, sizeof(ph)));
+    }
+#endif
+    if (meta[EHR_META_OVERFLOW])
         return fail(EHR_ERR_OVERFLOW, "fused path: a bin queue or a tile's blend list overflowed (%d queued, capacity %zu); "
                                       "re-plan with a larger slack", meta[0], ctx->entries_cap);
     return EHR_OK;

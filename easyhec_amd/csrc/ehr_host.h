@@ -48,9 +48,11 @@ struct ehr_ctx {
     size_t entries_cap = 0; // in entries
     int* host_pinned = nullptr;  // 4 ints, pinned, for the synchronous size read-back of the drop-in rasterize
     // fused path plan
-    int pB = 0, pL = 0, pT = 0, pH = 0, pW = 0;
+    int pB = 0, pL = 0, pV = 0, pT = 0, pH = 0, pW = 0;
+    int num_cus = 256;
+    ehr::Scratch posc;       // float4 [B * V] clip-space vertices of the current step
     ehr::Scratch tile_part;  // float [B * NT * (1 + 12 * L)] per-tile partial loss + MVP gradients
-    ehr::Scratch tile_list;  // int32 [B * NT] worklist of non-empty tiles
+    ehr::Scratch tile_list;  // int32 [2 * B * NT]: per-tile entry totals | work list of non-empty tiles
     // measurement hook (ehr_fused_timing): EHR_FUSED_STAGES + 1 events per recorded call
     bool timing = false;
     std::vector<hipEvent_t> ev;

@@ -44,35 +44,28 @@ void Scratch::release() {
 
 // ---- drop-in rasterize tile kernel -------------------------------------------------------------------------------
 
-// One workgroup per (image, tile).  LDS: 256 x 8-byte keys.  Writes rast (and rast_db) for every pixel of the tile.
+// One workgroup per (image, tile).  LDS: 256 x 8-byte keys + the waves' raster scratch.  Writes rast (and rast_db)
+// for every pixel of the tile.
 template <bool WITH_DB>
-__global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(PosSource src, BinGeom g,
+__global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSource src, BinGeom g,
                                                                       const int* __restrict__ counts,
                                                                       const int* __restrict__ offsets,
-                                                                      const int* __restrict__ entries, int entries_cap,
+                                                                      const int4* __restrict__ entries, int entries_cap,
                                                                       float4* __restrict__ rast,
                                                                       float4* __restrict__ rast_db) {
     __shared__ u64 key[EHR_TILE_W * EHR_TILE_H];
+    __shared__ WaveRaster wscratch[EHR_TILE_THREADS / 64];
     const int tile = blockIdx.x, b = blockIdx.y;
     const int tx = tile % g.ntx, ty = tile / g.ntx;
     const int rx0 = tx * EHR_TILE_W, ry0 = ty * EHR_TILE_H;
     const int tid = threadIdx.x;
     key[tid] = ~0ull;
     const int kidx = b * g.nt + tile;
-    const int n = counts[kidx];
+    int n = counts[kidx];
     const int off = offsets[kidx];
+    if (off + n > entries_cap) n = max(entries_cap - off, 0);
     __syncthreads();
-    for (int base = 0; base < n; base += EHR_TILE_THREADS) {
-        int i = base + tid;
-        bool active = i < n && off + i < entries_cap;
-        float4 p[3];
-        int t = 0, link;
-        if (active) {
-            t = entries[off + i];
-            active = src.fetch(b, t, p, link);
-        }
-        raster_wave<EHR_TILE_W, EHR_TILE_H, 12>(active, p, t, g.W, g.H, rx0, ry0, key);
-    }
+    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, wscratch);
     __syncthreads();
     // shade: one thread per pixel
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
@@ -83,9 +76,8 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(PosSource
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k != ~0ull) {
         int t = (int)(unsigned)(k & 0xffffffffu);
-        float4 p[3];
-        int link;
-        src.fetch(b, t, p, link);
+        const float4* pv = src.verts(b);
+        float4 p[3] = {pv[src.tri[3 * t]], pv[src.tri[3 * t + 1]], pv[src.tri[3 * t + 2]]};
         const float xs = 2.f / (float)g.W, xo = 1.f / (float)g.W - 1.f;
         const float ys = 2.f / (float)g.H, yo = 1.f / (float)g.H - 1.f;
         float fx = (float)ix * xs + xo;
@@ -227,6 +219,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->entries.release();
     c->tile_part.release();
     c->tile_list.release();
+    c->posc.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     (void)hipSetDevice(cur);
@@ -250,11 +243,11 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     g.L = 1;
     const int nkeys = B * g.nt;
     int rc;
-    if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + 4 + (ranges_host ? 2 * (size_t)B : 0)) * sizeof(int)))) return rc;
+    if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + 8 + (ranges_host ? 2 * (size_t)B : 0)) * sizeof(int)))) return rc;
     if ((rc = ctx->offsets.reserve((size_t)nkeys * sizeof(int)))) return rc;
     if (ctx->entries_cap == 0) {
         size_t want = std::max((size_t)1 << 20, (size_t)B * (size_t)std::max(T, 1) * 2);
-        if ((rc = ctx->entries.reserve(want * sizeof(int)))) return rc;
+        if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
         ctx->entries_cap = want;
     }
     int* counts = (int*)ctx->counts.ptr;
@@ -264,27 +257,29 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     int2* ranges_dev = nullptr;
     int tmax = T;
     if (ranges_host) {
-        ranges_dev = (int2*)(meta + 4);
+        ranges_dev = (int2*)(meta + 8);
         EHR_HIP(hipMemcpyAsync(ranges_dev, ranges_host, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
         tmax = 0;
         for (int b = 0; b < B; b++) tmax = std::max(tmax, ranges_host[2 * b + 1]);
         tmax = std::min(tmax, T);
     }
-    PosSource src;
+    ClipSource src;
     src.pos = (const float4*)pos;
     src.tri = tri;
+    src.tri_link = nullptr;
     src.ranges = ranges_dev;
     src.V = V;
     src.T = T;
-    src.instance = ranges_host ? 0 : 1;
+    src.L = 1;
+    src.image_stride = ranges_host ? 0 : V;
 
-    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 4) * sizeof(int), stream));
+    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 8) * sizeof(int), stream));
     dim3 bgrid((tmax + 255) / 256, B);
     if (tmax > 0) {
-        bin_kernel<PosSource, 0, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
+        bin_kernel<0, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
         EHR_LAUNCH_CHECK();
     }
-    bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nkeys, meta);
+    bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nullptr, nullptr, nkeys, 1, meta);
     EHR_LAUNCH_CHECK();
     // size read-back (the one synchronisation of this op): grow the queue storage if this frame needs more
     EHR_HIP(hipMemcpyAsync(ctx->host_pinned, meta, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -292,12 +287,12 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     size_t total = (size_t)ctx->host_pinned[0];
     if (total > ctx->entries_cap) {
         size_t want = total + total / 2;
-        if ((rc = ctx->entries.reserve(want * sizeof(int)))) return rc;
+        if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
         ctx->entries_cap = want;
     }
-    int* entries = (int*)ctx->entries.ptr;
+    int4* entries = (int4*)ctx->entries.ptr;
     if (tmax > 0) {
-        bin_kernel<PosSource, 0, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries,
+        bin_kernel<0, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries,
                                                                  (int)std::min(ctx->entries_cap, (size_t)0x7fffffff), meta);
         EHR_LAUNCH_CHECK();
     }

@@ -2,27 +2,33 @@
 // the fused mask-loss kernel.
 //
 // Pipeline (all on one stream, no host round trip on the fused path):
-//   bin_count  : one thread per (image, triangle): transform / clip / snap, atomically count the triangle into
-//                every (image, tile, link) queue its pixel bounding box (+halo) touches
-//   bin_alloc  : wave-aggregated bump allocation of queue storage (one atomic per wave, no scan kernel)
-//   bin_fill   : same traversal as bin_count, writes triangle ids into the queues
-//   tile kernel: one workgroup per 32x8-pixel tile; the tile's (+halo) depth/id buffer lives in LDS as 64-bit
-//                keys (ordered z/w << 32 | triangle id) updated with ds_min_u64, so the z-test result does not
-//                depend on queue order.  Micro-triangles (the median projected area is ~2 px) are rasterized by
-//                one lane each; larger ones are swept by the whole 64-lane wave (ballot + readlane broadcast).
+//   bin_count  : one thread per (image, triangle): gather the clip-space vertices, clip / snap, and count the
+//                triangle into every (image, tile, link) queue its pixel bounding box (+halo) touches.  Lanes of a
+//                wave that hit the same queue are merged with ballot/popcount so a hot tile costs one atomic per
+//                wave, not one per triangle.
+//   bin_alloc  : one thread per tile: sums the tile's per-link counts, bump-allocates queue storage with one atomic
+//                per wave (no scan kernel) and appends non-empty tiles to the work list.
+//   bin_fill   : same traversal as bin_count, writes {triangle, v0, v1, v2} into the queues.
+//   tile kernel: the tile's (+halo) depth/id buffer lives in LDS as 64-bit keys (ordered z/w << 32 | triangle id)
+//                updated with ds_min_u64, so the z-test result does not depend on queue order.  A wave takes 64
+//                queued triangles, prefix-sums their clamped bounding-box areas and splits the resulting pixel
+//                sequence EVENLY over its 64 lanes (each lane walks a contiguous run, stepping integer edge
+//                functions); covered fragments are compacted through an LDS ring with ballot/popcount and
+//                depth-tested 64 at a time, so neither the coverage walk nor the depth math runs on idle lanes.
 #pragma once
 #include "ehr_device.h"
 
 namespace ehr {
 
-// ---- triangle sources --------------------------------------------------------------------------------------------
+// ---- triangle source: clip-space vertices + indices -------------------------------------------------------------
 
-// drop-in rasterize: clip-space positions are given
-struct PosSource {
-    const float4* pos;
-    const int32_t* tri;
-    const int2* ranges;  // device [B] (start, count) or nullptr = all triangles
-    int V, T, instance;
+struct ClipSource {
+    const float4* pos;        // [B or 1][V] clip-space vertices
+    const int32_t* tri;       // [T][3]
+    const int32_t* tri_link;  // [T] link (queue) of each triangle, or nullptr = 0
+    const int2* ranges;       // device [B] (start, count) or nullptr = all triangles
+    int V, T, L;
+    int image_stride;         // V in instance mode, 0 when all images share the vertices (range mode)
     __device__ __forceinline__ void range(int b, int& t0, int& t1) const {
         t0 = 0;
         t1 = T;
@@ -32,43 +38,14 @@ struct PosSource {
             t1 = min(r.x + r.y, T);
         }
     }
-    __device__ __forceinline__ bool fetch(int b, int t, float4 p[3], int& link) const {
-        int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
-        link = 0;
-        if ((unsigned)v0 >= (unsigned)V || (unsigned)v1 >= (unsigned)V || (unsigned)v2 >= (unsigned)V) return false;
-        const float4* pb = pos + (instance ? (size_t)b * V : 0);
-        p[0] = pb[v0];
-        p[1] = pb[v1];
-        p[2] = pb[v2];
-        return true;
-    }
-};
-
-// fused path: object-space vertices + one MVP per (view, link)
-struct MvpSource {
-    const float* verts;
-    const int32_t* tri;
-    const int32_t* tri_link;
-    const float* mvp;  // [B, L, 16]
-    int V, T, L;
-    __device__ __forceinline__ void range(int, int& t0, int& t1) const {
-        t0 = 0;
-        t1 = T;
-    }
-    __device__ __forceinline__ float4 vertex(int b, int link, int v) const {
-        const float* M = mvp + ((size_t)b * L + link) * 16;
-        return transform_vertex(M, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
-    }
-    __device__ __forceinline__ bool fetch(int b, int t, float4 p[3], int& link) const {
-        int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
-        link = tri_link[t];
-        if ((unsigned)v0 >= (unsigned)V || (unsigned)v1 >= (unsigned)V || (unsigned)v2 >= (unsigned)V ||
-            (unsigned)link >= (unsigned)L)
-            return false;
-        p[0] = vertex(b, link, v0);
-        p[1] = vertex(b, link, v1);
-        p[2] = vertex(b, link, v2);
-        return true;
+    __device__ __forceinline__ const float4* verts(int b) const { return pos + (size_t)b * image_stride; }
+    __device__ __forceinline__ bool indices(int t, int& v0, int& v1, int& v2, int& link) const {
+        v0 = tri[3 * t];
+        v1 = tri[3 * t + 1];
+        v2 = tri[3 * t + 2];
+        link = tri_link ? tri_link[t] : 0;
+        return (unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V &&
+               (unsigned)link < (unsigned)L;
     }
 };
 
@@ -78,6 +55,11 @@ struct BinGeom {
     int W, H, ntx, nty, nt;  // tiles per row / column / image
     int L;                   // queues per tile
 };
+
+// meta words (device int[8]) shared by the bin / tile kernels
+#define EHR_META_TOTAL 0     // entries allocated
+#define EHR_META_OVERFLOW 1  // sticky overflow flag
+#define EHR_META_NWORK 2     // non-empty tiles appended to the work list
 
 // tile range touched by the triangle's pixel bounding box grown by HALO pixels
 template <int HALO>
@@ -103,78 +85,145 @@ __device__ __forceinline__ bool tri_tile_range(const float4 p[3], int W, int H, 
     return true;
 }
 
-// FILL = false: count; FILL = true: write ids.  grid.x covers triangles, grid.y = image.
-template <class Src, int HALO, bool FILL>
-__global__ void __launch_bounds__(256) bin_kernel(Src src, BinGeom g, int* __restrict__ counts, int* __restrict__ cursors,
-                                                  const int* __restrict__ offsets, int* __restrict__ entries,
-                                                  int entries_cap, int* __restrict__ meta) {
-    int b = blockIdx.y;
+// FILL = false: count; FILL = true: write entries.  grid.x covers triangles, grid.y = image.
+//
+// Device-scope atomics on one address serialise at the memory side (~12 ns each on MI355X), and a dense tile's queue
+// receives thousands of triangles, so the workgroup first merges its updates in an LDS hash (key -> count, LDS atomics)
+// and then issues ONE global atomic per distinct queue; each triangle keeps the rank the LDS atomic returned, which
+// becomes its slot inside the range the workgroup reserved.
+#define EHR_BIN_SLOTS 1024   // LDS hash slots per workgroup (256 triangles x up to EHR_BIN_LOCAL tiles each)
+#define EHR_BIN_LOCAL 3      // tiles per triangle merged through LDS; further tiles use direct global atomics
+
+template <int HALO, bool FILL>
+__global__ void __launch_bounds__(256) bin_kernel(ClipSource src, BinGeom g, int* __restrict__ counts,
+                                                  int* __restrict__ cursors, const int* __restrict__ offsets,
+                                                  int4* __restrict__ entries, int entries_cap, int* __restrict__ meta) {
+    __shared__ int hkey[EHR_BIN_SLOTS];
+    __shared__ int hcnt[EHR_BIN_SLOTS];  // count, then (FILL) the base of the reserved range
+    for (int i = threadIdx.x; i < EHR_BIN_SLOTS; i += 256) {
+        hkey[i] = -1;
+        hcnt[i] = 0;
+    }
+    const int b = blockIdx.y;
     int t0, t1;
     src.range(b, t0, t1);
-    int t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= t1) return;
-    float4 p[3];
-    int link;
-    if (!src.fetch(b, t, p, link)) return;
-    int tx0, tx1, ty0, ty1;
-    if (!tri_tile_range<HALO>(p, g.W, g.H, tx0, tx1, ty0, ty1)) return;
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
-            int key = ((b * g.nt) + ty * g.ntx + tx) * g.L + link;
-            if (!FILL) {
-                atomicAdd(&counts[key], 1);
-            } else {
-                int slot = atomicAdd(&cursors[key], 1);
-                int at = offsets[key] + slot;
+    const int t = t0 + blockIdx.x * blockDim.x + threadIdx.x;
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1, link = 0, v0 = 0, v1 = 0, v2 = 0;
+    if (t < t1 && src.indices(t, v0, v1, v2, link)) {
+        const float4* pv = src.verts(b);
+        float4 p[3] = {pv[v0], pv[v1], pv[v2]};
+        if (!tri_tile_range<HALO>(p, g.W, g.H, tx0, tx1, ty0, ty1)) {
+            tx1 = -1;
+            ty1 = -1;
+        }
+    }
+    const int nx = tx1 - tx0 + 1;
+    const int ntile = (tx1 >= tx0 && ty1 >= ty0) ? nx * (ty1 - ty0 + 1) : 0;
+    __syncthreads();
+    // phase 1: merge the first EHR_BIN_LOCAL tiles of every triangle in the LDS hash
+    int slot[EHR_BIN_LOCAL], rank[EHR_BIN_LOCAL];
+#pragma unroll
+    for (int c = 0; c < EHR_BIN_LOCAL; c++) {
+        slot[c] = -1;
+        rank[c] = 0;
+        if (c < ntile) {
+            const int ty = ty0 + c / nx, tx = tx0 + c % nx;
+            const int key = ((b * g.nt) + ty * g.ntx + tx) * g.L + link;
+            unsigned h = ((unsigned)key * 2654435761u) >> 22;  // 10 bits
+            for (;;) {
+                int cur = hkey[h];
+                if (cur == -1) {
+                    int prev = atomicCAS(&hkey[h], -1, key);
+                    cur = (prev == -1) ? key : prev;
+                }
+                if (cur == key) break;
+                h = (h + 1) & (EHR_BIN_SLOTS - 1);
+            }
+            slot[c] = (int)h;
+            rank[c] = atomicAdd(&hcnt[h], 1);
+        }
+    }
+    __syncthreads();
+    // phase 2: one global atomic per distinct queue touched by this workgroup
+    for (int i = threadIdx.x; i < EHR_BIN_SLOTS; i += 256) {
+        const int key = hkey[i];
+        if (key >= 0) {
+            const int c = hcnt[i];
+            if (FILL)
+                hcnt[i] = atomicAdd(&cursors[key], c);
+            else
+                atomicAdd(&counts[key], c);
+        }
+    }
+    if (FILL) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < EHR_BIN_LOCAL; c++) {
+            if (slot[c] >= 0) {
+                const int key = hkey[slot[c]];
+                const int at = offsets[key] + hcnt[slot[c]] + rank[c];
                 if (at < entries_cap)
-                    entries[at] = t;
+                    entries[at] = make_int4(t, v0, v1, v2);
                 else
-                    meta[1] = 1;  // overflow
+                    meta[EHR_META_OVERFLOW] = 1;
             }
         }
+    }
+    // phase 3: the remaining tiles of large triangles, directly
+    for (int c = EHR_BIN_LOCAL; c < ntile; c++) {
+        const int ty = ty0 + c / nx, tx = tx0 + c % nx;
+        const int key = ((b * g.nt) + ty * g.ntx + tx) * g.L + link;
+        if (FILL) {
+            const int at = offsets[key] + atomicAdd(&cursors[key], 1);
+            if (at < entries_cap)
+                entries[at] = make_int4(t, v0, v1, v2);
+            else
+                meta[EHR_META_OVERFLOW] = 1;
+        } else {
+            atomicAdd(&counts[key], 1);
+        }
+    }
 }
 
-// offsets[key] = start of the key's queue; meta[0] = total entries.  One atomic per wave.
+// One thread per (image, tile): offsets for the tile's L queues, per-tile total, work list of non-empty tiles.
 static __global__ void __launch_bounds__(256) bin_alloc_kernel(const int* __restrict__ counts, int* __restrict__ offsets,
-                                                        int nkeys, int* __restrict__ meta) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int c = (i < nkeys) ? counts[i] : 0;
-    int lane = threadIdx.x & 63;
+                                                               int* __restrict__ tile_total, int* __restrict__ worklist,
+                                                               int ntiles, int L, int* __restrict__ meta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (i < ntiles)
+        for (int l = 0; l < L; l++) c += counts[(size_t)i * L + l];
+    const int lane = threadIdx.x & 63;
     int incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
     }
-    int total = __shfl(incl, 63, 64);
-    int base = 0;
-    if (lane == 63 && total > 0) base = atomicAdd(&meta[0], total);
+    const int total = __shfl(incl, 63, 64);
+    const u64 ne = __ballot(c > 0);
+    int base = 0, wbase = 0;
+    if (lane == 63 && total > 0) {
+        base = atomicAdd(&meta[EHR_META_TOTAL], total);
+        wbase = atomicAdd(&meta[EHR_META_NWORK], __popcll(ne));
+    }
     base = __shfl(base, 63, 64);
-    if (i < nkeys) offsets[i] = base + incl - c;
+    wbase = __shfl(wbase, 63, 64);
+    if (i < ntiles) {
+        int run = base + incl - c;
+        for (int l = 0; l < L; l++) {
+            offsets[(size_t)i * L + l] = run;
+            run += counts[(size_t)i * L + l];
+        }
+        if (tile_total) tile_total[i] = c;
+        if (worklist && c > 0) {
+            const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            worklist[wbase + __popcll(ne & lt)] = i;
+        }
+    }
 }
 
 // ---- LDS tile raster ---------------------------------------------------------------------------------------------
-
-// Everything a lane needs to rasterize one (sub-)triangle into a region; broadcast with readlane for the
-// cooperative path.
-struct RasterJob {
-    float4 p[3];  // parent clip-space vertices (depth)
-    Coverage cv;  // snapped sub-triangle, bbox already clamped to the region
-    int t;
-};
-
-template <class T>
-__device__ __forceinline__ T bcast(T v, int src) {
-    return __shfl(v, src, 64);
-}
-__device__ __forceinline__ float4 bcast4(float4 v, int src) {
-    float4 r;
-    r.x = __shfl(v.x, src, 64);
-    r.y = __shfl(v.y, src, 64);
-    r.z = __shfl(v.z, src, 64);
-    r.w = __shfl(v.w, src, 64);
-    return r;
-}
 
 __device__ __forceinline__ void depth_test_write(const float4 p[3], int t, int ix, int iy, int W, int H, u64* slot) {
     const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
@@ -187,85 +236,326 @@ __device__ __forceinline__ void depth_test_write(const float4 p[3], int t, int i
     if (zw >= -1.f && zw <= 1.f) atomicMin(slot, ((u64)ord_key(zw) << 32) | (unsigned)t);
 }
 
-// Rasterize this lane's triangle `t` (active lanes only) into the LDS key buffer of a RW x RH region whose lower-left
-// pixel is (rx0, ry0).  Must be called by all 64 lanes of the wave (inactive lanes pass active = false).
-template <int RW, int RH, int SMALL>
-__device__ __forceinline__ void raster_wave(bool active, const float4 p[3], int t, int W, int H, int rx0, int ry0,
-                                            u64* __restrict__ key) {
+// Slow path (rare): a triangle that needs near-plane clipping or whose snapped vertices are too far from the region
+// for 32-bit edge functions.  Rasterized serially by its own lane with 64-bit edge functions.
+template <int RW, int RH>
+__device__ __noinline__ void raster_lane_slow(const float4 p[3], int t, int W, int H, int rx0, int ry0,
+                                              u64* __restrict__ key) {
     float4 q[4];
-    int n = active ? clip_near(p, q) : 0;
-    Coverage cvs[2];
-    unsigned big = 0;  // bit s: sub-triangle s is pending for the cooperative path
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        bool have = s + 2 < n;
-        Coverage cv;
-        cv.valid = false;
-        if (have) {
-            cv = setup_coverage(q[0], q[s + 1], q[s + 2], W, H);
-            cv.ix0 = max(cv.ix0, rx0);
-            cv.iy0 = max(cv.iy0, ry0);
-            cv.ix1 = min(cv.ix1, rx0 + RW - 1);
-            cv.iy1 = min(cv.iy1, ry0 + RH - 1);
-            if (cv.ix0 > cv.ix1 || cv.iy0 > cv.iy1) cv.valid = false;
+    int n = clip_near(p, q);
+    for (int s = 0; s + 2 < n; s++) {
+        Coverage cv = setup_coverage(q[0], q[s + 1], q[s + 2], W, H);
+        if (!cv.valid) continue;
+        cv.ix0 = max(cv.ix0, rx0);
+        cv.iy0 = max(cv.iy0, ry0);
+        cv.ix1 = min(cv.ix1, rx0 + RW - 1);
+        cv.iy1 = min(cv.iy1, ry0 + RH - 1);
+        if (cv.ix0 > cv.ix1 || cv.iy0 > cv.iy1) continue;
+        EdgeEval ee = setup_edges(cv, cv.ix0, cv.iy0, W, H);
+        for (int iy = cv.iy0; iy <= cv.iy1; iy++) {
+            i64 e0 = ee.e[0], e1 = ee.e[1], e2 = ee.e[2];
+            for (int ix = cv.ix0; ix <= cv.ix1; ix++) {
+                if ((e0 | e1 | e2) >= 0) depth_test_write(p, t, ix, iy, W, H, &key[(iy - ry0) * RW + (ix - rx0)]);
+                e0 += ee.sx[0];
+                e1 += ee.sx[1];
+                e2 += ee.sx[2];
+            }
+            ee.e[0] += ee.sy[0];
+            ee.e[1] += ee.sy[1];
+            ee.e[2] += ee.sy[2];
         }
-        cvs[s] = cv;
-        if (cv.valid) {
-            int bw = cv.ix1 - cv.ix0 + 1, bh = cv.iy1 - cv.iy0 + 1;
-            if (bw * bh <= SMALL) {
-                EdgeEval ee = setup_edges(cv, cv.ix0, cv.iy0, W, H);
-                for (int iy = cv.iy0; iy <= cv.iy1; iy++) {
-                    i64 e0 = ee.e[0], e1 = ee.e[1], e2 = ee.e[2];
-                    for (int ix = cv.ix0; ix <= cv.ix1; ix++) {
-                        if ((e0 | e1 | e2) >= 0)
-                            depth_test_write(p, t, ix, iy, W, H, &key[(iy - ry0) * RW + (ix - rx0)]);
-                        e0 += ee.sx[0];
-                        e1 += ee.sx[1];
-                        e2 += ee.sx[2];
+    }
+}
+
+// The fast (32-bit) rasterizer handles a triangle iff it needs no near-plane clipping and its snapped vertices lie
+// within +-8192 sub-pixels (512 pixels) of the region origin.  Same predicate as in raster_wave.
+template <int RW, int RH>
+__device__ __forceinline__ bool needs_slow_path(const float4 p[3], int W, int H, int rx0, int ry0) {
+    const bool simple = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (p[0].z + p[0].w >= 0.f) &&
+                        (p[1].z + p[1].w >= 0.f) && (p[2].z + p[2].w >= 0.f);
+    if (!simple) return true;
+    Coverage cv = setup_coverage(p[0], p[1], p[2], W, H);
+    if (!cv.valid) return false;
+    int bx0 = max(cv.ix0, rx0), by0 = max(cv.iy0, ry0);
+    int bx1 = min(cv.ix1, rx0 + RW - 1), by1 = min(cv.iy1, ry0 + RH - 1);
+    if (bx0 > bx1 || by0 > by1) return false;
+    const int ox = 16 * rx0 + 8 - 8 * W, oy = 16 * ry0 + 8 - 8 * H;
+    bool fits = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        i64 rx = (i64)cv.X[k] - ox, ry = (i64)cv.Y[k] - oy;
+        fits = fits && rx >= -8192 && rx <= 8192 && ry >= -8192 && ry <= 8192;
+    }
+    return !fits;
+}
+
+// Per-wave LDS scratch of the balanced rasterizer.
+struct WaveRaster {
+    int pre[65];        // exclusive prefix of the jobs' clamped bounding-box areas (+ total)
+    unsigned xy[64][3]; // snapped vertices relative to the region origin, int16 x | int16 y << 16
+    unsigned box[64];   // bbox inside the region: x0 | y0 << 8 | w << 16 | h << 24
+    int tri[64];
+    float4 pf[64][3];   // clip-space vertices (depth)
+    unsigned frag[128]; // ring of covered fragments: region pixel index | job << 16
+};
+
+#define EHR_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// Edge functions of a staged job in 32-bit arithmetic, evaluated at the job's bbox origin.
+struct Edge32 {
+    int e[3], sx[3], sy[3];
+};
+
+__device__ __forceinline__ Edge32 job_edges(const unsigned xy[3], int bx0, int by0) {
+    Edge32 ed;
+    int X[3], Y[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        X[k] = (int)(short)(xy[k] & 0xffffu);
+        Y[k] = (int)(short)(xy[k] >> 16);
+    }
+    const int Px = 16 * bx0, Py = 16 * by0;  // region pixel (0,0) has its centre at the origin
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int j = (k == 2) ? 0 : k + 1;
+        const int dX = X[j] - X[k], dY = Y[j] - Y[k];
+        const bool tl = (dY < 0) || (dY == 0 && dX < 0);
+        ed.e[k] = dX * (Py - Y[k]) - dY * (Px - X[k]) - (tl ? 0 : 1);
+        ed.sx[k] = -16 * dY;
+        ed.sy[k] = 16 * dX;
+    }
+    return ed;
+}
+
+// Depth-test `n` (<= 64) fragments from the ring, one per lane.
+template <int RW>
+__device__ __forceinline__ void drain_fragments(WaveRaster* ws, int head, int n, int W, int H, int rx0, int ry0,
+                                                u64* __restrict__ key) {
+    const int lane = lane_id();
+    if (lane < n) {
+        unsigned f = ws->frag[(head + lane) & 127];
+        int pix = f & 0xffffu, j = f >> 16;
+        float4 p[3] = {ws->pf[j][0], ws->pf[j][1], ws->pf[j][2]};
+        int py = pix / RW, px = pix - py * RW;
+        depth_test_write(p, ws->tri[j], rx0 + px, ry0 + py, W, H, &key[pix]);
+    }
+}
+
+// Rasterize up to 64 triangles (one per lane; inactive lanes pass active = false) into the LDS key buffer of the
+// RW x RH region whose lower-left pixel is (rx0, ry0).  Must be called by all 64 lanes of the wave.
+// Returns true on lanes whose triangle needs the slow path (near-plane clipping / far-away vertices); the caller
+// rasterizes those with raster_lane_slow where few registers are live.
+template <int RW, int RH>
+__device__ __forceinline__ bool raster_wave(bool active, const float4 p[3], int t, int W, int H, int rx0, int ry0,
+                                            u64* __restrict__ key, WaveRaster* __restrict__ ws) {
+    const int lane = lane_id();
+    // ---- per-lane setup
+    bool fast = false, slow = false;
+    Coverage cv;
+    cv.valid = false;
+    int area = 0;
+    unsigned pxy[3] = {0, 0, 0}, pbox = 0;
+    if (active) {
+        const bool simple = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (p[0].z + p[0].w >= 0.f) &&
+                            (p[1].z + p[1].w >= 0.f) && (p[2].z + p[2].w >= 0.f);
+        if (simple) {
+            cv = setup_coverage(p[0], p[1], p[2], W, H);
+            if (cv.valid) {
+                int bx0 = max(cv.ix0, rx0), by0 = max(cv.iy0, ry0);
+                int bx1 = min(cv.ix1, rx0 + RW - 1), by1 = min(cv.iy1, ry0 + RH - 1);
+                if (bx0 <= bx1 && by0 <= by1) {
+                    // region-relative snapped coordinates must fit 14 bits for the 32-bit edge functions
+                    const int ox = 16 * rx0 + 8 - 8 * W, oy = 16 * ry0 + 8 - 8 * H;
+                    bool fits = true;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        i64 rx = (i64)cv.X[k] - ox, ry = (i64)cv.Y[k] - oy;
+                        fits = fits && rx >= -8192 && rx <= 8192 && ry >= -8192 && ry <= 8192;
+                        pxy[k] = ((unsigned)(int)rx & 0xffffu) | ((unsigned)(int)ry << 16);
                     }
-                    ee.e[0] += ee.sy[0];
-                    ee.e[1] += ee.sy[1];
-                    ee.e[2] += ee.sy[2];
+                    if (fits) {
+                        fast = true;
+                        int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+                        area = bw * bh;
+                        pbox = (unsigned)(bx0 - rx0) | ((unsigned)(by0 - ry0) << 8) | ((unsigned)bw << 16) |
+                               ((unsigned)bh << 24);
+                    } else {
+                        slow = true;
+                    }
                 }
-            } else {
-                big |= 1u << s;
+            }
+        } else {
+            slow = true;
+        }
+    }
+    // ---- stage jobs, prefix-sum the areas
+    int incl = area;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const int S = __shfl(incl, 63, 64);
+    if (S == 0) return slow;  // wave-uniform
+    ws->pre[lane] = incl - area;
+    if (lane == 63) ws->pre[64] = S;
+    ws->xy[lane][0] = pxy[0];
+    ws->xy[lane][1] = pxy[1];
+    ws->xy[lane][2] = pxy[2];
+    ws->box[lane] = pbox;
+    ws->tri[lane] = t;
+    if (fast) {
+        ws->pf[lane][0] = p[0];
+        ws->pf[lane][1] = p[1];
+        ws->pf[lane][2] = p[2];
+    }
+    EHR_WAVE_LDS_FENCE();
+
+    // ---- each lane walks a contiguous run of K pixels of the concatenated bounding boxes
+    const int K = (S + 63) >> 6;
+    const int start = lane * K, end = min(start + K, S);
+    int j = 0, bw = 1, bh = 1, dx = 0, dy = 0, pix = 0;
+    Edge32 ed;
+    int er0 = 0, er1 = 0, er2 = 0;  // edge values at the start of the current row
+    ed.e[0] = ed.e[1] = ed.e[2] = -1;
+    ed.sx[0] = ed.sx[1] = ed.sx[2] = 0;
+    ed.sy[0] = ed.sy[1] = ed.sy[2] = 0;
+    if (start < end) {
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            int mid = (lo + hi + 1) >> 1;
+            if (ws->pre[mid] <= start)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        j = lo;
+        unsigned bx = ws->box[j];
+        int bx0 = bx & 255, by0 = (bx >> 8) & 255;
+        bw = (bx >> 16) & 255;
+        bh = bx >> 24;
+        unsigned xy[3] = {ws->xy[j][0], ws->xy[j][1], ws->xy[j][2]};
+        ed = job_edges(xy, bx0, by0);
+        int o = start - ws->pre[j];
+        dy = o / bw;
+        dx = o - dy * bw;
+        er0 = ed.e[0] + dy * ed.sy[0];
+        er1 = ed.e[1] + dy * ed.sy[1];
+        er2 = ed.e[2] + dy * ed.sy[2];
+        ed.e[0] = er0 + dx * ed.sx[0];
+        ed.e[1] = er1 + dx * ed.sx[1];
+        ed.e[2] = er2 + dx * ed.sx[2];
+        pix = (by0 + dy) * RW + bx0 + dx;
+    }
+    int qhead = 0, qcount = 0;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma nounroll
+    for (int it = 0; it < K; it++) {
+        const bool act = start + it < end;
+        const bool inside = act && ((ed.e[0] | ed.e[1] | ed.e[2]) >= 0);
+        const u64 m = __ballot(inside);
+        if (m) {
+            if (inside) ws->frag[(qhead + qcount + __popcll(m & lt)) & 127] = (unsigned)pix | ((unsigned)j << 16);
+            qcount += __popcll(m);
+            if (qcount >= 64) {
+                EHR_WAVE_LDS_FENCE();
+                drain_fragments<RW>(ws, qhead, 64, W, H, rx0, ry0, key);
+                qhead = (qhead + 64) & 127;
+                qcount -= 64;
+            }
+        }
+        if (act && start + it + 1 < end) {
+            dx++;
+            pix++;
+            ed.e[0] += ed.sx[0];
+            ed.e[1] += ed.sx[1];
+            ed.e[2] += ed.sx[2];
+            if (dx == bw) {
+                dx = 0;
+                dy++;
+                pix += RW - bw;
+                er0 += ed.sy[0];
+                er1 += ed.sy[1];
+                er2 += ed.sy[2];
+                ed.e[0] = er0;
+                ed.e[1] = er1;
+                ed.e[2] = er2;
+                if (dy == bh) {  // next job with a non-empty box
+                    do {
+                        j++;
+                    } while (ws->pre[j + 1] == ws->pre[j]);
+                    unsigned bx = ws->box[j];
+                    int bx0 = bx & 255, by0 = (bx >> 8) & 255;
+                    bw = (bx >> 16) & 255;
+                    bh = bx >> 24;
+                    unsigned xy[3] = {ws->xy[j][0], ws->xy[j][1], ws->xy[j][2]};
+                    ed = job_edges(xy, bx0, by0);
+                    er0 = ed.e[0];
+                    er1 = ed.e[1];
+                    er2 = ed.e[2];
+                    dy = 0;
+                    pix = by0 * RW + bx0;
+                }
             }
         }
     }
-    // cooperative sweep of the big ones: wave-uniform loop over (lane, sub-triangle)
-    const int lane = lane_id();
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        u64 pending = __ballot((big >> s) & 1u);
-        while (pending) {
-            int src = __ffsll((long long)pending) - 1;
-            pending &= pending - 1;
-            float4 bp[3];
-            bp[0] = bcast4(p[0], src);
-            bp[1] = bcast4(p[1], src);
-            bp[2] = bcast4(p[2], src);
-            Coverage cv;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                cv.X[k] = bcast(cvs[s].X[k], src);
-                cv.Y[k] = bcast(cvs[s].Y[k], src);
-            }
-            cv.ix0 = bcast(cvs[s].ix0, src);
-            cv.ix1 = bcast(cvs[s].ix1, src);
-            cv.iy0 = bcast(cvs[s].iy0, src);
-            cv.iy1 = bcast(cvs[s].iy1, src);
-            int bt = bcast(t, src);
-            int bw = cv.ix1 - cv.ix0 + 1, bh = cv.iy1 - cv.iy0 + 1;
-            EdgeEval ee = setup_edges(cv, cv.ix0, cv.iy0, W, H);
-            for (int i = lane; i < bw * bh; i += 64) {
-                int dy = i / bw, dx = i - dy * bw;
-                i64 e0 = ee.e[0] + dx * ee.sx[0] + dy * ee.sy[0];
-                i64 e1 = ee.e[1] + dx * ee.sx[1] + dy * ee.sy[1];
-                i64 e2 = ee.e[2] + dx * ee.sx[2] + dy * ee.sy[2];
-                if ((e0 | e1 | e2) >= 0) {
-                    int ix = cv.ix0 + dx, iy = cv.iy0 + dy;
-                    depth_test_write(bp, bt, ix, iy, W, H, &key[(iy - ry0) * RW + (ix - rx0)]);
-                }
+    if (qcount) {
+        EHR_WAVE_LDS_FENCE();
+        drain_fragments<RW>(ws, qhead, qcount, W, H, rx0, ry0, key);
+    }
+    EHR_WAVE_LDS_FENCE();  // scratch is reused by the next call
+    return slow;
+}
+
+// Rasterize one queue (n entries at `ent`) into `key` with all waves of the workgroup; entries are split evenly
+// over the waves.  Callers put barriers around it.
+#ifdef EHR_PHASE_TIMING
+__device__ unsigned long long* ehr_dbg_cycles = nullptr;  // profiling build: cycles inside raster_wave (wave 0)
+#endif
+
+template <int RW, int RH>
+__device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const int4* __restrict__ ent, int n, int W,
+                                             int H, int rx0, int ry0, u64* __restrict__ key,
+                                             WaveRaster* __restrict__ ws_all) {
+    const int nw = EHR_TILE_THREADS / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = (n + nw - 1) / nw;
+    const int w0 = wave * per, w1 = min(w0 + per, n);
+    WaveRaster* ws = ws_all + wave;
+    const float4* pv = src.verts(b);
+    int nslow = 0;  // wave-uniform: entries of this wave's share that need the slow path
+#pragma nounroll
+    for (int base = w0; base < w1; base += 64) {  // wave-uniform bounds
+        const int i = base + lane;
+        const bool active = i < w1;
+        float4 p[3];
+        int t = 0;
+        if (active) {
+            int4 e = ent[i];
+            t = e.x;
+            p[0] = pv[e.y];
+            p[1] = pv[e.z];
+            p[2] = pv[e.w];
+        }
+#ifdef EHR_PHASE_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long tq0 = __builtin_readcyclecounter();
+#endif
+        const bool slow = raster_wave<RW, RH>(active, p, t, W, H, rx0, ry0, key, ws);
+#ifdef EHR_PHASE_TIMING
+        if (threadIdx.x == 0 && ehr_dbg_cycles) atomicAdd(ehr_dbg_cycles, (unsigned long long)(__builtin_readcyclecounter() - tq0));
+#endif
+        nslow += __popcll(__ballot(slow));
+    }
+    if (nslow) {  // rare: second sweep over this wave's share, slow triangles only, one per lane
+#pragma nounroll
+        for (int base = w0; base < w1; base += 64) {
+            const int i = base + lane;
+            if (i < w1) {
+                int4 e = ent[i];
+                float4 p[3] = {pv[e.y], pv[e.z], pv[e.w]};
+                if (needs_slow_path<RW, RH>(p, W, H, rx0, ry0)) raster_lane_slow<RW, RH>(p, e.x, W, H, rx0, ry0, key);
             }
         }
     }

@@ -1,0 +1,118 @@
+"""``FusedPoseStep`` -- one optimisation step of /root/reference/easyhec/trainer/rbsolver.py:29-43 as a fixed chain of
+HIP launches with no host round trip: pose_forward -> {vertex transform, bin count/alloc/fill, tile kernels,
+reduce} -> pose_backward -> [all-reduce of 8 floats when data-parallel] -> Adam.
+
+It operates IN PLACE on an :class:`easyhec_amd.rb_solver.RBSolver`'s ``dof`` parameter and ``history_ops`` buffer and
+keeps torch.optim.Adam-compatible state (exp_avg, exp_avg_sq, step), so it is interchangeable with the autograd path
+of :class:`easyhec_amd.trainer.RBSolverTrainer` step for step (tests/test_gpu_fast.py)."""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, fused
+
+__all__ = ["FusedPoseStep"]
+
+
+def _f(x):
+    return ctypes.c_float(float(x))
+
+
+class FusedPoseStep:
+    def __init__(self, model, batch, lr=0.003, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0005, near=0.001, far=10.0,
+                 process_group=None):
+        self.model = model
+        self.renderer = model._ensure_renderer()
+        self.scene = model._ensure_scene()
+        self.glctx = self.renderer.glctx
+        dev = model.dof.device
+        self.dev = dev
+        self.H, self.W = model.H, model.W
+        self.ref = batch["mask"].to(dev, torch.float32).contiguous()
+        self.link_poses = batch["link_poses"].to(dev, torch.float32).contiguous()
+        self.K = batch["K"][0].to(dev, torch.float32).contiguous()
+        self.B, self.L = self.link_poses.shape[0], self.link_poses.shape[1]
+        assert self.L == self.scene.num_links and self.ref.shape == (self.B, self.H, self.W)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.near, self.far = near, far
+        self.pg = process_group
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+        # optimiser state (torch.optim.Adam names)
+        self.exp_avg = torch.zeros(6, device=dev)
+        self.exp_avg_sq = torch.zeros(6, device=dev)
+        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        # work buffers, allocated once
+        self.mvp = torch.empty((self.B, self.L, 4, 4), device=dev)
+        self.grad_mvp = torch.empty((self.B, self.L, 4, 4), device=dev)
+        self.tc_jac = torch.empty((7, 16), device=dev)
+        self.loss_b = torch.empty((self.B,), device=dev)
+        self.red = torch.empty((8,), device=dev)
+        self.loss = torch.zeros((1,), device=dev)
+        self.grad = torch.zeros((6,), device=dev)
+        self.mask = torch.empty((self.B, self.H, self.W), device=dev)
+        fused._ensure_plan(self.glctx, self.B, self.L, self.scene.num_verts, self.scene.num_tris, self.H, self.W)
+        self._graph = None
+
+    # -- one step -------------------------------------------------------------------------------------------------
+    def _enqueue(self, want_mask):
+        lib = _lib.lib()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        m = self.model
+        dof = m.dof.data
+        hist = m.history_ops
+        _lib.check(lib.ehr_pose_forward(_lib.ptr(dof), _lib.ptr(self.K), _lib.ptr(self.link_poses), self.B, self.L,
+                                        self.H, self.W, _f(self.near), _f(self.far), _lib.ptr(self.mvp),
+                                        _lib.ptr(self.tc_jac), _lib.ptr(self.step_t), _lib.ptr(hist), hist.shape[0],
+                                        stream), "ehr_pose_forward")
+        fused._launch(self.glctx, self.scene, self.mvp, self.ref, self.mask if want_mask else None, self.loss_b,
+                      self.grad_mvp)
+        _lib.check(lib.ehr_pose_backward(_lib.ptr(self.grad_mvp), _lib.ptr(self.loss_b), _lib.ptr(self.K),
+                                         _lib.ptr(self.link_poses), _lib.ptr(self.tc_jac), self.B, self.L, self.H,
+                                         self.W, _f(self.near), _f(self.far), _lib.ptr(self.red), stream),
+                   "ehr_pose_backward")
+        if self.distributed:
+            dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.pg)  # the ONE collective of a step (32 bytes)
+        _lib.check(lib.ehr_pose_adam(_lib.ptr(dof), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                     _lib.ptr(self.step_t), _lib.ptr(self.red), _f(self.lr), _f(self.betas[0]),
+                                     _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.loss),
+                                     _lib.ptr(self.grad), stream), "ehr_pose_adam")
+
+    def step(self, want_mask=False):
+        """Enqueue one optimisation step.  Returns the (device, 1-element) mean mask loss evaluated BEFORE the update,
+        like ``loss`` in trainer/rbsolver.py:33-41.  Never synchronises."""
+        with torch.cuda.device(self.dev):
+            if self._graph is not None and not want_mask:
+                self._graph.replay()
+            else:
+                self._enqueue(want_mask)
+        return self.loss
+
+    def capture(self):
+        """Capture the step into a hipGraph (torch.cuda.CUDAGraph): replay costs one launch on the host.  Not
+        available with data parallelism through torch.distributed unless the backend supports capture."""
+        if self._graph is not None:
+            return
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._enqueue(False)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        # undo the two warm-up updates? No: they are ordinary optimisation steps (state stays consistent).
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue(False)
+        self._graph = g
+
+    @property
+    def steps_done(self):
+        return int(self.step_t.item())
+
+    def state_dict(self):
+        """torch.optim.Adam-shaped state for checkpoints (trainer/rbsolver.py:95-114)."""
+        return {"state": {0: {"step": self.step_t.float().clone(), "exp_avg": self.exp_avg.clone(),
+                              "exp_avg_sq": self.exp_avg_sq.clone()}},
+                "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd,
+                                  "params": [0]}]}

@@ -22,7 +22,7 @@ class LinkScene:
         assert len(vertices) == len(faces) and len(vertices) > 0
         self.device = torch.device(device)
         self.num_links = len(vertices)
-        vs, fs, ls = [], [], []
+        vs, fs, ls, vls = [], [], [], []
         self.vert_offsets, self.tri_offsets = [0], [0]
         for l, (v, f) in enumerate(zip(vertices, faces)):
             v = torch.as_tensor(v, dtype=torch.float32).reshape(-1, 3)
@@ -30,11 +30,13 @@ class LinkScene:
             vs.append(v)
             fs.append(f + self.vert_offsets[-1])
             ls.append(torch.full((f.shape[0],), l, dtype=torch.int32))
+            vls.append(torch.full((v.shape[0],), l, dtype=torch.int32))
             self.vert_offsets.append(self.vert_offsets[-1] + v.shape[0])
             self.tri_offsets.append(self.tri_offsets[-1] + f.shape[0])
         self.verts = torch.cat(vs).contiguous().to(self.device)
         self.tris = torch.cat(fs).contiguous().to(self.device)
         self.tri_link = torch.cat(ls).contiguous().to(self.device)
+        self.vert_link = torch.cat(vls).contiguous().to(self.device)
         self.num_verts, self.num_tris = self.verts.shape[0], self.tris.shape[0]
         # links share no vertices, so the topology of the concatenation is the per-link topology
         self.opp = dr.antialias_construct_topology_hash(self.tris).opp
@@ -45,7 +47,7 @@ class _Plan:
     """Per-context plan for one (B, L, T, H, W) shape: sizes the ctx scratch once so the hot call never allocates."""
 
     def __init__(self, glctx, B, L, V, T, H, W, slack=4.0):
-        self.key = (B, L, T, H, W)
+        self.key = (B, L, V, T, H, W)
         with torch.cuda.device(glctx.device):
             _lib.check(_lib.lib().ehr_fused_plan(glctx.handle, B, L, V, T, H, W, ctypes.c_float(slack)),
                        "ehr_fused_plan")
@@ -53,7 +55,7 @@ class _Plan:
 
 def _ensure_plan(glctx, B, L, V, T, H, W):
     plan = getattr(glctx, "_plan", None)
-    if plan is None or plan.key != (B, L, T, H, W):
+    if plan is None or plan.key != (B, L, V, T, H, W):
         glctx._plan = _Plan(glctx, B, L, V, T, H, W)
 
 
@@ -69,7 +71,8 @@ def _launch(glctx, scene, mvp, ref, mask, loss, grad_mvp):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     with torch.cuda.device(glctx.device):
         _lib.check(_lib.lib().ehr_render_mask_loss(
-            glctx.handle, _lib.ptr(scene.verts), _lib.ptr(scene.tris), _lib.ptr(scene.tri_link), _lib.ptr(scene.opp),
+            glctx.handle, _lib.ptr(scene.verts), _lib.ptr(scene.tris), _lib.ptr(scene.tri_link),
+            _lib.ptr(scene.vert_link), _lib.ptr(scene.opp),
             _lib.ptr(mvp), _lib.ptr(ref), B, L, scene.num_verts, scene.num_tris, H, W, _lib.ptr(mask), _lib.ptr(loss),
             _lib.ptr(grad_mvp), stream), "ehr_render_mask_loss")
 

@@ -42,9 +42,11 @@ def shard_views(n_views, rank, world_size):
 
 
 class RBSolverTrainer:
-    def __init__(self, cfg, model, batch, process_group=None):
+    def __init__(self, cfg, model, batch, process_group=None, fast=False, graph=False):
         """batch: dict of this rank's device tensors (mask, link_poses, K, Tc_c2b) -- the single batch the reference
-        builds with batch_size=100 >= #frames (configs/xarm7/example.yaml:45)."""
+        builds with batch_size=100 >= #frames (configs/xarm7/example.yaml:45).
+        fast: run the step as the fixed HIP launch chain of :class:`easyhec_amd.fast.FusedPoseStep` (same arithmetic,
+        no autograd / torch glue); graph: additionally replay it as a captured hipGraph."""
         self.cfg = cfg
         self.model = model
         self.batch = dict(batch)
@@ -54,6 +56,15 @@ class RBSolverTrainer:
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
         self.last_loss = None
+        self.fast = None
+        if fast:
+            from .fast import FusedPoseStep
+            if cfg.solver.do_grad_clip or cfg.solver.optimizer != "Adam":
+                raise ValueError("fast path implements the reference's default solver only (Adam, no gradient clipping)")
+            self.fast = FusedPoseStep(model, self.batch, lr=cfg.solver.max_lr, weight_decay=cfg.solver.weight_decay,
+                                      process_group=process_group)
+            if graph and not self.distributed:
+                self.fast.capture()
         if "Tc_c2b" in self.batch and "gt_dof6" not in self.batch:
             gt = self.batch["Tc_c2b"][0]
             if not torch.allclose(gt.cpu(), torch.eye(4)):  # decided once, not per step (rb_solver.py:80)
@@ -61,6 +72,11 @@ class RBSolverTrainer:
 
     # one optimisation step == one "epoch" of the reference (trainer/rbsolver.py:29-43)
     def step(self, with_outputs=False):
+        if self.fast is not None and not with_outputs:
+            loss_value = self.fast.step()[0]
+            self.global_steps += 1
+            self.last_loss = loss_value
+            return {}, loss_value
         self.optimizer.zero_grad(set_to_none=False)
         output, loss_dict = self.model(self.batch, with_outputs=with_outputs)
         loss = sum(v for v in loss_dict.values())

@@ -89,8 +89,8 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  *     loss[b]  = sum_pixels (mask[b] - ref[b])^2       -> loss [B]
  *     grad_mvp[b,l] = d loss[b] / d MVP[b,l]           -> grad_mvp [B,L,16] (may be NULL: forward only)
  * Scene = all links concatenated: verts [V,3]; tris [T,3] with GLOBAL vertex indices, sorted by link;
- * tri_link [T] int32 link of each triangle; opp [T,3] from ehr_antialias_topology on the concatenated mesh
- * (links share no vertices, so the per-link topology is preserved); vert ranges are implied by the indices.
+ * tri_link [T] / vert_link [V] int32 link of each triangle / vertex; opp [T,3] from ehr_antialias_topology on the
+ * concatenated mesh (links share no vertices, so the per-link topology is preserved).
  * ehr_fused_plan sizes the ctx scratch for (B,L,T,H,W) and must be called (it synchronises) before the first
  * ehr_render_mask_loss of that shape; ehr_render_mask_loss itself never synchronises or allocates, so it can be
  * captured in a hipGraph.  If a bin queue overflows at run time, loss[] is set to NaN (never a silently wrong
@@ -98,17 +98,37 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  * `slack`. */
 int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack);
 int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
-                         const int32_t* opp, const float* mvp, const float* ref, int B, int L, int V, int T, int H,
-                         int W, float* mask, float* loss, float* grad_mvp, void* stream);
+                         const int32_t* vert_link, const int32_t* opp, const float* mvp, const float* ref, int B,
+                         int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream);
 int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVERFLOW */
 
 /* Measurement hook (bench.py's roofline leg): when enabled, every ehr_render_mask_loss call records hipEvents
  * around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED milliseconds
- * per stage since the last read -- ms[0] memset + bin count, ms[1] queue alloc, ms[2] bin fill, ms[3] tile kernel
- * (the dominant one), ms[4] reduce -- and the number of calls covered, then resets.  Not for use under graph capture. */
+ * per stage since the last read -- ms[0] memset + vertex transform + bin count, ms[1] queue alloc, ms[2] bin fill,
+ * ms[3] tile kernels (empty-tile stream + work-list tiles: the dominant stage), ms[4] reduce -- and the number of
+ * calls covered, then resets.  Not for use under graph capture. */
 #define EHR_FUSED_STAGES 5
 int ehr_fused_timing(ehr_ctx* ctx, int enable);
 int ehr_fused_timing_read(ehr_ctx* ctx, float* ms, int* ncalls);
+
+/* The two ends of one optimisation step around the renderer (trainer/rbsolver.py:29-43), each a single tiny kernel so
+ * that a whole step is a handful of launches with no host round trip:
+ *   ehr_pose_forward : dof[6] -> Tc_c2b = se3_exp_map(dof) (utils/pytorch3d_se3.py:46-130) ->
+ *                      mvp[b,l] = proj(K) @ opencv2blender @ Tc_c2b @ link_poses[b,l]   (rb_solver.py:52,63;
+ *                      nvdiffrast_renderer.py:33-37).  tc_jac [7,16]: Tc_c2b and d Tc_c2b / d dof_i (forward mode).
+ *                      If history != NULL, row step[0] of history [history_rows,6] receives dof (rb_solver.py:50-51).
+ *   ehr_pose_backward: grad_mvp [B,L,16] (= d loss_b / d mvp[b,l]) and loss [B] -> red[8] =
+ *                      {d(sum_b loss_b)/d dof (6), sum_b loss_b, B}: the 8 floats one all-reduce(sum) exchanges.
+ *   ehr_pose_adam    : torch.optim.Adam step (L2 weight decay added to the gradient) on dof with the MEAN-loss
+ *                      gradient red[0..5] / red[7]; m, v [6] and step [1] are the optimiser state; loss_out[0] =
+ *                      red[6] / red[7]; grad_out [6] optional.  K is the 3x3 row-major intrinsics matrix. */
+int ehr_pose_forward(const float* dof, const float* K, const float* link_poses, int B, int L, int H, int W, float n,
+                     float f, float* mvp, float* tc_jac, const int32_t* step, float* history, int history_rows,
+                     void* stream);
+int ehr_pose_backward(const float* grad_mvp, const float* loss, const float* K, const float* link_poses,
+                      const float* tc_jac, int B, int L, int H, int W, float n, float f, float* red, void* stream);
+int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* red, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
 
 #ifdef __cplusplus
 }
