@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="reference-shaped torch autograd step instead of the HIP launch chain")
-    ap.add_argument("--no-graph", action="store_true", help="launch the chain eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the launch chain as a captured hipGraph (experimental)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,7 +125,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from easyhec_amd import fused
-    p = build_problem(rank, world, dev, eager=args.eager, graph=(not args.no_graph) and world == 1)
+    p = build_problem(rank, world, dev, eager=args.eager, graph=args.graph and world == 1)
     tr = p["trainer"]
 
     def barrier():
@@ -180,7 +180,7 @@ def main():
             "config": {"workload": WORKLOAD, "robot": "xarm7 link0-7 (41096 tris, 20525 verts)",
                        "resolution": [p["H"], p["W"]], "views_per_gpu": p["B"], "global_views": p["n_views"],
                        "links": p["robot"].num_links, "antialias": True, "optimizer": "Adam lr 3e-3 wd 5e-4",
-                       "step": "torch autograd" if args.eager else ("HIP launch chain" + (", hipGraph replay" if tr.fast is not None and (not args.no_graph) and world == 1 else "")),
+                       "step": "torch autograd" if args.eager else ("HIP launch chain" + (", hipGraph replay" if tr.fast is not None and args.graph and world == 1 else "")),
                        "parallelism": f"dp{world} over views, one 8-float all-reduce/step" if world > 1 else "single GPU",
                        "final_mask_loss": round(final_loss, 3)},
             "roofline": {"bound": "hbm", "kernel": "fused_tile_kernel", "achieved": round(achieved, 2),

@@ -55,37 +55,56 @@ __device__ __forceinline__ float4 transform_vertex(const float* __restrict__ M, 
     return o;
 }
 
-// Sutherland-Hodgman against the near plane (d = z + w >= 0).  Returns 0, 3 or 4 polygon vertices.
-__device__ __forceinline__ int clip_near(const float4 p[3], float4 q[4]) {
+// Sutherland-Hodgman against the near plane (d = z + w >= 0).  Returns 0, 3 or 4 polygon vertices in q0..q3
+// (registers only: no dynamically indexed array, so no scratch memory).
+struct ClipPoly {
+    float4 q0, q1, q2, q3;
+    int n;
+};
+
+__device__ __forceinline__ float4 clip_lerp(const float4& a, const float4& b, float da, float db) {
+    float t = da / (da - db);
+    float4 r;
+    r.x = a.x + t * (b.x - a.x);
+    r.y = a.y + t * (b.y - a.y);
+    r.z = a.z + t * (b.z - a.z);
+    r.w = a.w + t * (b.w - a.w);
+    return r;
+}
+
+__device__ __forceinline__ ClipPoly clip_near_poly(const float4 p[3]) {
+    ClipPoly c;
+    c.n = 0;
+    c.q0 = c.q1 = c.q2 = c.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
     float d0 = p[0].z + p[0].w, d1 = p[1].z + p[1].w, d2 = p[2].z + p[2].w;
     bool all_in = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (d0 >= 0.f) && (d1 >= 0.f) && (d2 >= 0.f);
     if (all_in) {
-        q[0] = p[0];
-        q[1] = p[1];
-        q[2] = p[2];
-        return 3;
+        c.q0 = p[0];
+        c.q1 = p[1];
+        c.q2 = p[2];
+        c.n = 3;
+        return c;
     }
-    float d[3] = {d0, d1, d2};
-    int n = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        int j = (i == 2) ? 0 : i + 1;
-        bool in_i = d[i] >= 0.f, in_j = d[j] >= 0.f;
-        if (in_i) q[n++] = p[i];
-        if (in_i != in_j) {
-            float t = d[i] / (d[i] - d[j]);
-            float4 r;
-            r.x = p[i].x + t * (p[j].x - p[i].x);
-            r.y = p[i].y + t * (p[j].y - p[i].y);
-            r.z = p[i].z + t * (p[j].z - p[i].z);
-            r.w = p[i].w + t * (p[j].w - p[i].w);
-            q[n++] = r;
-        }
+    // Sutherland-Hodgman emits, for i = 0,1,2: p_i if inside, then the crossing of edge i -> i+1 if it crosses.
+    // The six mixed cases are written out so that the polygon lives in registers.
+    const int mask = (d0 >= 0.f ? 1 : 0) | (d1 >= 0.f ? 2 : 0) | (d2 >= 0.f ? 4 : 0);
+    const float4 I0 = clip_lerp(p[0], p[1], d0, d1);
+    const float4 I1 = clip_lerp(p[1], p[2], d1, d2);
+    const float4 I2 = clip_lerp(p[2], p[0], d2, d0);
+    switch (mask) {
+        case 1: c.q0 = p[0]; c.q1 = I0; c.q2 = I2; c.n = 3; break;
+        case 2: c.q0 = I0; c.q1 = p[1]; c.q2 = I1; c.n = 3; break;
+        case 4: c.q0 = I1; c.q1 = p[2]; c.q2 = I2; c.n = 3; break;
+        case 3: c.q0 = p[0]; c.q1 = p[1]; c.q2 = I1; c.q3 = I2; c.n = 4; break;
+        case 6: c.q0 = I0; c.q1 = p[1]; c.q2 = p[2]; c.q3 = I2; c.n = 4; break;
+        case 5: c.q0 = p[0]; c.q1 = I0; c.q2 = I1; c.q3 = p[2]; c.n = 4; break;
+        case 7: c.q0 = p[0]; c.q1 = p[1]; c.q2 = p[2]; c.n = 3; break;  // all d >= 0 but some w <= 0
+        default: c.n = 0; break;
     }
-    if (n < 3) return 0;
-    for (int i = 0; i < n; i++)
-        if (!(q[i].w > 0.f)) return 0;
-    return n;
+    if (c.n < 3) c.n = 0;
+    bool ok = (c.q0.w > 0.f) && (c.q1.w > 0.f) && (c.q2.w > 0.f) && (c.n < 4 || c.q3.w > 0.f);
+    if (!ok) c.n = 0;
+    return c;
 }
 
 // Integer coverage setup of one (sub-)triangle.  Coordinates are 1/16-pixel units relative to the image centre;

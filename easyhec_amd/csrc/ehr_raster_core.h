@@ -64,18 +64,21 @@ struct BinGeom {
 // tile range touched by the triangle's pixel bounding box grown by HALO pixels
 template <int HALO>
 __device__ __forceinline__ bool tri_tile_range(const float4 p[3], int W, int H, int& tx0, int& tx1, int& ty0, int& ty1) {
-    float4 q[4];
-    int n = clip_near(p, q);
+    const ClipPoly c = clip_near_poly(p);
     int ix0 = 0x7fffffff, iy0 = 0x7fffffff, ix1 = -1, iy1 = -1;
     bool any = false;
-    for (int s = 0; s + 2 < n; s++) {
-        Coverage cv = setup_coverage(q[0], q[s + 1], q[s + 2], W, H);
-        if (!cv.valid) continue;
-        any = true;
-        ix0 = min(ix0, cv.ix0);
-        iy0 = min(iy0, cv.iy0);
-        ix1 = max(ix1, cv.ix1);
-        iy1 = max(iy1, cv.iy1);
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (s + 2 < c.n) {
+            Coverage cv = (s == 0) ? setup_coverage(c.q0, c.q1, c.q2, W, H) : setup_coverage(c.q0, c.q2, c.q3, W, H);
+            if (cv.valid) {
+                any = true;
+                ix0 = min(ix0, cv.ix0);
+                iy0 = min(iy0, cv.iy0);
+                ix1 = max(ix1, cv.ix1);
+                iy1 = max(iy1, cv.iy1);
+            }
+        }
     }
     if (!any) return false;
     tx0 = max(ix0 - HALO, 0) / EHR_TILE_W;
@@ -239,12 +242,12 @@ __device__ __forceinline__ void depth_test_write(const float4 p[3], int t, int i
 // Slow path (rare): a triangle that needs near-plane clipping or whose snapped vertices are too far from the region
 // for 32-bit edge functions.  Rasterized serially by its own lane with 64-bit edge functions.
 template <int RW, int RH>
-__device__ __noinline__ void raster_lane_slow(const float4 p[3], int t, int W, int H, int rx0, int ry0,
+__device__ __noinline__ void raster_lane_slow(float4 pa, float4 pb, float4 pc, int t, int W, int H, int rx0, int ry0,
                                               u64* __restrict__ key) {
-    float4 q[4];
-    int n = clip_near(p, q);
-    for (int s = 0; s + 2 < n; s++) {
-        Coverage cv = setup_coverage(q[0], q[s + 1], q[s + 2], W, H);
+    const float4 p[3] = {pa, pb, pc};
+    const ClipPoly c = clip_near_poly(p);
+    for (int s = 0; s + 2 < c.n; s++) {
+        Coverage cv = (s == 0) ? setup_coverage(c.q0, c.q1, c.q2, W, H) : setup_coverage(c.q0, c.q2, c.q3, W, H);
         if (!cv.valid) continue;
         cv.ix0 = max(cv.ix0, rx0);
         cv.iy0 = max(cv.iy0, ry0);
@@ -555,7 +558,7 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
             if (i < w1) {
                 int4 e = ent[i];
                 float4 p[3] = {pv[e.y], pv[e.z], pv[e.w]};
-                if (needs_slow_path<RW, RH>(p, W, H, rx0, ry0)) raster_lane_slow<RW, RH>(p, e.x, W, H, rx0, ry0, key);
+                if (needs_slow_path<RW, RH>(p, W, H, rx0, ry0)) raster_lane_slow<RW, RH>(p[0], p[1], p[2], e.x, W, H, rx0, ry0, key);
             }
         }
     }

@@ -89,8 +89,10 @@ class FusedPoseStep:
         return self.loss
 
     def capture(self):
-        """Capture the step into a hipGraph (torch.cuda.CUDAGraph): replay costs one launch on the host.  Not
-        available with data parallelism through torch.distributed unless the backend supports capture."""
+        """EXPERIMENTAL: capture the step into a hipGraph (torch.cuda.CUDAGraph) so that a replay costs one launch on
+        the host.  The chain is GPU-bound, so this buys nothing measurable today, and with several rasterizer contexts
+        alive in one process a replay has produced GPU memory faults on ROCm 7.2 (open issues) -- keep it
+        off unless the process owns a single context.  Not available with data parallelism."""
         if self._graph is not None:
             return
         s = torch.cuda.Stream(device=self.dev)
