@@ -23,8 +23,8 @@ constexpr int RW = EHR_TILE_W + 2;  // region = tile + 1-pixel halo
 constexpr int RH = EHR_TILE_H + 2;
 constexpr int RN = RW * RH;          // 340
 constexpr int CAND_PER_THREAD = (2 * RN + EHR_TILE_THREADS - 1) / EHR_TILE_THREADS;  // 3
-constexpr int MAX_ITEMS = 1024;      // blended pairs kept per tile (all links); overflow is reported, never silent
-constexpr int MAX_LINKS = 64;
+constexpr int MAX_ITEMS = 960;      // blended pairs kept per tile (all links); overflow is reported, never silent
+constexpr int MAX_LINKS = 32;
 
 struct Item {
     int packed;  // bits 0-9 q (region index of pixel0) | 10 d | 11-12 di | 13 tri1 | 14 (c1 - c0 > 0)
@@ -104,8 +104,11 @@ __global__ void __launch_bounds__(256) fused_empty_kernel(BinGeom g, const int* 
     }
 }
 
-// Heavy tiles: persistent workgroups walk the work list of non-empty tiles.
-__global__ void __launch_bounds__(EHR_TILE_THREADS)
+// Heavy tiles: persistent workgroups walk the work list of non-empty tiles.  SLOW = false is the lean instantiation
+// (no 64-bit / clipping path, <= 128 VGPRs -> 4 workgroups per CU); tiles that hold a triangle needing that path are
+// on the second work list and run through the SLOW = true instantiation.
+template <bool SLOW>
+__global__ void __launch_bounds__(EHR_TILE_THREADS, SLOW ? 1 : 4)
 fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, const int* __restrict__ counts,
                   const int* __restrict__ offsets, const int4* __restrict__ entries, int entries_cap,
                   const int* __restrict__ worklist, const int32_t* __restrict__ opp, const float* __restrict__ ref,
@@ -126,7 +129,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
     const int L = g.L, W = g.W, H = g.H;
     const int part_stride = 1 + 12 * L;
     const int myq = (ly + 1) * RW + (lx + 1);
-    const int nwork = meta[EHR_META_NWORK];
+    const int nwork = meta[SLOW ? EHR_META_NWORK_SLOW : EHR_META_NWORK];
 #ifdef EHR_PHASE_TIMING
     // profiling build only (tools/phase_profile.sh): cycles spent up to each phase marker, summed over workgroups
     long long ph_last = __builtin_readcyclecounter();
@@ -171,7 +174,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
             __syncthreads();
             // ---- coverage + z-test of the link's queued triangles
             EHR_PHASE(0);
-            raster_queue<RW, RH>(src, b, entries + off, n, W, H, rx0, ry0, key, wscratch);
+            raster_queue<RW, RH, SLOW>(src, b, entries + off, n, W, H, rx0, ry0, key, wscratch, meta);
             __syncthreads();
             EHR_PHASE(1);
             // ---- pixel pairs with different triangle ids -> dense hit list (deterministic order)
@@ -442,7 +445,7 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     size_t nkeys = (size_t)B * g.nt * L;
     if (nkeys > 0x3fffffff) return fail(EHR_ERR_INVALID, "ehr_fused_plan: too many (view, tile, link) queues");
     int rc;
-    if ((rc = ctx->counts.reserve((2 * nkeys + 8 + 32) * sizeof(int)))) return rc;
+    if ((rc = ctx->counts.reserve((2 * nkeys + (size_t)B * g.nt + EHR_META_INTS) * sizeof(int)))) return rc;
     if ((rc = ctx->offsets.reserve(nkeys * sizeof(int)))) return rc;
     // queue storage: a triangle is queued once per tile its bounding box (+1 pixel) touches
     size_t want = (size_t)((double)slack * (double)B * (double)std::max(T, 1)) + 65536;
@@ -452,7 +455,7 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         ctx->entries_cap = want;
     }
     if ((rc = ctx->tile_part.reserve((size_t)B * g.nt * (1 + 12 * (size_t)L) * sizeof(float)))) return rc;
-    if ((rc = ctx->tile_list.reserve((size_t)2 * B * g.nt * sizeof(int)))) return rc;  // tile totals | work list
+    if ((rc = ctx->tile_list.reserve((size_t)3 * B * g.nt * sizeof(int)))) return rc;  // tile totals | lean work list | slow work list
     if ((rc = ctx->posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
     int dev = 0;
     EHR_HIP(hipGetDevice(&dev));
@@ -482,7 +485,8 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
     const int nkeys = ntiles * L;
     int* counts = (int*)ctx->counts.ptr;
     int* cursors = counts + nkeys;
-    int* meta = counts + 2 * nkeys;
+    int* tile_slow = counts + 2 * nkeys;       // [ntiles]
+    int* meta = tile_slow + ntiles;            // [EHR_META_INTS]
     int* offsets = (int*)ctx->offsets.ptr;
     int4* entries = (int4*)ctx->entries.ptr;
     int* tile_total = (int*)ctx->tile_list.ptr;
@@ -514,37 +518,41 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
         EHR_HIP(hipEventRecord(ev[0], stream));
     }
     // stage 0: clear queues, transform vertices, count
-    #ifdef EHR_PHASE_TIMING
-    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 8) * sizeof(int), stream));  // phase counters accumulate
-#else
-    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 8) * sizeof(int), stream));
-#endif
+        // counts | cursors | tile_slow | meta[0..8); the profiling counters behind meta[8] accumulate across calls
+    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + ntiles + 8) * sizeof(int), stream));
     if (V > 0) {
         fused_vertex_kernel<<<dim3((V + 255) / 256, B), 256, 0, stream>>>(verts, vert_link, mvp, V, L, posc);
         EHR_LAUNCH_CHECK();
     }
     dim3 bgrid((T + 255) / 256, B);
     if (T > 0) {
-        bin_kernel<1, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
+        bin_kernel<1, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta, tile_slow);
         EHR_LAUNCH_CHECK();
     }
     if (ev) EHR_HIP(hipEventRecord(ev[1], stream));
     // stage 1: queue allocation + work list
-    bin_alloc_kernel<<<(ntiles + 255) / 256, 256, 0, stream>>>(counts, offsets, tile_total, worklist, ntiles, L, meta);
+    bin_alloc_kernel<<<(ntiles + 255) / 256, 256, 0, stream>>>(counts, offsets, tile_total, worklist, tile_slow, ntiles, L,
+                                                               meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
     // stage 2: fill
     if (T > 0) {
-        bin_kernel<1, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries, ecap, meta);
+        bin_kernel<1, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries, ecap, meta, nullptr);
         EHR_LAUNCH_CHECK();
     }
     if (ev) EHR_HIP(hipEventRecord(ev[3], stream));
     // stage 3: tiles -- streaming pass over the empty ones, persistent workgroups over the work list
     fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
     EHR_LAUNCH_CHECK();
-    const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * 3));
-    fused_tile_kernel<<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, verts, counts, offsets, entries, ecap, worklist,
-                                                             opp, ref, mask, tile_part, grad_mvp ? 1 : 0, meta);
+    const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * 4));
+    fused_tile_kernel<false><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, verts, counts, offsets, entries, ecap,
+                                                                    worklist, opp, ref, mask, tile_part,
+                                                                    grad_mvp ? 1 : 0, meta);
+    EHR_LAUNCH_CHECK();
+    // tiles holding a near-clipped or very large triangle (normally none): same kernel with the 64-bit path compiled in
+    fused_tile_kernel<true><<<std::max(1, std::min(ntiles, ctx->num_cus)), EHR_TILE_THREADS, 0, stream>>>(
+        src, g, verts, counts, offsets, entries, ecap, worklist + ntiles, opp, ref, mask, tile_part, grad_mvp ? 1 : 0,
+        meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
     // stage 4: fixed-order reduction
@@ -561,18 +569,19 @@ int ehr_fused_status(ehr_ctx* ctx) {
     EHR_HIP(hipDeviceSynchronize());
     BinGeom g = make_geom(ctx->pH, ctx->pW, ctx->pL);
     const size_t nkeys = (size_t)ctx->pB * g.nt * ctx->pL;
+    const size_t meta_off = 2 * nkeys + (size_t)ctx->pB * g.nt;
     int meta[4] = {0, 0, 0, 0};
-    EHR_HIP(hipMemcpy(meta, (int*)ctx->counts.ptr + 2 * nkeys, sizeof(meta), hipMemcpyDeviceToHost));
+    EHR_HIP(hipMemcpy(meta, (int*)ctx->counts.ptr + meta_off, sizeof(meta), hipMemcpyDeviceToHost));
 #ifdef EHR_PHASE_TIMING
     {
         unsigned long long ph[8];
-        EHR_HIP(hipMemcpy(ph, (int*)ctx->counts.ptr + 2 * nkeys + 8, sizeof(ph), hipMemcpyDeviceToHost));
+        EHR_HIP(hipMemcpy(ph, (int*)ctx->counts.ptr + meta_off + 8, sizeof(ph), hipMemcpyDeviceToHost));
         const char* names[8] = {"pre-raster", "raster", "hit-discovery", "analysis", "gather", "composite", "backward", "(raster_wave)"};
         unsigned long long tot = 0;
         for (int i = 0; i < 7; i++) tot += ph[i];
         for (int i = 0; i < 8; i++)
             fprintf(stderr, "[ehr phase] %-14s %12llu cycles  %5.1f %%\n", names[i], ph[i], tot ? 100.0 * ph[i] / tot : 0.0);
-        EHR_HIP(hipMemset((int*)ctx->counts.ptr + 2 * nkeys + 8, 0, sizeof(ph)));
+        EHR_HIP(hipMemset((int*)ctx->counts.ptr + meta_off + 8, 0, sizeof(ph)));
     }
 #endif
     if (meta[EHR_META_OVERFLOW])

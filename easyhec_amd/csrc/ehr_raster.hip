@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
     const int off = offsets[kidx];
     if (off + n > entries_cap) n = max(entries_cap - off, 0);
     __syncthreads();
-    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, wscratch);
+    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, wscratch, nullptr);
     __syncthreads();
     // shade: one thread per pixel
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
@@ -243,7 +243,7 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     g.L = 1;
     const int nkeys = B * g.nt;
     int rc;
-    if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + 8 + (ranges_host ? 2 * (size_t)B : 0)) * sizeof(int)))) return rc;
+    if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + EHR_META_INTS + (ranges_host ? 2 * (size_t)B : 0)) * sizeof(int)))) return rc;
     if ((rc = ctx->offsets.reserve((size_t)nkeys * sizeof(int)))) return rc;
     if (ctx->entries_cap == 0) {
         size_t want = std::max((size_t)1 << 20, (size_t)B * (size_t)std::max(T, 1) * 2);
@@ -257,7 +257,7 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     int2* ranges_dev = nullptr;
     int tmax = T;
     if (ranges_host) {
-        ranges_dev = (int2*)(meta + 8);
+        ranges_dev = (int2*)(meta + EHR_META_INTS);
         EHR_HIP(hipMemcpyAsync(ranges_dev, ranges_host, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
         tmax = 0;
         for (int b = 0; b < B; b++) tmax = std::max(tmax, ranges_host[2 * b + 1]);
@@ -276,10 +276,10 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 8) * sizeof(int), stream));
     dim3 bgrid((tmax + 255) / 256, B);
     if (tmax > 0) {
-        bin_kernel<0, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta);
+        bin_kernel<0, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta, nullptr);
         EHR_LAUNCH_CHECK();
     }
-    bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nullptr, nullptr, nkeys, 1, meta);
+    bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nullptr, nullptr, nullptr, nkeys, 1, meta);
     EHR_LAUNCH_CHECK();
     // size read-back (the one synchronisation of this op): grow the queue storage if this frame needs more
     EHR_HIP(hipMemcpyAsync(ctx->host_pinned, meta, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -293,7 +293,7 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     int4* entries = (int4*)ctx->entries.ptr;
     if (tmax > 0) {
         bin_kernel<0, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries,
-                                                                 (int)std::min(ctx->entries_cap, (size_t)0x7fffffff), meta);
+                                                       (int)std::min(ctx->entries_cap, (size_t)0x7fffffff), meta, nullptr);
         EHR_LAUNCH_CHECK();
     }
     dim3 tgrid(g.nt, B);

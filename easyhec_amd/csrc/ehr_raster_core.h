@@ -60,11 +60,22 @@ struct BinGeom {
 #define EHR_META_TOTAL 0     // entries allocated
 #define EHR_META_OVERFLOW 1  // sticky overflow flag
 #define EHR_META_NWORK 2     // non-empty tiles appended to the work list
+#define EHR_META_NWORK_SLOW 3  // ... of which tiles that hold a triangle needing the 64-bit / clipping path
+#define EHR_META_INTS 40     // ints reserved for the meta block (8 words + profiling counters)
+
+// A triangle is "slow" when it needs near-plane clipping or spans more than this many sub-pixels: then (and only
+// then) its region-relative coordinates may not fit the 14 bits the 32-bit edge functions assume.  Tiles that hold a
+// slow triangle are processed by the SLOW instantiation of the tile kernel; all other tiles by the lean one.
+#define EHR_FAST_EXTENT (448 * 16)
 
 // tile range touched by the triangle's pixel bounding box grown by HALO pixels
 template <int HALO>
-__device__ __forceinline__ bool tri_tile_range(const float4 p[3], int W, int H, int& tx0, int& tx1, int& ty0, int& ty1) {
+__device__ __forceinline__ bool tri_tile_range(const float4 p[3], int W, int H, int& tx0, int& tx1, int& ty0, int& ty1,
+                                               bool& slow) {
     const ClipPoly c = clip_near_poly(p);
+    const bool simple = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (p[0].z + p[0].w >= 0.f) &&
+                        (p[1].z + p[1].w >= 0.f) && (p[2].z + p[2].w >= 0.f);
+    slow = !simple;
     int ix0 = 0x7fffffff, iy0 = 0x7fffffff, ix1 = -1, iy1 = -1;
     bool any = false;
 #pragma unroll
@@ -73,6 +84,9 @@ __device__ __forceinline__ bool tri_tile_range(const float4 p[3], int W, int H, 
             Coverage cv = (s == 0) ? setup_coverage(c.q0, c.q1, c.q2, W, H) : setup_coverage(c.q0, c.q2, c.q3, W, H);
             if (cv.valid) {
                 any = true;
+                i64 ex = (i64)max(cv.X[0], max(cv.X[1], cv.X[2])) - min(cv.X[0], min(cv.X[1], cv.X[2]));
+                i64 ey = (i64)max(cv.Y[0], max(cv.Y[1], cv.Y[2])) - min(cv.Y[0], min(cv.Y[1], cv.Y[2]));
+                if (ex > EHR_FAST_EXTENT || ey > EHR_FAST_EXTENT) slow = true;
                 ix0 = min(ix0, cv.ix0);
                 iy0 = min(iy0, cv.iy0);
                 ix1 = max(ix1, cv.ix1);
@@ -100,7 +114,8 @@ __device__ __forceinline__ bool tri_tile_range(const float4 p[3], int W, int H, 
 template <int HALO, bool FILL>
 __global__ void __launch_bounds__(256) bin_kernel(ClipSource src, BinGeom g, int* __restrict__ counts,
                                                   int* __restrict__ cursors, const int* __restrict__ offsets,
-                                                  int4* __restrict__ entries, int entries_cap, int* __restrict__ meta) {
+                                                  int4* __restrict__ entries, int entries_cap, int* __restrict__ meta,
+                                                  int* __restrict__ tile_slow) {
     __shared__ int hkey[EHR_BIN_SLOTS];
     __shared__ int hcnt[EHR_BIN_SLOTS];  // count, then (FILL) the base of the reserved range
     for (int i = threadIdx.x; i < EHR_BIN_SLOTS; i += 256) {
@@ -115,10 +130,14 @@ __global__ void __launch_bounds__(256) bin_kernel(ClipSource src, BinGeom g, int
     if (t < t1 && src.indices(t, v0, v1, v2, link)) {
         const float4* pv = src.verts(b);
         float4 p[3] = {pv[v0], pv[v1], pv[v2]};
-        if (!tri_tile_range<HALO>(p, g.W, g.H, tx0, tx1, ty0, ty1)) {
+        bool slow = false;
+        if (!tri_tile_range<HALO>(p, g.W, g.H, tx0, tx1, ty0, ty1, slow)) {
             tx1 = -1;
             ty1 = -1;
         }
+        if (!FILL && slow && tile_slow)  // rare: flag every tile the triangle is queued in
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) tile_slow[b * g.nt + ty * g.ntx + tx] = 1;
     }
     const int nx = tx1 - tx0 + 1;
     const int ntile = (tx1 >= tx0 && ty1 >= ty0) ? nx * (ty1 - ty0 + 1) : 0;
@@ -188,14 +207,17 @@ __global__ void __launch_bounds__(256) bin_kernel(ClipSource src, BinGeom g, int
     }
 }
 
-// One thread per (image, tile): offsets for the tile's L queues, per-tile total, work list of non-empty tiles.
+// One thread per (image, tile): offsets for the tile's L queues, per-tile total, work lists of non-empty tiles
+// (worklist[0 .. nwork) = lean tiles, worklist[ntiles .. ntiles + nwork_slow) = tiles flagged in tile_slow).
 static __global__ void __launch_bounds__(256) bin_alloc_kernel(const int* __restrict__ counts, int* __restrict__ offsets,
                                                                int* __restrict__ tile_total, int* __restrict__ worklist,
-                                                               int ntiles, int L, int* __restrict__ meta) {
+                                                               const int* __restrict__ tile_slow, int ntiles, int L,
+                                                               int* __restrict__ meta) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int c = 0;
     if (i < ntiles)
         for (int l = 0; l < L; l++) c += counts[(size_t)i * L + l];
+    const bool is_slow = (i < ntiles) && c > 0 && tile_slow && tile_slow[i] != 0;
     const int lane = threadIdx.x & 63;
     int incl = c;
 #pragma unroll
@@ -204,14 +226,17 @@ static __global__ void __launch_bounds__(256) bin_alloc_kernel(const int* __rest
         if (lane >= o) incl += v;
     }
     const int total = __shfl(incl, 63, 64);
-    const u64 ne = __ballot(c > 0);
-    int base = 0, wbase = 0;
+    const u64 ne = __ballot(c > 0 && !is_slow);
+    const u64 ns = __ballot(is_slow);
+    int base = 0, wbase = 0, sbase = 0;
     if (lane == 63 && total > 0) {
         base = atomicAdd(&meta[EHR_META_TOTAL], total);
-        wbase = atomicAdd(&meta[EHR_META_NWORK], __popcll(ne));
+        if (ne) wbase = atomicAdd(&meta[EHR_META_NWORK], __popcll(ne));
+        if (ns) sbase = atomicAdd(&meta[EHR_META_NWORK_SLOW], __popcll(ns));
     }
     base = __shfl(base, 63, 64);
     wbase = __shfl(wbase, 63, 64);
+    sbase = __shfl(sbase, 63, 64);
     if (i < ntiles) {
         int run = base + incl - c;
         for (int l = 0; l < L; l++) {
@@ -221,7 +246,10 @@ static __global__ void __launch_bounds__(256) bin_alloc_kernel(const int* __rest
         if (tile_total) tile_total[i] = c;
         if (worklist && c > 0) {
             const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            worklist[wbase + __popcll(ne & lt)] = i;
+            if (is_slow)
+                worklist[ntiles + sbase + __popcll(ns & lt)] = i;
+            else
+                worklist[wbase + __popcll(ne & lt)] = i;
         }
     }
 }
@@ -517,10 +545,10 @@ __device__ __forceinline__ bool raster_wave(bool active, const float4 p[3], int 
 __device__ unsigned long long* ehr_dbg_cycles = nullptr;  // profiling build: cycles inside raster_wave (wave 0)
 #endif
 
-template <int RW, int RH>
+template <int RW, int RH, bool SLOW>
 __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const int4* __restrict__ ent, int n, int W,
                                              int H, int rx0, int ry0, u64* __restrict__ key,
-                                             WaveRaster* __restrict__ ws_all) {
+                                             WaveRaster* __restrict__ ws_all, int* __restrict__ meta) {
     const int nw = EHR_TILE_THREADS / 64;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int per = (n + nw - 1) / nw;
@@ -551,7 +579,11 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
 #endif
         nslow += __popcll(__ballot(slow));
     }
-    if (nslow) {  // rare: second sweep over this wave's share, slow triangles only, one per lane
+    if (!SLOW) {
+        // tiles holding slow triangles are routed to the SLOW instantiation; if one shows up here the routing
+        // predicate is broken -- report it (loss = NaN) rather than drop the triangle silently
+        if (nslow && meta && lane == 0) meta[EHR_META_OVERFLOW] = 1;
+    } else if (nslow) {  // rare: second sweep over this wave's share, slow triangles only, one per lane
 #pragma nounroll
         for (int base = w0; base < w1; base += 64) {
             const int i = base + lane;

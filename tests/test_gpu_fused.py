@@ -57,6 +57,31 @@ def test_fused_matches_oracle(env, oracle, xarm7, H, W, scale, B):
     assert (grad[:, :, 2, :] == 0).all()
 
 
+def test_fused_slow_tiles_match_oracle(env, oracle, xarm7):
+    """Camera almost inside the robot: triangles cross the near plane and span hundreds of pixels, so their tiles take
+    the 64-bit / clipping instantiation of the tile kernel.  Same bit-exact bar."""
+    fused, ctx, scene, dev = env
+    from easyhec_amd.config import XARM7_K_1280x720
+    from easyhec_amd.synthetic import camera_Tc_c2b, make_views, scaled_K
+    H, W, B = 240, 320, 2
+    K = scaled_K(XARM7_K_1280x720, 0.25, W, H, True)
+    _, lp = make_views(xarm7, B, seed=4)
+    Tc = camera_Tc_c2b(radius=0.12, lift=0.15)          # eye a few centimetres from link geometry
+    Tc2 = camera_Tc_c2b(radius=0.45, lift=0.2)
+    Kz = K.copy()
+    Kz[:2, :2] *= 12.0                                  # and a 12x zoom: triangles of several hundred pixels
+    mvp = np.concatenate([helpers.mvp_numpy(K, H, W, Tc, lp[:1]), helpers.mvp_numpy(Kz, H, W, Tc2, lp[1:])])
+    rng = np.random.default_rng(3)
+    ref = (rng.uniform(size=(B, H, W)) > 0.5).astype(np.float32)
+    verts, tris, toff, voff = helpers.scene_arrays(xarm7)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(verts, tris, toff, voff, mvp, ref)
+    assert (m_ref > 0).mean() > 0.2
+    mask, loss, grad = run(fused, ctx, scene, mvp, ref, dev)
+    assert (mask == m_ref).all()
+    assert np.abs(loss - l_ref).max() <= 1e-6 * np.abs(l_ref).max()
+    assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+
+
 def test_fused_golden_fixtures(env, xarm7):
     fused, ctx, scene, dev = env
     g = np.load(os.path.join(GOLD, "fused_xarm7_160x120.npz"))
