@@ -12,6 +12,8 @@
 // bit-reproducible.  Blended pairs are kept as compact items in LDS; once all links are composited the per-pixel
 // loss gradient is known and the same workgroup back-propagates the items to 12 numbers per link (rows x, y, w of
 // d loss / d MVP).  HBM traffic per pixel is one read of the reference mask and one write of the rendered mask.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "ehr_host.h"
@@ -23,12 +25,12 @@ constexpr int RW = EHR_TILE_W + 2;  // region = tile + 1-pixel halo
 constexpr int RH = EHR_TILE_H + 2;
 constexpr int RN = RW * RH;          // 340
 constexpr int CAND_PER_THREAD = (2 * RN + EHR_TILE_THREADS - 1) / EHR_TILE_THREADS;  // 3
-constexpr int MAX_ITEMS = 960;      // blended pairs kept per tile (all links); overflow is reported, never silent
+constexpr int MAX_ITEMS = 704;      // blended pairs kept per tile (all links); overflow is reported, never silent
 constexpr int MAX_LINKS = 32;
 
 struct Item {
     int packed;  // bits 0-9 q (region index of pixel0) | 10 d | 11-12 di | 13 tri1 | 14 (c1 - c0 > 0)
-    int tri;     // chosen triangle (global index)
+    int v1, v2;  // the two vertices of the crossing silhouette edge (global ids)
     float alpha;
 };
 
@@ -120,6 +122,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
     __shared__ WaveRaster wscratch[EHR_TILE_THREADS / 64];
     __shared__ int seg_end[MAX_LINKS];
     __shared__ int cnt_l[MAX_LINKS];
+    __shared__ int off_l[MAX_LINKS];
     __shared__ float gpix[EHR_TILE_W * EHR_TILE_H];
     __shared__ int wave_tot[4];
     __shared__ float wred[4][12];
@@ -156,7 +159,17 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
         const float4* pv = src.verts(b);
 
         __syncthreads();  // previous tile's LDS users are done
-        if (tid < L) cnt_l[tid] = counts[kidx + tid];
+        if (tid < L) {
+            cnt_l[tid] = counts[kidx + tid];
+            off_l[tid] = offsets[kidx + tid];
+        }
+        // the reference-mask pixel is only needed after all links are composited: fetch it now, use it later
+        float refv = 0.f;
+        size_t im = 0;
+        if (in_img) {
+            im = ((size_t)b * H + (H - 1 - iy)) * W + ix;
+            refv = ref[im];
+        }
         __syncthreads();
 
         float acc = 0.f;
@@ -168,7 +181,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                 if (tid == 0) seg_end[l] = nitems;
                 continue;
             }
-            const int off = offsets[kidx + l];
+            const int off = off_l[l];
             if (off + n > entries_cap) n = max(entries_cap - off, 0);
             for (int i = tid; i < RN; i += EHR_TILE_THREADS) key[i] = ~0ull;
             __syncthreads();
@@ -197,10 +210,11 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                     bool ni = nx >= 1 && nx <= EHR_TILE_W && ny >= 1 && ny <= EHR_TILE_H;
                     ok = ok && (qi || ni);  // at least one of them interior to the tile
                     if (ok) {
-                        u64 k0 = key[q], k1 = key[ny * RW + nx];
-                        unsigned t0 = (k0 == ~0ull) ? 0xffffffffu : (unsigned)k0;
-                        unsigned t1 = (k1 == ~0ull) ? 0xffffffffu : (unsigned)k1;
-                        if (t0 != t1) {
+                        // Only pairs with exactly one covered pixel can change the result: with constant colour
+                        // inside a link, a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in
+                        // gradient, so those (the vast majority of id changes) need no silhouette analysis.
+                        const bool c0 = key[q] != ~0ull, c1 = key[ny * RW + nx] != ~0ull;
+                        if (c0 != c1) {
                             myhit[j] = (unsigned)(q | (d << 15));
                             nh++;
                         }
@@ -219,7 +233,8 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                 const int h = hbase + tid;
                 Item it;
                 it.packed = 0;
-                it.tri = 0;
+                it.v1 = 0;
+                it.v2 = 0;
                 it.alpha = 0.f;
                 int keep = 0;
                 if (h < nhits) {
@@ -240,13 +255,16 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                         py += d;
                     }
                     float4 p[3], o[3];
-#pragma unroll
-                    for (int k = 0; k < 3; k++) p[k] = pv[src.tri[3 * t + k]];
+                    int vi[3], ov[3];
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
-                        int ov = opp[3 * t + k];
-                        o[k] = ((unsigned)ov < (unsigned)src.V) ? pv[ov] : p[k];
+                        vi[k] = src.tri[3 * t + k];
+                        ov[k] = opp[3 * t + k];
                     }
+#pragma unroll
+                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)src.V) ? pv[ov[k]] : p[k];
                     AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
                     if (a.found) {
                         pairA[d][q] = a.alpha;
@@ -256,7 +274,8 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                         bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
                         if (oi && a.alpha != 0.f && (tri0 >= 0) != (tri1 >= 0)) {
                             it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((tri1 >= 0 ? 1 : 0) << 14);
-                            it.tri = t;
+                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
+                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
                             it.alpha = a.alpha;
                             keep = want_grad;
                         }
@@ -298,9 +317,8 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
         // ---- composite, loss, mask write (image convention: row 0 = top)
         float e2 = 0.f, gval = 0.f;
         if (in_img) {
-            size_t im = ((size_t)b * H + (H - 1 - iy)) * W + ix;
             float m = acc > 1.f ? 1.f : acc;
-            float e = m - ref[im];
+            float e = m - refv;
             e2 = e * e;
             gval = (acc <= 1.f) ? 2.f * e : 0.f;
             if (mask) mask[im] = m;
@@ -325,8 +343,8 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
 #pragma unroll
             for (int k = 0; k < 12; k++) G[k] = 0.f;
             for (int it = seg0 + tid; it < seg1; it += EHR_TILE_THREADS) {
-                Item im = items[it];
-                int q = im.packed & 1023, d = (im.packed >> 10) & 1, di = (im.packed >> 11) & 3;
+                const Item im = items[it];
+                int q = im.packed & 1023, d = (im.packed >> 10) & 1;
                 int tri1 = (im.packed >> 13) & 1;
                 float dc = ((im.packed >> 14) & 1) ? 1.f : -1.f;
                 int nq = q + (d ? RW : 1);
@@ -335,10 +353,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                 float gi = gpix[oy * EHR_TILE_W + ox];
                 float dd = gi * dc;
                 if (gi == 0.f || dd == 0.f) continue;
-                int t = im.tri;
-                int i1 = (di < 2) ? di + 1 : 0;
-                int i2 = (i1 < 2) ? i1 + 1 : 0;
-                int v1 = src.tri[3 * t + i1], v2 = src.tri[3 * t + i2];
+                int v1 = im.v1, v2 = im.v2;
                 int qx = q % RW, qy = q / RW;
                 int px = rx0 + qx, py = ry0 + qy;
                 if (tri1) {
@@ -544,7 +559,8 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
     // stage 3: tiles -- streaming pass over the empty ones, persistent workgroups over the work list
     fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
     EHR_LAUNCH_CHECK();
-    const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * 4));
+    static const int grid_mult = getenv("EHR_TILE_GRID_MULT") ? atoi(getenv("EHR_TILE_GRID_MULT")) : 6;  // tuning knob
+    const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * std::max(1, grid_mult)));
     fused_tile_kernel<false><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, verts, counts, offsets, entries, ecap,
                                                                     worklist, opp, ref, mask, tile_part,
                                                                     grad_mvp ? 1 : 0, meta);
