@@ -34,30 +34,6 @@ struct Item {
     float alpha;
 };
 
-// Deterministic block-wide exclusive offset of `cnt` items per thread; total returned through `total`.
-// wave_tot: LDS int[4].  Contains two barriers.
-__device__ __forceinline__ int block_offset(int cnt, int* wave_tot, int& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < EHR_TILE_THREADS / 64; w++) {
-        int v = wave_tot[w];
-        if (w < wave) base += v;
-        tot += v;
-    }
-    __syncthreads();
-    total = tot;
-    return base + incl - cnt;
-}
-
 // clip-space vertices of every (view, vertex): posc[b][v] = MVP[b, vert_link[v]] * [x, y, z, 1]
 // (easyhec/utils/nvdiffrast_utils.py:14-18 for all links of a view at once)
 __global__ void __launch_bounds__(256) fused_vertex_kernel(const float* __restrict__ verts,
@@ -114,17 +90,17 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS, SLOW ? 1 : 4)
 fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, const int* __restrict__ counts,
                   const int* __restrict__ offsets, const int4* __restrict__ entries, int entries_cap,
                   const int* __restrict__ worklist, const int32_t* __restrict__ opp, const float* __restrict__ ref,
-                  float* __restrict__ mask, float* __restrict__ tile_part, int want_grad, int* __restrict__ meta) {
+                  float* __restrict__ mask, float* __restrict__ tile_part, int want_grad, int* __restrict__ meta,
+                  int dbg) {
     __shared__ u64 key[RN];
     __shared__ float pairA[2][RN];
     __shared__ unsigned short hits[2 * RN];
     __shared__ Item items[MAX_ITEMS];
-    __shared__ WaveRaster wscratch[EHR_TILE_THREADS / 64];
+    __shared__ BlockRaster wscratch;
     __shared__ int seg_end[MAX_LINKS];
     __shared__ int cnt_l[MAX_LINKS];
     __shared__ int off_l[MAX_LINKS];
     __shared__ float gpix[EHR_TILE_W * EHR_TILE_H];
-    __shared__ int wave_tot[4];
     __shared__ float wred[4][12];
 
     const int tid = threadIdx.x;
@@ -187,7 +163,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
             __syncthreads();
             // ---- coverage + z-test of the link's queued triangles
             EHR_PHASE(0);
-            raster_queue<RW, RH, SLOW>(src, b, entries + off, n, W, H, rx0, ry0, key, wscratch, meta);
+            if (!(dbg & 2)) raster_queue<RW, RH, SLOW>(src, b, entries + off, n, W, H, rx0, ry0, key, &wscratch, meta);
             __syncthreads();
             EHR_PHASE(1);
             // ---- pixel pairs with different triangle ids -> dense hit list (deterministic order)
@@ -222,7 +198,8 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                 }
             }
             int nhits;
-            int hoff = block_offset(nh, wave_tot, nhits);
+            if (dbg & 1) nh = 0;
+            int hoff = block_offset(nh, wscratch.wave_tot, nhits);
 #pragma unroll
             for (int j = 0; j < CAND_PER_THREAD; j++)
                 if (myhit[j] != 0xffffffffu) hits[hoff++] = (unsigned short)myhit[j];
@@ -282,7 +259,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                     }
                 }
                 int nfound;
-                int ioff = block_offset(keep, wave_tot, nfound);
+                int ioff = block_offset(keep, wscratch.wave_tot, nfound);
                 if (keep) {
                     int at = nitems + ioff;
                     if (at < MAX_ITEMS)
@@ -561,14 +538,15 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
     EHR_LAUNCH_CHECK();
     static const int grid_mult = getenv("EHR_TILE_GRID_MULT") ? atoi(getenv("EHR_TILE_GRID_MULT")) : 6;  // tuning knob
     const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * std::max(1, grid_mult)));
+    static const int dbg_skip = getenv("EHR_DEBUG_SKIP") ? atoi(getenv("EHR_DEBUG_SKIP")) : 0;  // profiling aid only
     fused_tile_kernel<false><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, verts, counts, offsets, entries, ecap,
                                                                     worklist, opp, ref, mask, tile_part,
-                                                                    grad_mvp ? 1 : 0, meta);
+                                                                    grad_mvp ? 1 : 0, meta, dbg_skip);
     EHR_LAUNCH_CHECK();
     // tiles holding a near-clipped or very large triangle (normally none): same kernel with the 64-bit path compiled in
     fused_tile_kernel<true><<<std::max(1, std::min(ntiles, ctx->num_cus)), EHR_TILE_THREADS, 0, stream>>>(
         src, g, verts, counts, offsets, entries, ecap, worklist + ntiles, opp, ref, mask, tile_part, grad_mvp ? 1 : 0,
-        meta);
+        meta, dbg_skip);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
     // stage 4: fixed-order reduction

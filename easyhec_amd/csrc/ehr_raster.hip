@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
                                                                       float4* __restrict__ rast,
                                                                       float4* __restrict__ rast_db) {
     __shared__ u64 key[EHR_TILE_W * EHR_TILE_H];
-    __shared__ WaveRaster wscratch[EHR_TILE_THREADS / 64];
+    __shared__ BlockRaster wscratch;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int tx = tile % g.ntx, ty = tile / g.ntx;
     const int rx0 = tx * EHR_TILE_W, ry0 = ty * EHR_TILE_H;
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
     const int off = offsets[kidx];
     if (off + n > entries_cap) n = max(entries_cap - off, 0);
     __syncthreads();
-    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, wscratch, nullptr);
+    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, &wscratch, nullptr);
     __syncthreads();
     // shade: one thread per pixel
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;

@@ -320,14 +320,39 @@ __device__ __forceinline__ bool needs_slow_path(const float4 p[3], int W, int H,
     return !fits;
 }
 
-// Per-wave LDS scratch of the balanced rasterizer.
-struct WaveRaster {
-    int pre[65];        // exclusive prefix of the jobs' clamped bounding-box areas (+ total)
-    unsigned xy[64][3]; // snapped vertices relative to the region origin, int16 x | int16 y << 16
-    unsigned box[64];   // bbox inside the region: x0 | y0 << 8 | w << 16 | h << 24
-    int tri[64];
-    float4 pf[64][3];   // clip-space vertices (depth)
-    unsigned frag[128]; // ring of covered fragments: region pixel index | job << 16
+// Deterministic block-wide exclusive offset of `cnt` items per thread; total returned through `total`.
+// wave_tot: LDS int[EHR_TILE_THREADS / 64].  Contains two barriers.
+__device__ __forceinline__ int block_offset(int cnt, int* wave_tot, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < EHR_TILE_THREADS / 64; w++) {
+        int v = wave_tot[w];
+        if (w < wave) base += v;
+        tot += v;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - cnt;
+}
+
+// LDS scratch of the balanced rasterizer (one per workgroup).
+struct BlockRaster {
+    int pre[EHR_TILE_THREADS + 1];        // exclusive prefix of the jobs' clamped bounding-box areas (+ total)
+    unsigned xy[EHR_TILE_THREADS][3];     // snapped vertices relative to the region origin, int16 x | int16 y << 16
+    unsigned box[EHR_TILE_THREADS];       // bbox inside the region: x0 | y0 << 8 | w << 16 | h << 24
+    int tri[EHR_TILE_THREADS];
+    float4 pf[EHR_TILE_THREADS][3];       // clip-space vertices (depth)
+    unsigned frag[EHR_TILE_THREADS / 64][128];  // per-wave ring of covered fragments: region pixel index | job << 16
+    int wave_tot[EHR_TILE_THREADS / 64];
 };
 
 #define EHR_WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -358,236 +383,203 @@ __device__ __forceinline__ Edge32 job_edges(const unsigned xy[3], int bx0, int b
     return ed;
 }
 
-// Depth-test `n` (<= 64) fragments from the ring, one per lane.
+// Depth-test `n` (<= 64) fragments from this wave's ring, one per lane.
 template <int RW>
-__device__ __forceinline__ void drain_fragments(WaveRaster* ws, int head, int n, int W, int H, int rx0, int ry0,
-                                                u64* __restrict__ key) {
+__device__ __forceinline__ void drain_fragments(BlockRaster* br, const unsigned* ring, int head, int n, int W, int H,
+                                                int rx0, int ry0, u64* __restrict__ key) {
     const int lane = lane_id();
     if (lane < n) {
-        unsigned f = ws->frag[(head + lane) & 127];
+        unsigned f = ring[(head + lane) & 127];
         int pix = f & 0xffffu, j = f >> 16;
-        float4 p[3] = {ws->pf[j][0], ws->pf[j][1], ws->pf[j][2]};
+        float4 p[3] = {br->pf[j][0], br->pf[j][1], br->pf[j][2]};
         int py = pix / RW, px = pix - py * RW;
-        depth_test_write(p, ws->tri[j], rx0 + px, ry0 + py, W, H, &key[pix]);
+        depth_test_write(p, br->tri[j], rx0 + px, ry0 + py, W, H, &key[pix]);
     }
 }
 
-// Rasterize up to 64 triangles (one per lane; inactive lanes pass active = false) into the LDS key buffer of the
-// RW x RH region whose lower-left pixel is (rx0, ry0).  Must be called by all 64 lanes of the wave.
-// Returns true on lanes whose triangle needs the slow path (near-plane clipping / far-away vertices); the caller
-// rasterizes those with raster_lane_slow where few registers are live.
-template <int RW, int RH>
-__device__ __forceinline__ bool raster_wave(bool active, const float4 p[3], int t, int W, int H, int rx0, int ry0,
-                                            u64* __restrict__ key, WaveRaster* __restrict__ ws) {
-    const int lane = lane_id();
-    // ---- per-lane setup
-    bool fast = false, slow = false;
-    Coverage cv;
-    cv.valid = false;
-    int area = 0;
-    unsigned pxy[3] = {0, 0, 0}, pbox = 0;
-    if (active) {
-        const bool simple = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (p[0].z + p[0].w >= 0.f) &&
-                            (p[1].z + p[1].w >= 0.f) && (p[2].z + p[2].w >= 0.f);
-        if (simple) {
-            cv = setup_coverage(p[0], p[1], p[2], W, H);
-            if (cv.valid) {
-                int bx0 = max(cv.ix0, rx0), by0 = max(cv.iy0, ry0);
-                int bx1 = min(cv.ix1, rx0 + RW - 1), by1 = min(cv.iy1, ry0 + RH - 1);
-                if (bx0 <= bx1 && by0 <= by1) {
-                    // region-relative snapped coordinates must fit 14 bits for the 32-bit edge functions
-                    const int ox = 16 * rx0 + 8 - 8 * W, oy = 16 * ry0 + 8 - 8 * H;
-                    bool fits = true;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        i64 rx = (i64)cv.X[k] - ox, ry = (i64)cv.Y[k] - oy;
-                        fits = fits && rx >= -8192 && rx <= 8192 && ry >= -8192 && ry <= 8192;
-                        pxy[k] = ((unsigned)(int)rx & 0xffffu) | ((unsigned)(int)ry << 16);
-                    }
-                    if (fits) {
-                        fast = true;
-                        int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-                        area = bw * bh;
-                        pbox = (unsigned)(bx0 - rx0) | ((unsigned)(by0 - ry0) << 8) | ((unsigned)bw << 16) |
-                               ((unsigned)bh << 24);
-                    } else {
-                        slow = true;
-                    }
-                }
-            }
-        } else {
-            slow = true;
-        }
-    }
-    // ---- stage jobs, prefix-sum the areas
-    int incl = area;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
-    const int S = __shfl(incl, 63, 64);
-    if (S == 0) return slow;  // wave-uniform
-    ws->pre[lane] = incl - area;
-    if (lane == 63) ws->pre[64] = S;
-    ws->xy[lane][0] = pxy[0];
-    ws->xy[lane][1] = pxy[1];
-    ws->xy[lane][2] = pxy[2];
-    ws->box[lane] = pbox;
-    ws->tri[lane] = t;
-    if (fast) {
-        ws->pf[lane][0] = p[0];
-        ws->pf[lane][1] = p[1];
-        ws->pf[lane][2] = p[2];
-    }
-    EHR_WAVE_LDS_FENCE();
-
-    // ---- each lane walks a contiguous run of K pixels of the concatenated bounding boxes
-    const int K = (S + 63) >> 6;
-    const int start = lane * K, end = min(start + K, S);
-    int j = 0, bw = 1, bh = 1, dx = 0, dy = 0, pix = 0;
-    Edge32 ed;
-    int er0 = 0, er1 = 0, er2 = 0;  // edge values at the start of the current row
-    ed.e[0] = ed.e[1] = ed.e[2] = -1;
-    ed.sx[0] = ed.sx[1] = ed.sx[2] = 0;
-    ed.sy[0] = ed.sy[1] = ed.sy[2] = 0;
-    if (start < end) {
-        int lo = 0, hi = 63;
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
-            int mid = (lo + hi + 1) >> 1;
-            if (ws->pre[mid] <= start)
-                lo = mid;
-            else
-                hi = mid - 1;
-        }
-        j = lo;
-        unsigned bx = ws->box[j];
-        int bx0 = bx & 255, by0 = (bx >> 8) & 255;
-        bw = (bx >> 16) & 255;
-        bh = bx >> 24;
-        unsigned xy[3] = {ws->xy[j][0], ws->xy[j][1], ws->xy[j][2]};
-        ed = job_edges(xy, bx0, by0);
-        int o = start - ws->pre[j];
-        dy = o / bw;
-        dx = o - dy * bw;
-        er0 = ed.e[0] + dy * ed.sy[0];
-        er1 = ed.e[1] + dy * ed.sy[1];
-        er2 = ed.e[2] + dy * ed.sy[2];
-        ed.e[0] = er0 + dx * ed.sx[0];
-        ed.e[1] = er1 + dx * ed.sx[1];
-        ed.e[2] = er2 + dx * ed.sx[2];
-        pix = (by0 + dy) * RW + bx0 + dx;
-    }
-    int qhead = 0, qcount = 0;
-    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma nounroll
-    for (int it = 0; it < K; it++) {
-        const bool act = start + it < end;
-        const bool inside = act && ((ed.e[0] | ed.e[1] | ed.e[2]) >= 0);
-        const u64 m = __ballot(inside);
-        if (m) {
-            if (inside) ws->frag[(qhead + qcount + __popcll(m & lt)) & 127] = (unsigned)pix | ((unsigned)j << 16);
-            qcount += __popcll(m);
-            if (qcount >= 64) {
-                EHR_WAVE_LDS_FENCE();
-                drain_fragments<RW>(ws, qhead, 64, W, H, rx0, ry0, key);
-                qhead = (qhead + 64) & 127;
-                qcount -= 64;
-            }
-        }
-        if (act && start + it + 1 < end) {
-            dx++;
-            pix++;
-            ed.e[0] += ed.sx[0];
-            ed.e[1] += ed.sx[1];
-            ed.e[2] += ed.sx[2];
-            if (dx == bw) {
-                dx = 0;
-                dy++;
-                pix += RW - bw;
-                er0 += ed.sy[0];
-                er1 += ed.sy[1];
-                er2 += ed.sy[2];
-                ed.e[0] = er0;
-                ed.e[1] = er1;
-                ed.e[2] = er2;
-                if (dy == bh) {  // next job with a non-empty box
-                    do {
-                        j++;
-                    } while (ws->pre[j + 1] == ws->pre[j]);
-                    unsigned bx = ws->box[j];
-                    int bx0 = bx & 255, by0 = (bx >> 8) & 255;
-                    bw = (bx >> 16) & 255;
-                    bh = bx >> 24;
-                    unsigned xy[3] = {ws->xy[j][0], ws->xy[j][1], ws->xy[j][2]};
-                    ed = job_edges(xy, bx0, by0);
-                    er0 = ed.e[0];
-                    er1 = ed.e[1];
-                    er2 = ed.e[2];
-                    dy = 0;
-                    pix = by0 * RW + bx0;
-                }
-            }
-        }
-    }
-    if (qcount) {
-        EHR_WAVE_LDS_FENCE();
-        drain_fragments<RW>(ws, qhead, qcount, W, H, rx0, ry0, key);
-    }
-    EHR_WAVE_LDS_FENCE();  // scratch is reused by the next call
-    return slow;
-}
-
-// Rasterize one queue (n entries at `ent`) into `key` with all waves of the workgroup; entries are split evenly
-// over the waves.  Callers put barriers around it.
-#ifdef EHR_PHASE_TIMING
-__device__ unsigned long long* ehr_dbg_cycles = nullptr;  // profiling build: cycles inside raster_wave (wave 0)
-#endif
-
+// Rasterize one queue (n entries at `ent`) into `key` with the whole workgroup.  256 triangles per round: every thread
+// sets one up (gather, snap, clamp the box to the region), a block-wide prefix sum of the box areas splits the
+// concatenated pixel sequence EVENLY over all threads (so all waves finish the walk together), each thread walks its
+// contiguous run stepping 32-bit edge functions, covered fragments are compacted per wave (ballot/popcount) into an
+// LDS ring and depth-tested 64 at a time.  Callers put barriers around it.
 template <int RW, int RH, bool SLOW>
 __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const int4* __restrict__ ent, int n, int W,
                                              int H, int rx0, int ry0, u64* __restrict__ key,
-                                             WaveRaster* __restrict__ ws_all, int* __restrict__ meta) {
-    const int nw = EHR_TILE_THREADS / 64;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per = (n + nw - 1) / nw;
-    const int w0 = wave * per, w1 = min(w0 + per, n);
-    WaveRaster* ws = ws_all + wave;
+                                             BlockRaster* __restrict__ br, int* __restrict__ meta) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* pv = src.verts(b);
-    int nslow = 0;  // wave-uniform: entries of this wave's share that need the slow path
+    unsigned* ring = br->frag[wave];
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int nslow = 0;
 #pragma nounroll
-    for (int base = w0; base < w1; base += 64) {  // wave-uniform bounds
-        const int i = base + lane;
-        const bool active = i < w1;
+    for (int base = 0; base < n; base += EHR_TILE_THREADS) {  // block-uniform
+        const int i = base + tid;
+        const bool active = i < n;
+        // ---- per-thread setup
         float4 p[3];
         int t = 0;
+        bool fast = false, slow = false;
+        int area = 0;
+        unsigned pxy[3] = {0, 0, 0}, pbox = 0;
         if (active) {
             int4 e = ent[i];
             t = e.x;
             p[0] = pv[e.y];
             p[1] = pv[e.z];
             p[2] = pv[e.w];
+            const bool simple = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (p[0].z + p[0].w >= 0.f) &&
+                                (p[1].z + p[1].w >= 0.f) && (p[2].z + p[2].w >= 0.f);
+            if (simple) {
+                Coverage cv = setup_coverage(p[0], p[1], p[2], W, H);
+                if (cv.valid) {
+                    int bx0 = max(cv.ix0, rx0), by0 = max(cv.iy0, ry0);
+                    int bx1 = min(cv.ix1, rx0 + RW - 1), by1 = min(cv.iy1, ry0 + RH - 1);
+                    if (bx0 <= bx1 && by0 <= by1) {
+                        // region-relative snapped coordinates must fit 14 bits for the 32-bit edge functions
+                        const int ox = 16 * rx0 + 8 - 8 * W, oy = 16 * ry0 + 8 - 8 * H;
+                        bool fits = true;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            i64 rx = (i64)cv.X[k] - ox, ry = (i64)cv.Y[k] - oy;
+                            fits = fits && rx >= -8192 && rx <= 8192 && ry >= -8192 && ry <= 8192;
+                            pxy[k] = ((unsigned)(int)rx & 0xffffu) | ((unsigned)(int)ry << 16);
+                        }
+                        if (fits) {
+                            fast = true;
+                            int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+                            area = bw * bh;
+                            pbox = (unsigned)(bx0 - rx0) | ((unsigned)(by0 - ry0) << 8) | ((unsigned)bw << 16) |
+                                   ((unsigned)bh << 24);
+                        } else {
+                            slow = true;
+                        }
+                    }
+                }
+            } else {
+                slow = true;
+            }
         }
-#ifdef EHR_PHASE_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long tq0 = __builtin_readcyclecounter();
-#endif
-        const bool slow = raster_wave<RW, RH>(active, p, t, W, H, rx0, ry0, key, ws);
-#ifdef EHR_PHASE_TIMING
-        if (threadIdx.x == 0 && ehr_dbg_cycles) atomicAdd(ehr_dbg_cycles, (unsigned long long)(__builtin_readcyclecounter() - tq0));
-#endif
-        nslow += __popcll(__ballot(slow));
+        nslow += slow ? 1 : 0;
+        // ---- block-wide prefix sum of the areas, stage the jobs
+        int S;
+        const int excl = block_offset(area, br->wave_tot, S);
+        if (S == 0) continue;  // block-uniform
+        br->pre[tid] = excl;
+        if (tid == EHR_TILE_THREADS - 1) br->pre[EHR_TILE_THREADS] = S;
+        br->xy[tid][0] = pxy[0];
+        br->xy[tid][1] = pxy[1];
+        br->xy[tid][2] = pxy[2];
+        br->box[tid] = pbox;
+        br->tri[tid] = t;
+        if (fast) {
+            br->pf[tid][0] = p[0];
+            br->pf[tid][1] = p[1];
+            br->pf[tid][2] = p[2];
+        }
+        __syncthreads();
+        // ---- every thread walks a contiguous run of K pixels of the concatenated bounding boxes
+        const int K = (S + EHR_TILE_THREADS - 1) / EHR_TILE_THREADS;
+        const int start = tid * K, end = min(start + K, S);
+        int j = 0, bw = 1, bh = 1, dx = 0, dy = 0, pix = 0;
+        Edge32 ed;
+        int er0 = 0, er1 = 0, er2 = 0;  // edge values at the start of the current row
+        ed.e[0] = ed.e[1] = ed.e[2] = -1;
+        ed.sx[0] = ed.sx[1] = ed.sx[2] = 0;
+        ed.sy[0] = ed.sy[1] = ed.sy[2] = 0;
+        if (start < end) {
+            int lo = 0, hi = EHR_TILE_THREADS - 1;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                int mid = (lo + hi + 1) >> 1;
+                if (br->pre[mid] <= start)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            j = lo;
+            unsigned bx = br->box[j];
+            int bx0 = bx & 255, by0 = (bx >> 8) & 255;
+            bw = (bx >> 16) & 255;
+            bh = bx >> 24;
+            unsigned xy[3] = {br->xy[j][0], br->xy[j][1], br->xy[j][2]};
+            ed = job_edges(xy, bx0, by0);
+            int o = start - br->pre[j];
+            dy = o / bw;
+            dx = o - dy * bw;
+            er0 = ed.e[0] + dy * ed.sy[0];
+            er1 = ed.e[1] + dy * ed.sy[1];
+            er2 = ed.e[2] + dy * ed.sy[2];
+            ed.e[0] = er0 + dx * ed.sx[0];
+            ed.e[1] = er1 + dx * ed.sx[1];
+            ed.e[2] = er2 + dx * ed.sx[2];
+            pix = (by0 + dy) * RW + bx0 + dx;
+        }
+        int qhead = 0, qcount = 0;
+#pragma nounroll
+        for (int it = 0; it < K; it++) {
+            const bool act = start + it < end;
+            const bool inside = act && ((ed.e[0] | ed.e[1] | ed.e[2]) >= 0);
+            const u64 m = __ballot(inside);
+            if (m) {
+                if (inside) ring[(qhead + qcount + __popcll(m & lt)) & 127] = (unsigned)pix | ((unsigned)j << 16);
+                qcount += __popcll(m);
+                if (qcount >= 64) {
+                    EHR_WAVE_LDS_FENCE();
+                    drain_fragments<RW>(br, ring, qhead, 64, W, H, rx0, ry0, key);
+                    qhead = (qhead + 64) & 127;
+                    qcount -= 64;
+                }
+            }
+            if (act && start + it + 1 < end) {
+                dx++;
+                pix++;
+                ed.e[0] += ed.sx[0];
+                ed.e[1] += ed.sx[1];
+                ed.e[2] += ed.sx[2];
+                if (dx == bw) {
+                    dx = 0;
+                    dy++;
+                    pix += RW - bw;
+                    er0 += ed.sy[0];
+                    er1 += ed.sy[1];
+                    er2 += ed.sy[2];
+                    ed.e[0] = er0;
+                    ed.e[1] = er1;
+                    ed.e[2] = er2;
+                    if (dy == bh) {  // next job with a non-empty box
+                        do {
+                            j++;
+                        } while (br->pre[j + 1] == br->pre[j]);
+                        unsigned bx = br->box[j];
+                        int bx0 = bx & 255, by0 = (bx >> 8) & 255;
+                        bw = (bx >> 16) & 255;
+                        bh = bx >> 24;
+                        unsigned xy[3] = {br->xy[j][0], br->xy[j][1], br->xy[j][2]};
+                        ed = job_edges(xy, bx0, by0);
+                        er0 = ed.e[0];
+                        er1 = ed.e[1];
+                        er2 = ed.e[2];
+                        dy = 0;
+                        pix = by0 * RW + bx0;
+                    }
+                }
+            }
+        }
+        if (qcount) {
+            EHR_WAVE_LDS_FENCE();
+            drain_fragments<RW>(br, ring, qhead, qcount, W, H, rx0, ry0, key);
+        }
+        __syncthreads();  // the job table is rewritten by the next round
     }
     if (!SLOW) {
         // tiles holding slow triangles are routed to the SLOW instantiation; if one shows up here the routing
         // predicate is broken -- report it (loss = NaN) rather than drop the triangle silently
-        if (nslow && meta && lane == 0) meta[EHR_META_OVERFLOW] = 1;
-    } else if (nslow) {  // rare: second sweep over this wave's share, slow triangles only, one per lane
+        if (nslow && meta) meta[EHR_META_OVERFLOW] = 1;
+    } else if (__syncthreads_or(nslow)) {  // rare: second sweep, slow triangles only, one per thread
 #pragma nounroll
-        for (int base = w0; base < w1; base += 64) {
-            const int i = base + lane;
-            if (i < w1) {
+        for (int base = 0; base < n; base += EHR_TILE_THREADS) {
+            const int i = base + tid;
+            if (i < n) {
                 int4 e = ent[i];
                 float4 p[3] = {pv[e.y], pv[e.z], pv[e.w]};
                 if (needs_slow_path<RW, RH>(p, W, H, rx0, ry0)) raster_lane_slow<RW, RH>(p[0], p[1], p[2], e.x, W, H, rx0, ry0, key);
