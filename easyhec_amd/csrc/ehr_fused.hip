@@ -454,6 +454,11 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     hipDeviceProp_t prop;
     EHR_HIP(hipGetDeviceProperties(&prop, dev));
     ctx->num_cus = prop.multiProcessorCount;
+    if (!ctx->side) {
+        EHR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        EHR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        EHR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
     ctx->pB = B;
     ctx->pL = L;
     ctx->pV = V;
@@ -527,6 +532,16 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
                                                                meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
+    // the empty-tile stream only needs the tile totals: fork it onto the side stream so that it runs under the queue
+    // fill and the tile kernels (it is bandwidth-bound, they are latency-bound); joined before the reduction
+    const bool overlap = !ctx->timing && ctx->side != nullptr;
+    if (overlap) {
+        EHR_HIP(hipEventRecord(ctx->ev_fork, stream));
+        EHR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        fused_empty_kernel<<<dim3(g.nty, B), 256, 0, ctx->side>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
+        EHR_LAUNCH_CHECK();
+        EHR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+    }
     // stage 2: fill
     if (T > 0) {
         bin_kernel<1, true><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, entries, ecap, meta, nullptr);
@@ -534,8 +549,10 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
     }
     if (ev) EHR_HIP(hipEventRecord(ev[3], stream));
     // stage 3: tiles -- streaming pass over the empty ones, persistent workgroups over the work list
-    fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
-    EHR_LAUNCH_CHECK();
+    if (!overlap) {
+        fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
+        EHR_LAUNCH_CHECK();
+    }
     static const int grid_mult = getenv("EHR_TILE_GRID_MULT") ? atoi(getenv("EHR_TILE_GRID_MULT")) : 6;  // tuning knob
     const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * std::max(1, grid_mult)));
     static const int dbg_skip = getenv("EHR_DEBUG_SKIP") ? atoi(getenv("EHR_DEBUG_SKIP")) : 0;  // profiling aid only
@@ -548,6 +565,7 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
         src, g, verts, counts, offsets, entries, ecap, worklist + ntiles, opp, ref, mask, tile_part, grad_mvp ? 1 : 0,
         meta, dbg_skip);
     EHR_LAUNCH_CHECK();
+    if (overlap) EHR_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
     if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
     // stage 4: fixed-order reduction
     dim3 rgrid(L + 1, B);

@@ -53,6 +53,9 @@ struct ehr_ctx {
     ehr::Scratch posc;       // float4 [B * V] clip-space vertices of the current step
     ehr::Scratch tile_part;  // float [B * NT * (1 + 12 * L)] per-tile partial loss + MVP gradients
     ehr::Scratch tile_list;  // int32 [2 * B * NT]: per-tile entry totals | work list of non-empty tiles
+    // side stream: the empty-tile streaming kernel overlaps the queue fill + tile kernels
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // measurement hook (ehr_fused_timing): EHR_FUSED_STAGES + 1 events per recorded call
     bool timing = false;
     std::vector<hipEvent_t> ev;

@@ -222,6 +222,9 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->posc.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side) (void)hipStreamDestroy(c->side);
     (void)hipSetDevice(cur);
     delete c;
     return EHR_OK;
