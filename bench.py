@@ -29,7 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-WORKLOAD = "xarm7_1280x720_8view"
+WORKLOAD = "xarm7_1280x720_8view"   # BASELINE configs[2]; --workload selects another one for side measurements
 VIEWS_PER_GPU = 8
 
 
@@ -39,7 +39,7 @@ def algorithmic_bytes_per_frame(robot, H, W):
     return 2 * G + 16 * H * W + 128 * robot.num_links
 
 
-def build_problem(rank, world, dev, eager=False, graph=True):
+def build_problem(rank, world, dev, eager=False, graph=True, workload=WORKLOAD):
     from easyhec_amd import dr, fused
     from easyhec_amd.config import Cfg
     from easyhec_amd.rb_solver import RBSolver
@@ -47,10 +47,10 @@ def build_problem(rank, world, dev, eager=False, graph=True):
     from easyhec_amd.synthetic import WORKLOADS, camera_Tc_c2b, make_views, perturb_pose
     from easyhec_amd.trainer import RBSolverTrainer, shard_views
 
-    wl = WORKLOADS[WORKLOAD]
+    wl = WORKLOADS[workload]
     robot = load_robot(wl["robot"])
     H, W, K = wl["H"], wl["W"], np.asarray(wl["K"], dtype=np.float64)
-    n_views = VIEWS_PER_GPU * world
+    n_views = (VIEWS_PER_GPU if workload == WORKLOAD else wl["views"]) * world
     _, link_poses = make_views(robot, n_views, seed=0)
     lo, hi = shard_views(n_views, rank, world)
     link_poses = link_poses[lo:hi]
@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="reference-shaped torch autograd step instead of the HIP launch chain")
+    ap.add_argument("--workload", default=WORKLOAD, help="side measurements only; the headline is the default")
     ap.add_argument("--graph", action="store_true", help="replay the launch chain as a captured hipGraph (experimental)")
     args = ap.parse_args()
 
@@ -125,7 +126,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from easyhec_amd import fused
-    p = build_problem(rank, world, dev, eager=args.eager, graph=args.graph and world == 1)
+    p = build_problem(rank, world, dev, eager=args.eager, graph=args.graph and world == 1, workload=args.workload)
     tr = p["trainer"]
 
     def barrier():
@@ -173,11 +174,11 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "mask-render fwd+bwd frames/sec, xArm7 50k-tri @1280x720x8-view",
+            "metric": "mask-render fwd+bwd frames/sec, xArm7 50k-tri @1280x720x8-view" if args.workload == WORKLOAD else f"mask-render fwd+bwd frames/sec, {args.workload}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "robot": "xarm7 link0-7 (41096 tris, 20525 verts)",
+            "config": {"workload": args.workload, "robot": f"{p['robot'].name} ({p['robot'].num_tris} tris, {p['robot'].num_verts} verts)",
                        "resolution": [p["H"], p["W"]], "views_per_gpu": p["B"], "global_views": p["n_views"],
                        "links": p["robot"].num_links, "antialias": True, "optimizer": "Adam lr 3e-3 wd 5e-4",
                        "step": "torch autograd" if args.eager else ("HIP launch chain" + (", hipGraph replay" if tr.fast is not None and args.graph and world == 1 else "")),

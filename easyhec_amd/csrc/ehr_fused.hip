@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "ehr_host.h"
+#include "ehr_pose_core.h"
 #include "ehr_raster_core.h"
 
 namespace ehr {
@@ -45,6 +46,60 @@ __global__ void __launch_bounds__(256) fused_vertex_kernel(const float* __restri
     const int l = vert_link[v];
     float4 o = make_float4(0.f, 0.f, 0.f, -1.f);  // invalid link -> behind the camera, never drawn
     if ((unsigned)l < (unsigned)L) o = transform_vertex(mvp + ((size_t)b * L + l) * 16, verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
+    posc[(size_t)b * V + v] = o;
+}
+
+// Merged first stage of a solver step: pose_forward (6 threads, one partial each) + zeroing of the queue counters +
+// vertex transform, in one launch.  grid = (ceil(V / 256), B).
+__global__ void __launch_bounds__(256)
+step_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vert_link, const float* __restrict__ dof,
+                   const float* __restrict__ K, const float* __restrict__ link_poses, int V, int L, int H, int W, float n,
+                   float f, float4* __restrict__ posc, float* __restrict__ mvp, float* __restrict__ tc_jac,
+                   const int* __restrict__ step, float* __restrict__ history, int history_rows, int* __restrict__ zero,
+                   int nzero) {
+    __shared__ float Tc[16];
+    __shared__ float M[MAX_LINKS][16];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const bool first = blockIdx.x == 0 && b == 0;
+    if (tid < 6) {
+        Dual<1> T[16];
+        se3_exp_dual<1>(dof, 1e-4f, T, tid);
+        if (tid == 0)
+            for (int i = 0; i < 16; i++) Tc[i] = T[i].v;
+        if (first) {
+            for (int i = 0; i < 16; i++) {
+                if (tid == 0) tc_jac[i] = T[i].v;
+                tc_jac[16 * (tid + 1) + i] = T[i].d[0];
+            }
+            if (tid == 0 && history && step) {
+                int row = step[0];
+                if (row >= 0 && row < history_rows)
+                    for (int k = 0; k < 6; k++) history[6 * row + k] = dof[k];
+            }
+        }
+    }
+    // clear this block's slice of the queue counters (count | cursor | slow flags | meta) for the step
+    {
+        const int nblk = gridDim.x * gridDim.y, blk = b * gridDim.x + blockIdx.x;
+        const int per = (nzero + nblk - 1) / nblk;
+        const int z0 = blk * per, z1 = min(z0 + per, nzero);
+        for (int i = z0 + tid; i < z1; i += 256) zero[i] = 0;
+    }
+    __syncthreads();
+    if (tid < L) {
+        float P[16], C[16];
+        projection(K, H, W, n, f, P);
+        mvp_from_pose(Tc, P, link_poses + ((size_t)b * L + tid) * 16, C);
+        for (int k = 0; k < 16; k++) M[tid][k] = C[k];
+        if (blockIdx.x == 0)
+            for (int k = 0; k < 16; k++) mvp[((size_t)b * L + tid) * 16 + k] = C[k];
+    }
+    __syncthreads();
+    const int v = blockIdx.x * 256 + tid;
+    if (v >= V) return;
+    const int l = vert_link[v];
+    float4 o = make_float4(0.f, 0.f, 0.f, -1.f);
+    if ((unsigned)l < (unsigned)L) o = transform_vertex(M[l], verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]);
     posc[(size_t)b * V + v] = o;
 }
 
@@ -363,10 +418,26 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
 
 // Fixed-order reduction of the per-tile partials.  grid = (L + 1, B): block (j, b) reduces link j's 12 numbers
 // (j < L) or the loss (j == L).
+struct StepTail {  // what the last reduce block needs to finish a solver step (all device pointers)
+    const float* K;
+    const float* link_poses;
+    const float* tc_jac;
+    float* red;
+    float* dof;
+    float* m;
+    float* v;
+    int* step;
+    float* loss_out;
+    float* grad_out;
+    float n, f, lr, b1, b2, eps, wd;
+    int defer_adam;
+};
+
+template <bool TAIL>
 __global__ void __launch_bounds__(256) fused_reduce_kernel(BinGeom g, const int* __restrict__ counts,
                                                            const float* __restrict__ tile_part,
                                                            float* __restrict__ loss, float* __restrict__ grad_mvp,
-                                                           const int* __restrict__ meta) {
+                                                           int* __restrict__ meta, StepTail tail) {
     __shared__ double red[256][12];
     const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, L = g.L;
     const int part_stride = 1 + 12 * L;
@@ -376,7 +447,7 @@ __global__ void __launch_bounds__(256) fused_reduce_kernel(BinGeom g, const int*
     if (j == L) {
         for (int t = tid; t < g.nt; t += 256) s[0] += (double)tile_part[(size_t)(b * g.nt + t) * part_stride];
     } else {
-        if (!grad_mvp) return;
+        if (!grad_mvp && !TAIL) return;
         for (int t = tid; t < g.nt; t += 256) {
             if (counts[(b * g.nt + t) * L + j] == 0) continue;
             const float* p = tile_part + (size_t)(b * g.nt + t) * part_stride + 1 + 12 * j;
@@ -408,6 +479,30 @@ __global__ void __launch_bounds__(256) fused_reduce_kernel(BinGeom g, const int*
         if (r == 1) v = (float)red[0][4 + c];
         if (r == 3) v = (float)red[0][8 + c];
         grad_mvp[((size_t)b * L + j) * 16 + tid] = v;
+    }
+    if (TAIL) {
+        // Merged last stage: the block that finishes last (ticket) turns grad_mvp / loss into the dof gradient and,
+        // unless the caller wants to all-reduce first, applies Adam.  Release/acquire at agent scope around the
+        // ticket: the other blocks ran on other CUs / XCDs.
+        __shared__ int is_last;
+        __shared__ double S[256][16];
+        __shared__ double lsum[256];
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must land before the ticket (G16)
+            int t = atomicAdd(&meta[EHR_META_TICKET], 1);
+            is_last = (t == (int)(gridDim.x * gridDim.y) - 1);
+            __threadfence();
+        }
+        __syncthreads();
+        if (!is_last) return;
+        pose_backward_block(grad_mvp, loss, tail.K, tail.link_poses, tail.tc_jac, gridDim.y, L, g.H, g.W, tail.n, tail.f,
+                            tail.red, S, lsum);
+        __syncthreads();
+        if (!tail.defer_adam)
+            pose_adam_block(tail.dof, tail.m, tail.v, tail.step, tail.red, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,
+                            tail.loss_out, tail.grad_out);
     }
 }
 
@@ -468,14 +563,29 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     return EHR_OK;
 }
 
-int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
-                         const int32_t* vert_link, const int32_t* opp, const float* mvp, const float* ref, int B,
-                         int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream_) {
-    if (!ctx) return fail(EHR_ERR_INVALID, "ehr_render_mask_loss: ctx is NULL");
+struct StepHead {  // inputs of the merged first stage (pose forward inside the vertex kernel)
+    const float* dof;
+    const float* K;
+    const float* link_poses;
+    float* tc_jac;
+    const int* step;
+    float* history;
+    int history_rows;
+    float n, f;
+};
+
+// The launch chain of the fused op.  head/tail == nullptr: generic form (mvp given, stops at loss / grad_mvp).
+// head/tail != nullptr: solver-step form (pose forward merged into the vertex kernel, pose backward (+ Adam) merged into
+// the reduction): 7 launches instead of 12.
+static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
+                       const int32_t* vert_link, const int32_t* opp, float* mvp, const float* ref, int B, int L, int V,
+                       int T, int H, int W, float* mask, float* loss, float* grad_mvp, const StepHead* head,
+                       const StepTail* tail, void* stream_) {
+    if (!ctx) return fail(EHR_ERR_INVALID, "fused op: ctx is NULL");
     if (!verts || !tris || !tri_link || !vert_link || !opp || !mvp || !ref || !loss)
-        return fail(EHR_ERR_INVALID, "ehr_render_mask_loss: NULL tensor");
+        return fail(EHR_ERR_INVALID, "fused op: NULL tensor");
     if (ctx->pB != B || ctx->pL != L || ctx->pV != V || ctx->pT != T || ctx->pH != H || ctx->pW != W)
-        return fail(EHR_ERR_INVALID, "ehr_render_mask_loss: shape differs from the planned one; call ehr_fused_plan first");
+        return fail(EHR_ERR_INVALID, "fused op: shape differs from the planned one; call ehr_fused_plan first");
     hipStream_t stream = (hipStream_t)stream_;
     BinGeom g = make_geom(H, W, L);
     const int ntiles = B * g.nt;
@@ -516,10 +626,18 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
     }
     // stage 0: clear queues, transform vertices, count
         // counts | cursors | tile_slow | meta[0..8); the profiling counters behind meta[8] accumulate across calls
-    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + ntiles + 8) * sizeof(int), stream));
-    if (V > 0) {
-        fused_vertex_kernel<<<dim3((V + 255) / 256, B), 256, 0, stream>>>(verts, vert_link, mvp, V, L, posc);
+    const int nzero = 2 * nkeys + ntiles + 8;
+    if (head && V > 0) {
+        step_vertex_kernel<<<dim3((V + 255) / 256, B), 256, 0, stream>>>(
+            verts, vert_link, head->dof, head->K, head->link_poses, V, L, H, W, head->n, head->f, posc, mvp, head->tc_jac,
+            head->step, head->history, head->history_rows, counts, nzero);
         EHR_LAUNCH_CHECK();
+    } else {
+        EHR_HIP(hipMemsetAsync(counts, 0, (size_t)nzero * sizeof(int), stream));
+        if (V > 0) {
+            fused_vertex_kernel<<<dim3((V + 255) / 256, B), 256, 0, stream>>>(verts, vert_link, mvp, V, L, posc);
+            EHR_LAUNCH_CHECK();
+        }
     }
     dim3 bgrid((T + 255) / 256, B);
     if (T > 0) {
@@ -569,10 +687,64 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
     if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
     // stage 4: fixed-order reduction
     dim3 rgrid(L + 1, B);
-    fused_reduce_kernel<<<rgrid, 256, 0, stream>>>(g, counts, tile_part, loss, grad_mvp, meta);
+    if (tail) {
+        fused_reduce_kernel<true><<<rgrid, 256, 0, stream>>>(g, counts, tile_part, loss, grad_mvp, meta, *tail);
+    } else {
+        StepTail none = {};
+        fused_reduce_kernel<false><<<rgrid, 256, 0, stream>>>(g, counts, tile_part, loss, grad_mvp, meta, none);
+    }
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[5], stream));
     return EHR_OK;
+}
+
+int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
+                         const int32_t* vert_link, const int32_t* opp, const float* mvp, const float* ref, int B,
+                         int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream) {
+    return fused_chain(ctx, verts, tris, tri_link, vert_link, opp, const_cast<float*>(mvp), ref, B, L, V, T, H, W, mask,
+                       loss, grad_mvp, nullptr, nullptr, stream);
+}
+
+int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
+                    const int32_t* vert_link, const int32_t* opp, const float* K, const float* link_poses,
+                    const float* ref, int B, int L, int V, int T, int H, int W, float near_, float far_, float* dof,
+                    float* adam_m, float* adam_v, int32_t* step, float* history, int history_rows, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, float* mvp, float* tc_jac, float* mask, float* loss_b,
+                    float* grad_mvp, float* red, float* loss_out, float* grad_out, int defer_adam, void* stream) {
+    if (!K || !link_poses || !dof || !adam_m || !adam_v || !step || !tc_jac || !grad_mvp || !red)
+        return fail(EHR_ERR_INVALID, "ehr_solver_step: NULL tensor");
+    if (L > MAX_LINKS) return fail(EHR_ERR_INVALID, "ehr_solver_step: more than %d links", MAX_LINKS);
+    StepHead head;
+    head.dof = dof;
+    head.K = K;
+    head.link_poses = link_poses;
+    head.tc_jac = tc_jac;
+    head.step = step;
+    head.history = history;
+    head.history_rows = history_rows;
+    head.n = near_;
+    head.f = far_;
+    StepTail tail;
+    tail.K = K;
+    tail.link_poses = link_poses;
+    tail.tc_jac = tc_jac;
+    tail.red = red;
+    tail.dof = dof;
+    tail.m = adam_m;
+    tail.v = adam_v;
+    tail.step = step;
+    tail.loss_out = loss_out;
+    tail.grad_out = grad_out;
+    tail.n = near_;
+    tail.f = far_;
+    tail.lr = lr;
+    tail.b1 = beta1;
+    tail.b2 = beta2;
+    tail.eps = eps;
+    tail.wd = weight_decay;
+    tail.defer_adam = defer_adam;
+    return fused_chain(ctx, verts, tris, tri_link, vert_link, opp, mvp, ref, B, L, V, T, H, W, mask, loss_b, grad_mvp,
+                       &head, &tail, stream);
 }
 
 int ehr_fused_status(ehr_ctx* ctx) {

@@ -1,0 +1,256 @@
+// ehr_pose_core.h -- device code shared by the stand-alone pose kernels (ehr_pose.hip) and the merged step kernels
+// (ehr_fused.hip): se3 exponential with forward-mode partials, projection, 4x4 products, the pose backward and Adam.
+// Reference formulas: /root/reference/easyhec/utils/pytorch3d_se3.py:12-41, :46-130, :218-245;
+// /root/reference/easyhec/utils/nvdiffrast_utils.py:5-11; /root/reference/easyhec/solver/build.py:12-29.
+#pragma once
+#include "ehr_device.h"
+
+namespace ehr {
+
+// ---- forward-mode scalar with N partials ----------------------------------------------------------------------
+template <int N>
+struct Dual {
+    float v;
+    float d[N];
+};
+template <int N>
+__device__ __forceinline__ Dual<N> dconst(float c) {
+    Dual<N> r;
+    r.v = c;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = 0.f;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> operator+(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] + b.d[i];
+    return r;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> operator-(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] - b.d[i];
+    return r;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> operator*(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+    return r;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> operator/(const Dual<N>& a, const Dual<N>& b) {
+    Dual<N> r;
+    float inv = 1.f / b.v;
+    r.v = a.v * inv;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> dneg(const Dual<N>& a) {
+    return dconst<N>(0.f) - a;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> dsqrt(const Dual<N>& a) {
+    Dual<N> r;
+    r.v = sqrtf(a.v);
+    float k = 0.5f / r.v;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] * k;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> dsin(const Dual<N>& a) {
+    Dual<N> r;
+    r.v = sinf(a.v);
+    float c = cosf(a.v);
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] * c;
+    return r;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> dcos(const Dual<N>& a) {
+    Dual<N> r;
+    r.v = cosf(a.v);
+    float s = -sinf(a.v);
+#pragma unroll
+    for (int i = 0; i < N; i++) r.d[i] = a.d[i] * s;
+    return r;
+}
+// torch.clamp(x, min=eps): value max(x, eps), gradient passes only where x >= eps
+template <int N>
+__device__ __forceinline__ Dual<N> dclamp_min(const Dual<N>& a, float eps) {
+    return (a.v >= eps) ? a : dconst<N>(eps);
+}
+
+typedef Dual<6> D6;
+
+// Tc (row-major 4x4, the usual [[R, t], [0, 1]]) and partials from dof = [log_translation, log_rotation].
+// N = 6: all six partials (slot i = d/d dof_i).  N = 1: only the partial w.r.t. dof[which].
+template <int N>
+__device__ void se3_exp_dual(const float* dof, float eps, Dual<N> T[16], int which = 0) {
+    Dual<N> x[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        x[i] = dconst<N>(dof[i]);
+        if (N == 6) x[i].d[i % N] = 1.f;
+        else if (i == which) x[i].d[0] = 1.f;
+    }
+    const Dual<N> u0 = x[0], u1 = x[1], u2 = x[2], w0 = x[3], w1 = x[4], w2 = x[5];
+    Dual<N> nrms = w0 * w0 + w1 * w1 + w2 * w2;
+    Dual<N> th = dsqrt(dclamp_min(nrms, eps));
+    Dual<N> one = dconst<N>(1.f), zero = dconst<N>(0.f);
+    Dual<N> inv = one / th;
+    Dual<N> fac1 = inv * dsin(th);
+    Dual<N> fac2 = inv * inv * (one - dcos(th));
+    // hat(w) and its square
+    Dual<N> K[9] = {zero, dneg(w2), w1, w2, zero, dneg(w0), dneg(w1), w0, zero};
+    Dual<N> K2[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) K2[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+    Dual<N> fv1 = (one - dcos(th)) / (th * th);
+    Dual<N> fv2 = (th - dsin(th)) / (th * th * th);
+    Dual<N> u[3] = {u0, u1, u2};
+    for (int r = 0; r < 3; r++) {
+        Dual<N> t = zero;
+        for (int c = 0; c < 3; c++) {
+            Dual<N> I = dconst<N>(r == c ? 1.f : 0.f);
+            T[4 * r + c] = fac1 * K[3 * r + c] + fac2 * K2[3 * r + c] + I;
+            Dual<N> V = I + K[3 * r + c] * fv1 + K2[3 * r + c] * fv2;
+            t = t + V * u[c];
+        }
+        T[4 * r + 3] = t;
+    }
+    T[12] = zero;
+    T[13] = zero;
+    T[14] = zero;
+    T[15] = one;
+}
+
+__device__ __forceinline__ void mat4_mul(const float* A, const float* B, float* C) {
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            float s = A[4 * r] * B[c];
+            s = fmaf(A[4 * r + 1], B[4 + c], s);
+            s = fmaf(A[4 * r + 2], B[8 + c], s);
+            s = fmaf(A[4 * r + 3], B[12 + c], s);
+            C[4 * r + c] = s;
+        }
+}
+
+__device__ __forceinline__ void projection(const float* K, int H, int W, float n, float f, float* P) {
+    float fu = K[0], fv = K[4], cu = K[2], cv = K[5];
+    for (int i = 0; i < 16; i++) P[i] = 0.f;
+    P[0] = 2.f * fu / (float)W;
+    P[2] = -2.f * cu / (float)W + 1.f;
+    P[5] = 2.f * fv / (float)H;
+    P[6] = 2.f * cv / (float)H - 1.f;
+    P[10] = -(f + n) / (f - n);
+    P[11] = -2.f * f * n / (f - n);
+    P[14] = -1.f;
+}
+
+
+// MVP[b,l] = proj @ (opencv2blender @ (Tc @ link_pose))   (rb_solver.py:63; nvdiffrast_renderer.py:35,37)
+__device__ __forceinline__ void mvp_from_pose(const float* Tc, const float* P, const float* lp, float* C) {
+    float A[16];
+    mat4_mul(Tc, lp, A);
+    for (int c = 0; c < 4; c++) {  // opencv2blender = diag(1,-1,-1,1)
+        A[4 + c] = -A[4 + c];
+        A[8 + c] = -A[8 + c];
+    }
+    mat4_mul(P, A, C);
+}
+
+// d(sum_b loss_b)/d dof, the loss sum and the frame count from d loss_b / d MVP[b,l]; one 256-thread workgroup,
+// fixed-order reductions.  S: LDS double [256][16]; lsum: LDS double [256].
+__device__ __forceinline__ void pose_backward_block(const float* __restrict__ grad_mvp, const float* __restrict__ loss,
+                                                    const float* __restrict__ K, const float* __restrict__ link_poses,
+                                                    const float* __restrict__ tc_jac, int B, int L, int H, int W,
+                                                    float n, float f, float* __restrict__ red, double (*S)[16],
+                                                    double* lsum) {
+    float P[16];
+    projection(K, H, W, n, f, P);
+    for (int r = 0; r < 4; r++) {  // PF = proj @ opencv2blender
+        P[4 * r + 1] = -P[4 * r + 1];
+        P[4 * r + 2] = -P[4 * r + 2];
+    }
+    double acc[16];
+    for (int k = 0; k < 16; k++) acc[k] = 0.0;
+    double la = 0.0;
+    for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
+        const float* G = grad_mvp + (size_t)i * 16;
+        const float* lp = link_poses + (size_t)i * 16;
+        float M[16];  // d/dTc of <G, PF @ Tc @ lp>  =  PF^T @ G @ lp^T
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                float s = 0.f;
+                for (int k = 0; k < 4; k++) s = fmaf(P[4 * k + r], G[4 * k + c], s);
+                M[4 * r + c] = s;
+            }
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                float s = 0.f;
+                for (int k = 0; k < 4; k++) s = fmaf(M[4 * r + k], lp[4 * c + k], s);
+                acc[4 * r + c] += (double)s;
+            }
+    }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) la += (double)loss[i];
+    for (int k = 0; k < 16; k++) S[threadIdx.x][k] = acc[k];
+    lsum[threadIdx.x] = la;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            for (int k = 0; k < 16; k++) S[threadIdx.x][k] += S[threadIdx.x + o][k];
+            lsum[threadIdx.x] += lsum[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) {
+        const float* J = tc_jac + 16 * (threadIdx.x + 1);
+        double g = 0.0;
+        for (int k = 0; k < 16; k++) g += S[0][k] * (double)J[k];
+        red[threadIdx.x] = (float)g;
+    }
+    if (threadIdx.x == 6) red[6] = (float)lsum[0];
+    if (threadIdx.x == 7) red[7] = (float)B;
+}
+
+// torch.optim.Adam with L2 weight decay on dof, gradient of the MEAN per-frame loss = red[0..5] / red[7].
+// Call with >= 7 threads of one workgroup; contains a barrier.
+__device__ __forceinline__ void pose_adam_block(float* __restrict__ dof, float* __restrict__ m, float* __restrict__ v,
+                                                int* __restrict__ step, const float* __restrict__ red, float lr,
+                                                float b1, float b2, float eps, float wd, float* __restrict__ loss_out,
+                                                float* __restrict__ grad_out) {
+    const int i = threadIdx.x;
+    const int t = step[0] + 1;
+    const float nfr = red[7];
+    if (i < 6) {
+        float g = red[i] / nfr;
+        if (grad_out) grad_out[i] = g;
+        float p = dof[i];
+        g = g + wd * p;
+        float mi = b1 * m[i] + (1.f - b1) * g;
+        float vi = b2 * v[i] + (1.f - b2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        float bc1 = 1.f - powf(b1, (float)t);
+        float bc2 = 1.f - powf(b2, (float)t);
+        float step_size = lr / bc1;
+        float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        dof[i] = p - step_size * (mi / denom);
+    }
+    if (i == 6 && loss_out) loss_out[0] = red[6] / nfr;
+    __syncthreads();
+    if (i == 0) step[0] = t;
+}
+
+}  // namespace ehr

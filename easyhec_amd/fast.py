@@ -58,25 +58,26 @@ class FusedPoseStep:
     def _enqueue(self, want_mask):
         lib = _lib.lib()
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        m = self.model
+        m, sc = self.model, self.scene
         dof = m.dof.data
         hist = m.history_ops
-        _lib.check(lib.ehr_pose_forward(_lib.ptr(dof), _lib.ptr(self.K), _lib.ptr(self.link_poses), self.B, self.L,
-                                        self.H, self.W, _f(self.near), _f(self.far), _lib.ptr(self.mvp),
-                                        _lib.ptr(self.tc_jac), _lib.ptr(self.step_t), _lib.ptr(hist), hist.shape[0],
-                                        stream), "ehr_pose_forward")
-        fused._launch(self.glctx, self.scene, self.mvp, self.ref, self.mask if want_mask else None, self.loss_b,
-                      self.grad_mvp)
-        _lib.check(lib.ehr_pose_backward(_lib.ptr(self.grad_mvp), _lib.ptr(self.loss_b), _lib.ptr(self.K),
-                                         _lib.ptr(self.link_poses), _lib.ptr(self.tc_jac), self.B, self.L, self.H,
-                                         self.W, _f(self.near), _f(self.far), _lib.ptr(self.red), stream),
-                   "ehr_pose_backward")
+        # one C call = 7 launches: [pose fwd + counter clear + vertex transform] -> count -> alloc -> fill ->
+        # tiles (lean, slow) -> [reduce + pose bwd (+ Adam)]
+        _lib.check(lib.ehr_solver_step(
+            self.glctx.handle, _lib.ptr(sc.verts), _lib.ptr(sc.tris), _lib.ptr(sc.tri_link), _lib.ptr(sc.vert_link),
+            _lib.ptr(sc.opp), _lib.ptr(self.K), _lib.ptr(self.link_poses), _lib.ptr(self.ref), self.B, self.L,
+            sc.num_verts, sc.num_tris, self.H, self.W, _f(self.near), _f(self.far), _lib.ptr(dof),
+            _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), _lib.ptr(self.step_t), _lib.ptr(hist), hist.shape[0],
+            _f(self.lr), _f(self.betas[0]), _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.mvp),
+            _lib.ptr(self.tc_jac), _lib.ptr(self.mask if want_mask else None), _lib.ptr(self.loss_b),
+            _lib.ptr(self.grad_mvp), _lib.ptr(self.red), _lib.ptr(self.loss), _lib.ptr(self.grad),
+            int(self.distributed), stream), "ehr_solver_step")
         if self.distributed:
             dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.pg)  # the ONE collective of a step (32 bytes)
-        _lib.check(lib.ehr_pose_adam(_lib.ptr(dof), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                     _lib.ptr(self.step_t), _lib.ptr(self.red), _f(self.lr), _f(self.betas[0]),
-                                     _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.loss),
-                                     _lib.ptr(self.grad), stream), "ehr_pose_adam")
+            _lib.check(lib.ehr_pose_adam(_lib.ptr(dof), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                         _lib.ptr(self.step_t), _lib.ptr(self.red), _f(self.lr), _f(self.betas[0]),
+                                         _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.loss),
+                                         _lib.ptr(self.grad), stream), "ehr_pose_adam")
 
     def step(self, want_mask=False):
         """Enqueue one optimisation step.  Returns the (device, 1-element) mean mask loss evaluated BEFORE the update,

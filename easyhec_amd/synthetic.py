@@ -70,7 +70,7 @@ WORKLOADS = {
     "xarm7_1280x720_8view": dict(robot="xarm7", H=720, W=1280, K=np.array(XARM7_K_1280x720), views=8, radius=1.3,
                                  lift=0.3),
     "franka_1920x1080_16view": dict(robot="franka", H=1080, W=1920, K=np.array(FRANKA_K_1920x1080), views=16,
-                                    radius=1.6, lift=0.35),
+                                    radius=2.6, lift=0.5),
     "xarm7_1280x720_64view": dict(robot="xarm7", H=720, W=1280, K=np.array(XARM7_K_1280x720), views=64, radius=1.3,
                                   lift=0.3),
 }

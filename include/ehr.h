@@ -130,6 +130,20 @@ int ehr_pose_backward(const float* grad_mvp, const float* loss, const float* K, 
 int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* red, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
 
+/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 7 launches: ehr_pose_forward is merged into
+ * the vertex-transform kernel (which also clears the queue counters) and ehr_pose_backward + ehr_pose_adam into the
+ * last-arriving block of the reduction.  Same arithmetic and outputs as calling the pieces one by one:
+ * mvp [B,L,16], tc_jac [7,16], loss_b [B], grad_mvp [B,L,16], red [8], loss_out [1], grad_out [6] are all written.
+ * defer_adam != 0 stops after `red` so that the caller can all-reduce it across ranks and then call ehr_pose_adam.
+ * Requires ehr_fused_plan for (B,L,V,T,H,W); never synchronises or allocates. */
+int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
+                    const int32_t* vert_link, const int32_t* opp, const float* K, const float* link_poses,
+                    const float* ref, int B, int L, int V, int T, int H, int W, float near_plane, float far_plane,
+                    float* dof, float* adam_m, float* adam_v, int32_t* step, float* history, int history_rows, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float* mvp, float* tc_jac, float* mask,
+                    float* loss_b, float* grad_mvp, float* red, float* loss_out, float* grad_out, int defer_adam,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

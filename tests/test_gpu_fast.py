@@ -85,3 +85,36 @@ def test_fast_step_tracks_autograd_step(xarm7):
     # Adam state is torch.optim.Adam-shaped
     sd = tf.fast.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 17
+
+
+def test_merged_step_equals_the_separate_kernels(xarm7):
+    """ehr_solver_step (7 launches) against ehr_pose_forward -> ehr_render_mask_loss -> ehr_pose_backward ->
+    ehr_pose_adam called one by one from the same state: identical bits."""
+    import ctypes
+    from easyhec_amd import _lib, fused
+    from easyhec_amd.fast import FusedPoseStep
+    cfg, make, batch = problem(xarm7, 3, 240, 320, 0.25)
+    ma, mb = make(), make()
+    fa, fb = FusedPoseStep(ma, batch), FusedPoseStep(mb, batch)
+    lib = _lib.lib()
+    f = lambda x: ctypes.c_float(float(x))
+    for it in range(4):
+        fa.step()
+        # the same step, piece by piece, on model b
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dof, hist = mb.dof.data, mb.history_ops
+        _lib.check(lib.ehr_pose_forward(_lib.ptr(dof), _lib.ptr(fb.K), _lib.ptr(fb.link_poses), fb.B, fb.L, fb.H, fb.W,
+                                        f(fb.near), f(fb.far), _lib.ptr(fb.mvp), _lib.ptr(fb.tc_jac),
+                                        _lib.ptr(fb.step_t), _lib.ptr(hist), hist.shape[0], stream), "fwd")
+        fused._launch(fb.glctx, fb.scene, fb.mvp, fb.ref, None, fb.loss_b, fb.grad_mvp)
+        _lib.check(lib.ehr_pose_backward(_lib.ptr(fb.grad_mvp), _lib.ptr(fb.loss_b), _lib.ptr(fb.K),
+                                         _lib.ptr(fb.link_poses), _lib.ptr(fb.tc_jac), fb.B, fb.L, fb.H, fb.W,
+                                         f(fb.near), f(fb.far), _lib.ptr(fb.red), stream), "bwd")
+        _lib.check(lib.ehr_pose_adam(_lib.ptr(dof), _lib.ptr(fb.exp_avg), _lib.ptr(fb.exp_avg_sq), _lib.ptr(fb.step_t),
+                                     _lib.ptr(fb.red), f(fb.lr), f(fb.betas[0]), f(fb.betas[1]), f(fb.eps), f(fb.wd),
+                                     _lib.ptr(fb.loss), _lib.ptr(fb.grad), stream), "adam")
+        torch.cuda.synchronize()
+        for name in ["mvp", "tc_jac", "loss_b", "grad_mvp", "red", "loss", "grad", "exp_avg", "exp_avg_sq", "step_t"]:
+            assert torch.equal(getattr(fa, name), getattr(fb, name)), (it, name)
+        assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(ma.history_ops[:8], mb.history_ops[:8])
+    fused.check_status(fa.glctx)

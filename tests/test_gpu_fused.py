@@ -213,3 +213,35 @@ def test_overflow_is_reported_not_silent(env):
                                     torch.zeros((1, H, W), device=dev))
     assert torch.isfinite(l2).all() and float(m2.max()) <= 1.0
     fused.check_status(ctx3)
+
+
+def test_franka_config4_full_size(oracle):
+    """BASELINE configs[3]: Franka link0-7 + hand (133 676 triangles), 1920x1080, 16 views.  Bit-exact against the
+    oracle on the first 3 views, oracle-free properties on all 16."""
+    from easyhec_amd import dr, fused
+    from easyhec_amd.robot import load_robot
+    from easyhec_amd.synthetic import WORKLOADS, camera_Tc_c2b, make_views, perturb_pose
+    dev = torch.device("cuda:0")
+    fr = load_robot("franka")
+    wl = WORKLOADS["franka_1920x1080_16view"]
+    H, W, K, B = wl["H"], wl["W"], wl["K"], wl["views"]
+    _, lp = make_views(fr, B, seed=0)
+    Tc = camera_Tc_c2b(radius=wl["radius"], lift=wl["lift"])
+    mvp = helpers.mvp_numpy(K, H, W, perturb_pose(Tc), lp)
+    ctx = dr.RasterizeCudaContext()
+    scene = fused.LinkScene([v for v, _ in fr.meshes], [f for _, f in fr.meshes], dev)
+    rng = np.random.default_rng(4)
+    ref = (rng.uniform(size=(B, H, W)) > 0.97).astype(np.float32)
+    mask, loss, grad = run(fused, ctx, scene, mvp, ref, dev)
+    verts, tris, toff, voff = helpers.scene_arrays(fr)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(verts, tris, toff, voff, mvp[:3], ref[:3])
+    assert (mask[:3] == m_ref).all()
+    assert np.abs(loss[:3] - l_ref).max() <= 1e-6 * np.abs(l_ref).max()
+    assert np.abs(grad[:3] - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+    assert mask.min() >= 0 and mask.max() <= 1 and np.isfinite(grad).all()
+    for b in range(B):   # every view fully in frame, as the config asks
+        ys, xs = np.nonzero(mask[b] > 0)
+        assert 0 < xs.min() and xs.max() < W - 1 and 0 < ys.min() and ys.max() < H - 1
+    assert np.allclose(loss, ((mask.astype(np.float64) - ref) ** 2).sum(axis=(1, 2)), rtol=1e-6)
+    again = run(fused, ctx, scene, mvp, ref, dev)
+    assert (again[0] == mask).all() and (again[1] == loss).all() and (again[2] == grad).all()
