@@ -444,15 +444,35 @@ __global__ void __launch_bounds__(256) fused_reduce_kernel(BinGeom g, const int*
     double s[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) s[k] = 0.0;
-    if (j == L) {
-        for (int t = tid; t < g.nt; t += 256) s[0] += (double)tile_part[(size_t)(b * g.nt + t) * part_stride];
-    } else {
-        if (!grad_mvp && !TAIL) return;
-        for (int t = tid; t < g.nt; t += 256) {
-            if (counts[(b * g.nt + t) * L + j] == 0) continue;
-            const float* p = tile_part + (size_t)(b * g.nt + t) * part_stride + 1 + 12 * j;
+    // two independent batches of loads per thread (counts, then partials) instead of a dependent chain per tile
+    constexpr int MAXT = 16;  // tiles per thread per batch
+    for (int t0 = 0; t0 < g.nt; t0 += 256 * MAXT) {
+        if (j == L) {
+            float v[MAXT];
 #pragma unroll
-            for (int k = 0; k < 12; k++) s[k] += (double)p[k];
+            for (int i = 0; i < MAXT; i++) {
+                int t = t0 + tid + 256 * i;
+                v[i] = (t < g.nt) ? tile_part[(size_t)(b * g.nt + t) * part_stride] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < MAXT; i++) s[0] += (double)v[i];
+        } else {
+            if (!grad_mvp && !TAIL) return;
+            unsigned act = 0;
+#pragma unroll
+            for (int i = 0; i < MAXT; i++) {
+                int t = t0 + tid + 256 * i;
+                if (t < g.nt && counts[(b * g.nt + t) * L + j] != 0) act |= 1u << i;
+            }
+#pragma unroll
+            for (int i = 0; i < MAXT; i++) {
+                if (act & (1u << i)) {
+                    int t = t0 + tid + 256 * i;
+                    const float* p = tile_part + (size_t)(b * g.nt + t) * part_stride + 1 + 12 * j;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) s[k] += (double)p[k];
+                }
+            }
         }
     }
 #pragma unroll
@@ -679,7 +699,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
                                                                     grad_mvp ? 1 : 0, meta, dbg_skip);
     EHR_LAUNCH_CHECK();
     // tiles holding a near-clipped or very large triangle (normally none): same kernel with the 64-bit path compiled in
-    fused_tile_kernel<true><<<std::max(1, std::min(ntiles, ctx->num_cus)), EHR_TILE_THREADS, 0, stream>>>(
+    fused_tile_kernel<true><<<std::max(1, std::min(ntiles, ctx->num_cus / 8)), EHR_TILE_THREADS, 0, stream>>>(
         src, g, verts, counts, offsets, entries, ecap, worklist + ntiles, opp, ref, mask, tile_part, grad_mvp ? 1 : 0,
         meta, dbg_skip);
     EHR_LAUNCH_CHECK();
