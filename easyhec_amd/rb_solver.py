@@ -65,6 +65,21 @@ class RBSolver(nn.Module):
     def Tc_c2b(self):
         return se3_exp_map(self.dof[None]).permute(0, 2, 1)[0]
 
+    def _forward_three_ops(self, renderer, Tc_c2b, link_poses, K, masks_ref):
+        """The reference's own schedule (rb_solver.py:60-72): one rasterize / interpolate / antialias round trip per
+        (frame, link) through the drop-in ops, links summed and clamped, SSE per frame, mean over frames."""
+        per_frame_loss, per_frame_mask = [], []
+        for frame in range(masks_ref.shape[0]):
+            silhouettes = [
+                renderer.render_mask(getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}"), K=K,
+                                     object_pose=Tc_c2b @ link_poses[frame, k])
+                for k in range(self.nlinks)
+            ]
+            composite = torch.stack(silhouettes).sum(0).clamp(max=1)
+            per_frame_mask.append(composite)
+            per_frame_loss.append(((composite - masks_ref[frame].float()) ** 2).sum())
+        return torch.stack(per_frame_mask), torch.stack(per_frame_loss).mean()
+
     # -- forward -------------------------------------------------------------------------------------------------
     def forward(self, dps, with_outputs=True):
         assert dps.get("global_step", 0) == 0
@@ -86,19 +101,8 @@ class RBSolver(nn.Module):
             loss = losses.mean()
             all_frame_all_link_si = rendered if with_outputs else None
         else:
-            losses, all_frame_all_link_si = [], []
-            for bid in range(batch_size):
-                all_link_si = []
-                for link_idx in range(self.nlinks):
-                    Tc_c2l = Tc_c2b @ link_poses[bid, link_idx]
-                    verts, faces = getattr(self, f"vertices_{link_idx}"), getattr(self, f"faces_{link_idx}")
-                    si = renderer.render_mask(verts, faces, K=K, object_pose=Tc_c2l)
-                    all_link_si.append(si)
-                all_link_si = torch.stack(all_link_si).sum(0).clamp(max=1)
-                all_frame_all_link_si.append(all_link_si)
-                losses.append(torch.sum((all_link_si - masks_ref[bid].float()) ** 2))
-            loss = torch.stack(losses).mean()
-            all_frame_all_link_si = torch.stack(all_frame_all_link_si)
+            rendered, loss = self._forward_three_ops(renderer, Tc_c2b, link_poses, K, masks_ref)
+            all_frame_all_link_si = rendered
 
         output = {}
         if with_outputs:

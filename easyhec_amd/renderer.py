@@ -34,13 +34,9 @@ class NVDiffrastRenderer:
         return ent[2]
 
     def render_mask(self, verts, faces, K, object_pose, anti_aliasing=True):
-        """
-        @param verts: N,3, torch.tensor, float, cuda
-        @param faces: M,3, torch.tensor, int32, cuda
-        @param K: 3,3 torch.tensor, float ,cuda
-        @param object_pose: 4,4 torch.tensor, float, cuda
-        @return: mask: 0 to 1, HxW torch.cuda.FloatTensor
-        """
+        """Silhouette of one mesh.  verts [N,3] float32 and faces [M,3] int32 on the HIP device, K [3,3] pinhole
+        intrinsics, object_pose [4,4] camera<-object (OpenCV axes).  Returns the [H,W] float mask in [0,1] (row 0 = top),
+        differentiable w.r.t. object_pose; with ``anti_aliasing=False`` a bool mask (``rast z/w > 0``)."""
         proj = K_to_projection(K, self.H, self.W).to(verts.device)
         pose = self.opencv2blender @ object_pose
         pos_clip = transform_pos(proj @ pose, verts)
