@@ -11,7 +11,7 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-__all__ = ["load_stl", "load_ply", "load_dae", "load_mesh", "merge_vertices"]
+__all__ = ["load_stl", "load_ply", "load_dae", "load_mesh", "merge_vertices", "merge_corners"]
 
 _MERGE_DIGITS = 8  # trimesh tol.merge = 1e-8
 
@@ -39,6 +39,26 @@ def merge_vertices(vertices, faces, digits=_MERGE_DIGITS):
         new_faces = remap[new_faces]
         new_vertices = new_vertices[used]
     return new_vertices, new_faces.astype(np.int32)
+
+
+def merge_corners(positions, normals=None, digits=_MERGE_DIGITS, digits_norm=2):
+    """trimesh's ``merge_vertices`` for a triangle soup that carries per-corner normals: corners collapse only when
+    position (1e-8) AND normal (1e-2) agree (``merge_norm=False``, ``digits_norm=2`` are trimesh's defaults).  A mesh
+    exported with flat per-face normals therefore stays (almost) a vertex soup -- which is what the reference renders
+    for the Franka Collada meshes, and what makes ``dr.antialias`` treat nearly every edge as a silhouette edge.
+    Returns (vertices [V,3] float64, faces [T,3] int32), first-occurrence order."""
+    positions = np.asarray(positions, dtype=np.float64).reshape(-1, 3)
+    cols = [np.round(positions * (10.0 ** digits))]
+    if normals is not None:
+        cols.append(np.round(np.asarray(normals, dtype=np.float64).reshape(-1, 3) * (10.0 ** digits_norm)))
+    key = np.column_stack(cols).astype(np.int64)
+    _, first, inverse = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inverse = inverse.reshape(-1)
+    order = np.argsort(first, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    faces = rank[inverse].reshape(-1, 3)
+    return positions[first[order]], faces.astype(np.int32)
 
 
 def load_stl(path, merge=True):
@@ -142,9 +162,10 @@ def _dae_floats(text):
 
 
 def load_dae(path, merge=True):
-    """Collada -> one merged triangle mesh with the scene-graph node transforms applied (as trimesh's
-    ``force='mesh'`` does; e.g. franka link1.dae carries a <matrix> translation).  Unit scaling (<unit meter=..>)
-    is NOT applied, like trimesh."""
+    """Collada -> one triangle mesh with the scene-graph node transforms applied (as trimesh's ``force='mesh'`` does;
+    e.g. franka link1.dae carries a <matrix> translation).  Vertices are merged per primitive the way trimesh does
+    when normals are present: position AND normal must agree (:func:`merge_corners`).  Unit scaling
+    (<unit meter=..>) is NOT applied, like trimesh."""
     root = ET.parse(path).getroot()
     ns = root.tag[:root.tag.index("}") + 1] if root.tag.startswith("{") else ""
 
@@ -175,38 +196,42 @@ def load_dae(path, merge=True):
                 mesh.findall(q("polygons"))):
             inputs = prim.findall(q("input"))
             nin = max(int(i.get("offset", "0")) for i in inputs) + 1
-            voff, vsrc = 0, None
+            voff, vsrc, noff, nsrc = 0, None, 0, None
             for i in inputs:
                 if i.get("semantic") == "VERTEX":
                     voff = int(i.get("offset", "0"))
                     vsrc = vmap[i.get("source").lstrip("#")]
+                elif i.get("semantic") == "NORMAL":
+                    noff = int(i.get("offset", "0"))
+                    nsrc = i.get("source").lstrip("#")
             if vsrc is None:
                 continue
             pos = sources[vsrc][:, :3]
             if prim.tag == q("polygons"):
-                polys = [np.array(p.text.split(), dtype=np.int64).reshape(-1, nin)[:, voff] for p in
-                         prim.findall(q("p"))]
+                rows = [np.array(p.text.split(), dtype=np.int64).reshape(-1, nin) for p in prim.findall(q("p"))]
             else:
                 p = prim.find(q("p"))
                 if p is None or p.text is None:
                     continue
-                idx = np.array(p.text.split(), dtype=np.int64).reshape(-1, nin)[:, voff]
+                allidx = np.array(p.text.split(), dtype=np.int64).reshape(-1, nin)
                 if prim.tag == q("triangles"):
-                    polys = None
-                    tri = idx.reshape(-1, 3)
+                    rows = None
+                    corners = allidx
                 else:
                     vc = np.array(prim.find(q("vcount")).text.split(), dtype=np.int64)
-                    polys, o = [], 0
+                    rows, o = [], 0
                     for c in vc:
-                        polys.append(idx[o:o + c])
+                        rows.append(allidx[o:o + c])
                         o += c
             if prim.tag != q("triangles"):
                 tl = []
-                for pl in polys:
+                for pl in rows:
                     for k in range(1, len(pl) - 1):
-                        tl.append([pl[0], pl[k], pl[k + 1]])
-                tri = np.array(tl, dtype=np.int64).reshape(-1, 3)
-            parts.append((pos, tri))
+                        tl += [pl[0], pl[k], pl[k + 1]]
+                corners = np.array(tl, dtype=np.int64).reshape(-1, nin)
+            cpos = pos[corners[:, voff]]
+            cnrm = sources[nsrc][:, :3][corners[:, noff]] if (nsrc is not None and nsrc in sources) else None
+            parts.append((cpos, cnrm))
         geoms[gid] = parts
 
     def node_matrix(node):
@@ -232,11 +257,16 @@ def load_dae(path, merge=True):
         nonlocal nv
         m = parent @ node_matrix(node)
         for ig in node.findall(q("instance_geometry")):
-            for pos, tri in geoms.get(ig.get("url").lstrip("#"), []):
-                pw = pos @ m[:3, :3].T + m[:3, 3]
-                all_v.append(pw)
-                all_f.append(tri + nv)
-                nv += pw.shape[0]
+            for cpos, cnrm in geoms.get(ig.get("url").lstrip("#"), []):
+                # trimesh processes (merges) every primitive when it is loaded, in local coordinates, then applies the
+                # scene-graph transform and concatenates without merging across primitives
+                if merge:
+                    pv, pf = merge_corners(cpos, cnrm)
+                else:
+                    pv, pf = cpos, np.arange(cpos.shape[0], dtype=np.int32).reshape(-1, 3)
+                all_v.append(pv @ m[:3, :3].T + m[:3, 3])
+                all_f.append(pf.astype(np.int64) + nv)
+                nv += pv.shape[0]
         for ch in node.findall(q("node")):
             walk(ch, m)
 
@@ -247,12 +277,13 @@ def load_dae(path, merge=True):
                 walk(node, np.eye(4))
     if not all_v:  # no scene graph: take every geometry untransformed
         for parts in geoms.values():
-            for pos, tri in parts:
-                all_v.append(pos); all_f.append(tri + nv); nv += pos.shape[0]
+            for cpos, cnrm in parts:
+                pv, pf = merge_corners(cpos, cnrm) if merge else (cpos, np.arange(cpos.shape[0]).reshape(-1, 3))
+                all_v.append(pv)
+                all_f.append(np.asarray(pf, dtype=np.int64) + nv)
+                nv += pv.shape[0]
     verts = np.concatenate(all_v, axis=0)
     faces = np.concatenate(all_f, axis=0)
-    if merge:
-        return merge_vertices(verts, faces)
     return verts, faces.astype(np.int32)
 
 

@@ -6,7 +6,7 @@ import struct
 import numpy as np
 
 from easyhec_amd.kinematics import UrdfChain, rpy_to_matrix
-from easyhec_amd.mesh_io import load_dae, load_ply, load_stl, merge_vertices
+from easyhec_amd.mesh_io import load_dae, load_ply, load_stl, merge_corners, merge_vertices
 from easyhec_amd.robot import load_robot
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -94,3 +94,31 @@ def test_urdf_chain_spec_round_trip(xarm7):
     ch2 = UrdfChain(spec=xarm7.chain.spec())
     q = np.linspace(-0.5, 0.5, 7)
     assert np.abs(ch2.link_poses(q, xarm7.use_links) - xarm7.link_poses(q)).max() == 0
+
+
+def test_merge_corners_respects_normals_like_trimesh():
+    """Two triangles sharing an edge: merged by position when their corner normals agree to 1e-2, kept apart when the
+    faces carry different (flat) normals -- trimesh.merge_vertices(merge_norm=False, digits_norm=2)."""
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], float)
+    up = np.tile([0, 0, 1.0], (6, 1))
+    v, f = merge_corners(pos, up)
+    assert v.shape[0] == 4 and f.tolist() == [[0, 1, 2], [1, 3, 2]]
+    tilted = up.copy()
+    tilted[3:] = [0, 0.1, 0.995]
+    v2, f2 = merge_corners(pos, tilted)
+    assert v2.shape[0] == 6 and f2.tolist() == [[0, 1, 2], [3, 4, 5]]
+    almost = up.copy()
+    almost[3:] = [0, 0.001, 1.0]                      # rounds to the same 1e-2 cell
+    assert merge_corners(pos, almost)[0].shape[0] == 4
+    assert merge_corners(pos, None)[0].shape[0] == 4  # no normals: position only (the STL case)
+
+
+def test_franka_collada_meshes_stay_nearly_unmerged():
+    """The Franka visual meshes carry flat per-face normals, so the reference (trimesh) renders them almost as a
+    vertex soup: ~2.8 corners per triangle survive the merge.  This is what makes dr.antialias see nearly every edge
+    as a silhouette edge and gives the dense gradients the reference's Franka example converges with."""
+    fr = load_robot("franka")
+    assert fr.num_tris == 133676
+    assert 2.5 * fr.num_tris < fr.num_verts <= 3 * fr.num_tris
+    xa = load_robot("xarm7")
+    assert xa.num_verts < 0.6 * xa.num_tris            # STL: merged by position

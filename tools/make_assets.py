@@ -57,6 +57,27 @@ def main():
     np.savez_compressed(os.path.join(gdir, "xarm7_zeropos.npz"), vertices=pv.astype(np.float32),
                         faces=pf.astype(np.int32), corner_3d=meta["corner_3d"], K=meta["K"])
     print("zeropos", pv.shape, pf.shape)
+    # the reference's only real image dataset (assets/franka_offline_example.zip): masks + qpos + K as arrays
+    import io
+    import zipfile
+    from PIL import Image
+    z = zipfile.ZipFile(os.path.join(REF, "franka_offline_example.zip"))
+    masks, qpos = [], []
+    for i in range(10):
+        with Image.open(io.BytesIO(z.read(f"offline_example/mask/{i:06d}.png"))) as im:
+            a = np.asarray(im)
+        masks.append((a.max(axis=2) if a.ndim == 3 else a) > 0)
+        qpos.append(np.loadtxt(io.BytesIO(z.read(f"offline_example/qpos/{i:06d}.txt"))))
+    K = np.loadtxt(io.BytesIO(z.read("offline_example/K.txt")))
+    masks = np.stack(masks)
+    # init pose of configs/franka/example_franka_offline.yaml:5-8
+    init = np.array([[9.3969262e-01, 3.4202009e-01, 6.4914198e-09, -6.4085639e-01],
+                     [1.7101002e-01, -4.6984622e-01, -8.6602539e-01, 4.9582830e-01],
+                     [-2.9619810e-01, 8.1379771e-01, -4.9999991e-01, 1.2412001e+00],
+                     [0, 0, 0, 1]])
+    np.savez_compressed(os.path.join(gdir, "franka_offline_example.npz"), masks=np.packbits(masks), shape=masks.shape,
+                        qpos=np.stack(qpos), K=K, init_Tc_c2b=init)
+    print("franka offline example", masks.shape, "foreground", masks.mean(axis=(1, 2)).round(3))
 
 
 if __name__ == "__main__":
