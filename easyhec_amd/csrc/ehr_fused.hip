@@ -167,7 +167,6 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
 #ifdef EHR_PHASE_TIMING
     // profiling build only (tools/phase_profile.sh): cycles spent up to each phase marker, summed over workgroups
     long long ph_last = __builtin_readcyclecounter();
-    if (tid == 0) ehr_dbg_cycles = (unsigned long long*)(meta + 8) + 7;
 #define EHR_PHASE(i)                                                                   \
     do {                                                                               \
         long long now_ = __builtin_readcyclecounter();                                 \
@@ -780,10 +779,10 @@ int ehr_fused_status(ehr_ctx* ctx) {
     {
         unsigned long long ph[8];
         EHR_HIP(hipMemcpy(ph, (int*)ctx->counts.ptr + meta_off + 8, sizeof(ph), hipMemcpyDeviceToHost));
-        const char* names[8] = {"pre-raster", "raster", "hit-discovery", "analysis", "gather", "composite", "backward", "(raster_wave)"};
+        const char* names[8] = {"pre-raster", "raster", "hit-discovery", "analysis", "gather", "composite", "backward", ""};
         unsigned long long tot = 0;
         for (int i = 0; i < 7; i++) tot += ph[i];
-        for (int i = 0; i < 8; i++)
+        for (int i = 0; i < 7; i++)
             fprintf(stderr, "[ehr phase] %-14s %12llu cycles  %5.1f %%\n", names[i], ph[i], tot ? 100.0 * ph[i] / tot : 0.0);
         EHR_HIP(hipMemset((int*)ctx->counts.ptr + meta_off + 8, 0, sizeof(ph)));
     }
