@@ -352,7 +352,7 @@ struct BlockRaster {
     unsigned box[EHR_TILE_THREADS];       // bbox inside the region: x0 | y0 << 8 | w << 16 | h << 24
     int tri[EHR_TILE_THREADS];
     float4 pf[EHR_TILE_THREADS][3];       // clip-space vertices (depth)
-    unsigned frag[EHR_TILE_THREADS / 64][128];  // per-wave ring of covered fragments: region pixel index | job << 16
+    unsigned frag[EHR_TILE_THREADS / 64][128];  // per-wave ring: first pixel | 4-bit coverage << 12 | job << 16
     int wave_tot[EHR_TILE_THREADS / 64];
 };
 
@@ -384,17 +384,22 @@ __device__ __forceinline__ Edge32 job_edges(const unsigned xy[3], int bx0, int b
     return ed;
 }
 
-// Depth-test `n` (<= 64) fragments from this wave's ring, one per lane.
+// Depth-test `n` (<= 64) ring entries, one per lane.  An entry is a run of up to 4 horizontally adjacent pixels of one
+// job: first region pixel (bits 0-11) | 4-bit coverage mask (12-15) | job (16-31).
 template <int RW>
 __device__ __forceinline__ void drain_fragments(BlockRaster* br, const unsigned* ring, int head, int n, int W, int H,
                                                 int rx0, int ry0, u64* __restrict__ key) {
     const int lane = lane_id();
     if (lane < n) {
         unsigned f = ring[(head + lane) & 127];
-        int pix = f & 0xffffu, j = f >> 16;
+        int pix = f & 0xfffu, j = f >> 16;
+        unsigned m4 = (f >> 12) & 15u;
         float4 p[3] = {br->pf[j][0], br->pf[j][1], br->pf[j][2]};
+        const int t = br->tri[j];
         int py = pix / RW, px = pix - py * RW;
-        depth_test_write(p, br->tri[j], rx0 + px, ry0 + py, W, H, &key[pix]);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (m4 & (1u << i)) depth_test_write(p, t, rx0 + px + i, ry0 + py, W, H, &key[pix + i]);
     }
 }
 
@@ -448,7 +453,7 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
                         if (fits) {
                             fast = true;
                             int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-                            area = bw * bh;
+                            area = ((bw + 3) >> 2) * bh;  // work units: runs of 4 pixels along a row
                             pbox = (unsigned)(bx0 - rx0) | ((unsigned)(by0 - ry0) << 8) | ((unsigned)bw << 16) |
                                    ((unsigned)bh << 24);
                         } else {
@@ -478,10 +483,11 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
             br->pf[tid][2] = p[2];
         }
         __syncthreads();
-        // ---- every thread walks a contiguous run of K pixels of the concatenated bounding boxes
+        // ---- every thread walks a contiguous run of K work units; a unit = 4 horizontally adjacent pixels of a job's
+        //      bounding box (the per-unit bookkeeping -- ballot, ring push, row/job advance -- is paid once per 4 tests)
         const int K = (S + EHR_TILE_THREADS - 1) / EHR_TILE_THREADS;
         const int start = tid * K, end = min(start + K, S);
-        int j = 0, bw = 1, bh = 1, dx = 0, dy = 0, pix = 0;
+        int j = 0, bw = 1, bh = 1, gw = 1, gx = 0, dy = 0, pix = 0, rowpix = 0;
         Edge32 ed;
         int er0 = 0, er1 = 0, er2 = 0;  // edge values at the start of the current row
         ed.e[0] = ed.e[1] = ed.e[2] = -1;
@@ -502,27 +508,40 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
             int bx0 = bx & 255, by0 = (bx >> 8) & 255;
             bw = (bx >> 16) & 255;
             bh = bx >> 24;
+            gw = (bw + 3) >> 2;
             unsigned xy[3] = {br->xy[j][0], br->xy[j][1], br->xy[j][2]};
             ed = job_edges(xy, bx0, by0);
             int o = start - br->pre[j];
-            dy = o / bw;
-            dx = o - dy * bw;
+            dy = o / gw;
+            gx = o - dy * gw;
             er0 = ed.e[0] + dy * ed.sy[0];
             er1 = ed.e[1] + dy * ed.sy[1];
             er2 = ed.e[2] + dy * ed.sy[2];
-            ed.e[0] = er0 + dx * ed.sx[0];
-            ed.e[1] = er1 + dx * ed.sx[1];
-            ed.e[2] = er2 + dx * ed.sx[2];
-            pix = (by0 + dy) * RW + bx0 + dx;
+            ed.e[0] = er0 + 4 * gx * ed.sx[0];
+            ed.e[1] = er1 + 4 * gx * ed.sx[1];
+            ed.e[2] = er2 + 4 * gx * ed.sx[2];
+            rowpix = (by0 + dy) * RW + bx0;
+            pix = rowpix + 4 * gx;
         }
         int qhead = 0, qcount = 0;
 #pragma nounroll
         for (int it = 0; it < K; it++) {
             const bool act = start + it < end;
-            const bool inside = act && ((ed.e[0] | ed.e[1] | ed.e[2]) >= 0);
+            unsigned m4 = 0;
+            if (act) {
+                const int a1 = ed.e[0] + ed.sx[0], a2 = a1 + ed.sx[0], a3 = a2 + ed.sx[0];
+                const int b1 = ed.e[1] + ed.sx[1], b2 = b1 + ed.sx[1], b3 = b2 + ed.sx[1];
+                const int c1 = ed.e[2] + ed.sx[2], c2 = c1 + ed.sx[2], c3 = c2 + ed.sx[2];
+                m4 = ((ed.e[0] | ed.e[1] | ed.e[2]) >= 0 ? 1u : 0u) | ((a1 | b1 | c1) >= 0 ? 2u : 0u) |
+                     ((a2 | b2 | c2) >= 0 ? 4u : 0u) | ((a3 | b3 | c3) >= 0 ? 8u : 0u);
+                const int rem = bw - 4 * gx;  // pixels of this unit that lie inside the bounding box
+                if (rem < 4) m4 &= (1u << rem) - 1u;
+            }
+            const bool inside = m4 != 0;
             const u64 m = __ballot(inside);
             if (m) {
-                if (inside) ring[(qhead + qcount + __popcll(m & lt)) & 127] = (unsigned)pix | ((unsigned)j << 16);
+                if (inside)
+                    ring[(qhead + qcount + __popcll(m & lt)) & 127] = (unsigned)pix | (m4 << 12) | ((unsigned)j << 16);
                 qcount += __popcll(m);
                 if (qcount >= 64) {
                     EHR_WAVE_LDS_FENCE();
@@ -532,15 +551,16 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
                 }
             }
             if (act && start + it + 1 < end) {
-                dx++;
-                pix++;
-                ed.e[0] += ed.sx[0];
-                ed.e[1] += ed.sx[1];
-                ed.e[2] += ed.sx[2];
-                if (dx == bw) {
-                    dx = 0;
+                gx++;
+                pix += 4;
+                ed.e[0] += 4 * ed.sx[0];
+                ed.e[1] += 4 * ed.sx[1];
+                ed.e[2] += 4 * ed.sx[2];
+                if (gx == gw) {
+                    gx = 0;
                     dy++;
-                    pix += RW - bw;
+                    rowpix += RW;
+                    pix = rowpix;
                     er0 += ed.sy[0];
                     er1 += ed.sy[1];
                     er2 += ed.sy[2];
@@ -555,13 +575,15 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
                         int bx0 = bx & 255, by0 = (bx >> 8) & 255;
                         bw = (bx >> 16) & 255;
                         bh = bx >> 24;
+                        gw = (bw + 3) >> 2;
                         unsigned xy[3] = {br->xy[j][0], br->xy[j][1], br->xy[j][2]};
                         ed = job_edges(xy, bx0, by0);
                         er0 = ed.e[0];
                         er1 = ed.e[1];
                         er2 = ed.e[2];
                         dy = 0;
-                        pix = by0 * RW + bx0;
+                        rowpix = by0 * RW + bx0;
+                        pix = rowpix;
                     }
                 }
             }
