@@ -28,6 +28,9 @@ constexpr int RN = RW * RH;          // 340
 constexpr int CAND_PER_THREAD = (2 * RN + EHR_TILE_THREADS - 1) / EHR_TILE_THREADS;  // 3
 constexpr int MAX_ITEMS = 704;      // blended pairs kept per tile (all links); overflow is reported, never silent
 constexpr int MAX_LINKS = 32;
+#ifndef EHR_LEAN_WAVES
+#define EHR_LEAN_WAVES 4  // waves per SIMD the lean tile kernel is compiled for (4 workgroups per CU)
+#endif
 
 struct Item {
     int packed;  // bits 0-9 q (region index of pixel0) | 10 d | 11-12 di | 13 tri1 | 14 (c1 - c0 > 0)
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(256) fused_empty_kernel(BinGeom g, const int* 
 // (no 64-bit / clipping path, <= 128 VGPRs -> 4 workgroups per CU); tiles that hold a triangle needing that path are
 // on the second work list and run through the SLOW = true instantiation.
 template <bool SLOW>
-__global__ void __launch_bounds__(EHR_TILE_THREADS, SLOW ? 1 : 4)
+__global__ void __launch_bounds__(EHR_TILE_THREADS, SLOW ? 1 : EHR_LEAN_WAVES)
 fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, const int* __restrict__ counts,
                   const int* __restrict__ offsets, const int4* __restrict__ entries, int entries_cap,
                   const int* __restrict__ worklist, const int32_t* __restrict__ opp, const float* __restrict__ ref,
@@ -205,6 +208,15 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
         float acc = 0.f;
         int nitems = 0;  // uniform across the block
 
+        // queue entries of the NEXT link pass are fetched while the current one is processed (one global round trip
+        // per pass off the critical path)
+        int4 pre_e = make_int4(0, 0, 0, 0);
+        {
+            int lf = 0;
+            while (lf < L && cnt_l[lf] == 0) lf++;
+            if (lf < L && tid < cnt_l[lf] && off_l[lf] + tid < entries_cap) pre_e = entries[off_l[lf] + tid];
+        }
+
         for (int l = 0; l < L; l++) {
             int n = cnt_l[l];
             if (n == 0) {
@@ -213,11 +225,18 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
             }
             const int off = off_l[l];
             if (off + n > entries_cap) n = max(entries_cap - off, 0);
+            const int4 cur_e = pre_e;
+            {
+                int ln = l + 1;
+                while (ln < L && cnt_l[ln] == 0) ln++;
+                if (ln < L && tid < cnt_l[ln] && off_l[ln] + tid < entries_cap) pre_e = entries[off_l[ln] + tid];
+            }
             for (int i = tid; i < RN; i += EHR_TILE_THREADS) key[i] = ~0ull;
             __syncthreads();
             // ---- coverage + z-test of the link's queued triangles
             EHR_PHASE(0);
-            if (!(dbg & 2)) raster_queue<RW, RH, SLOW>(src, b, entries + off, n, W, H, rx0, ry0, key, &wscratch, meta);
+            if (!(dbg & 2))
+                raster_queue<RW, RH, SLOW>(src, b, entries + off, n, W, H, rx0, ry0, key, &wscratch, meta, cur_e, true);
             __syncthreads();
             EHR_PHASE(1);
             // ---- pixel pairs with different triangle ids -> dense hit list (deterministic order)
@@ -777,13 +796,16 @@ int ehr_fused_status(ehr_ctx* ctx) {
     EHR_HIP(hipMemcpy(meta, (int*)ctx->counts.ptr + meta_off, sizeof(meta), hipMemcpyDeviceToHost));
 #ifdef EHR_PHASE_TIMING
     {
-        unsigned long long ph[8];
+        unsigned long long ph[16];
         EHR_HIP(hipMemcpy(ph, (int*)ctx->counts.ptr + meta_off + 8, sizeof(ph), hipMemcpyDeviceToHost));
         const char* names[8] = {"pre-raster", "raster", "hit-discovery", "analysis", "gather", "composite", "backward", ""};
         unsigned long long tot = 0;
         for (int i = 0; i < 7; i++) tot += ph[i];
         for (int i = 0; i < 7; i++)
             fprintf(stderr, "[ehr phase] %-14s %12llu cycles  %5.1f %%\n", names[i], ph[i], tot ? 100.0 * ph[i] / tot : 0.0);
+        const char* sub[7] = {"r:load-wait", "r:setup", "r:prefix-sum", "r:stage+sync", "r:search", "r:walk", "r:tail+sync"};
+        for (int i = 0; i < 7; i++)
+            fprintf(stderr, "[ehr phase]   %-14s %12llu cycles  %5.1f %%\n", sub[i], ph[8 + i], tot ? 100.0 * ph[8 + i] / tot : 0.0);
         EHR_HIP(hipMemset((int*)ctx->counts.ptr + meta_off + 8, 0, sizeof(ph)));
     }
 #endif

@@ -62,7 +62,7 @@ struct BinGeom {
 #define EHR_META_NWORK 2     // non-empty tiles appended to the work list
 #define EHR_META_NWORK_SLOW 3  // ... of which tiles that hold a triangle needing the 64-bit / clipping path
 #define EHR_META_TICKET 6     // arrival counter of the merged reduce + pose-backward kernel
-#define EHR_META_INTS 40     // ints reserved for the meta block (8 words + profiling counters)
+#define EHR_META_INTS 48     // ints reserved for the meta block (8 words + profiling counters)
 
 // A triangle is "slow" when it needs near-plane clipping or spans more than this many sub-pixels: then (and only
 // then) its region-relative coordinates may not fit the 14 bits the 32-bit edge functions assume.  Tiles that hold a
@@ -408,15 +408,32 @@ __device__ __forceinline__ void drain_fragments(BlockRaster* br, const unsigned*
 // concatenated pixel sequence EVENLY over all threads (so all waves finish the walk together), each thread walks its
 // contiguous run stepping 32-bit edge functions, covered fragments are compacted per wave (ballot/popcount) into an
 // LDS ring and depth-tested 64 at a time.  Callers put barriers around it.
+#ifdef EHR_PHASE_TIMING
+#define EHR_SUBPHASE(i)                                                                       \
+    do {                                                                                      \
+        long long now_ = __builtin_readcyclecounter();                                        \
+        if (threadIdx.x == 0 && meta)                                                         \
+            atomicAdd((unsigned long long*)(meta + 8) + 8 + (i), (unsigned long long)(now_ - sub_last)); \
+        sub_last = now_;                                                                      \
+    } while (0)
+#else
+#define EHR_SUBPHASE(i) do { } while (0)
+#endif
+
 template <int RW, int RH, bool SLOW>
 __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const int4* __restrict__ ent, int n, int W,
                                              int H, int rx0, int ry0, u64* __restrict__ key,
-                                             BlockRaster* __restrict__ br, int* __restrict__ meta) {
+                                             BlockRaster* __restrict__ br, int* __restrict__ meta,
+                                             int4 first = make_int4(0, 0, 0, 0), bool have_first = false) {
+    // `first`: this thread's entry of round 0 (ent[tid]) if the caller already fetched it (prefetch across passes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* pv = src.verts(b);
     unsigned* ring = br->frag[wave];
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int nslow = 0;
+#ifdef EHR_PHASE_TIMING
+    long long sub_last = __builtin_readcyclecounter();
+#endif
 #pragma nounroll
     for (int base = 0; base < n; base += EHR_TILE_THREADS) {  // block-uniform
         const int i = base + tid;
@@ -428,11 +445,17 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
         int area = 0;
         unsigned pxy[3] = {0, 0, 0}, pbox = 0;
         if (active) {
-            int4 e = ent[i];
+            int4 e = (have_first && base == 0) ? first : ent[i];
             t = e.x;
             p[0] = pv[e.y];
             p[1] = pv[e.z];
             p[2] = pv[e.w];
+#ifdef EHR_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        }
+        EHR_SUBPHASE(0);
+        if (active) {
             const bool simple = (p[0].w > 0.f) && (p[1].w > 0.f) && (p[2].w > 0.f) && (p[0].z + p[0].w >= 0.f) &&
                                 (p[1].z + p[1].w >= 0.f) && (p[2].z + p[2].w >= 0.f);
             if (simple) {
@@ -466,9 +489,11 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
             }
         }
         nslow += slow ? 1 : 0;
+        EHR_SUBPHASE(1);
         // ---- block-wide prefix sum of the areas, stage the jobs
         int S;
         const int excl = block_offset(area, br->wave_tot, S);
+        EHR_SUBPHASE(2);
         if (S == 0) continue;  // block-uniform
         br->pre[tid] = excl;
         if (tid == EHR_TILE_THREADS - 1) br->pre[EHR_TILE_THREADS] = S;
@@ -483,6 +508,7 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
             br->pf[tid][2] = p[2];
         }
         __syncthreads();
+        EHR_SUBPHASE(3);
         // ---- every thread walks a contiguous run of K work units; a unit = 4 horizontally adjacent pixels of a job's
         //      bounding box (the per-unit bookkeeping -- ballot, ring push, row/job advance -- is paid once per 4 tests)
         const int K = (S + EHR_TILE_THREADS - 1) / EHR_TILE_THREADS;
@@ -524,6 +550,7 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
             pix = rowpix + 4 * gx;
         }
         int qhead = 0, qcount = 0;
+        EHR_SUBPHASE(4);
 #pragma nounroll
         for (int it = 0; it < K; it++) {
             const bool act = start + it < end;
@@ -588,11 +615,13 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
                 }
             }
         }
+        EHR_SUBPHASE(5);
         if (qcount) {
             EHR_WAVE_LDS_FENCE();
             drain_fragments<RW>(br, ring, qhead, qcount, W, H, rx0, ry0, key);
         }
         __syncthreads();  // the job table is rewritten by the next round
+        EHR_SUBPHASE(6);
     }
     if (!SLOW) {
         // tiles holding slow triangles are routed to the SLOW instantiation; if one shows up here the routing
