@@ -235,8 +235,11 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
             __syncthreads();
             // ---- coverage + z-test of the link's queued triangles
             EHR_PHASE(0);
-            if (!(dbg & 2))
-                raster_queue<RW, RH, SLOW>(src, b, entries + off, n, W, H, rx0, ry0, key, &wscratch, meta, cur_e, true);
+            if (!(dbg & 2)) {
+                RoundZero pre;
+                pre.e = cur_e;
+                raster_queue<RW, RH, SLOW, 1>(src, b, entries + off, n, W, H, rx0, ry0, key, &wscratch, meta, pre);
+            }
             __syncthreads();
             EHR_PHASE(1);
             // ---- pixel pairs with different triangle ids -> dense hit list (deterministic order)

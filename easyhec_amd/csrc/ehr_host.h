@@ -53,6 +53,9 @@ struct ehr_ctx {
     ehr::Scratch posc;       // float4 [B * V] clip-space vertices of the current step
     ehr::Scratch tile_part;  // float [B * NT * (1 + 12 * L)] per-tile partial loss + MVP gradients
     ehr::Scratch tile_list;  // int32 [2 * B * NT]: per-tile entry totals | work list of non-empty tiles
+    // space-explorer scoring (ehr_mask_variance) keeps its own scratch so that it never disturbs a solver plan
+    ehr::Scratch sc_counts, sc_offsets, sc_entries, sc_posc;
+    size_t sc_entries_cap = 0;
     // side stream: the empty-tile streaming kernel overlaps the queue fill + tile kernels
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;

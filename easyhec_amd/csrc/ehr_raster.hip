@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
     const int off = offsets[kidx];
     if (off + n > entries_cap) n = max(entries_cap - off, 0);
     __syncthreads();
-    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, &wscratch, nullptr);
+    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, &wscratch, nullptr, RoundZero());
     __syncthreads();
     // shade: one thread per pixel
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
@@ -199,7 +199,7 @@ int ehr_ctx_create(int device, ehr_ctx** out) {
     EHR_HIP(hipSetDevice(device));
     ehr_ctx* c = new ehr_ctx();
     c->device = device;
-    hipError_t e = hipHostMalloc((void**)&c->host_pinned, 4 * sizeof(int), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void**)&c->host_pinned, 8 * sizeof(int), hipHostMallocDefault);
     (void)hipSetDevice(cur);
     if (e != hipSuccess) {
         delete c;
@@ -220,6 +220,10 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->tile_part.release();
     c->tile_list.release();
     c->posc.release();
+    c->sc_counts.release();
+    c->sc_offsets.release();
+    c->sc_entries.release();
+    c->sc_posc.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

@@ -235,34 +235,47 @@ __global__ void __launch_bounds__(256) bin_kernel(ClipSource src, BinGeom g, int
 
 // One thread per (image, tile): offsets for the tile's L queues, per-tile total, work lists of non-empty tiles
 // (worklist[0 .. nwork) = lean tiles, worklist[ntiles .. ntiles + nwork_slow) = tiles flagged in tile_slow).
+// Queue storage and work-list slots are bump-allocated with ONE device atomic per workgroup and counter (same-address
+// device atomics serialise at ~12 ns each, so per-wave allocation dominated this kernel on many-view launches).
 static __global__ void __launch_bounds__(256) bin_alloc_kernel(const int* __restrict__ counts, int* __restrict__ offsets,
                                                                int* __restrict__ tile_total, int* __restrict__ worklist,
                                                                const int* __restrict__ tile_slow, int ntiles, int L,
                                                                int* __restrict__ meta) {
+    __shared__ int wsum[3][4];   // per wave: entries, lean tiles, slow tiles
+    __shared__ int bbase[3];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int c = 0;
     if (i < ntiles)
         for (int l = 0; l < L; l++) c += counts[(size_t)i * L + l];
     const bool is_slow = (i < ntiles) && c > 0 && tile_slow && tile_slow[i] != 0;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
     }
-    const int total = __shfl(incl, 63, 64);
     const u64 ne = __ballot(c > 0 && !is_slow);
     const u64 ns = __ballot(is_slow);
-    int base = 0, wbase = 0, sbase = 0;
-    if (lane == 63 && total > 0) {
-        base = atomicAdd(&meta[EHR_META_TOTAL], total);
-        if (ne) wbase = atomicAdd(&meta[EHR_META_NWORK], __popcll(ne));
-        if (ns) sbase = atomicAdd(&meta[EHR_META_NWORK_SLOW], __popcll(ns));
+    if (lane == 63) {
+        wsum[0][wave] = incl;
+        wsum[1][wave] = __popcll(ne);
+        wsum[2][wave] = __popcll(ns);
     }
-    base = __shfl(base, 63, 64);
-    wbase = __shfl(wbase, 63, 64);
-    sbase = __shfl(sbase, 63, 64);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        const int tot = (wsum[k][0] + wsum[k][1]) + (wsum[k][2] + wsum[k][3]);
+        const int word = (k == 0) ? EHR_META_TOTAL : (k == 1 ? EHR_META_NWORK : EHR_META_NWORK_SLOW);
+        bbase[k] = (tot > 0 && (k == 0 || worklist)) ? atomicAdd(&meta[word], tot) : 0;
+    }
+    __syncthreads();
+    int base = bbase[0], wbase = bbase[1], sbase = bbase[2];
+    for (int w = 0; w < wave; w++) {
+        base += wsum[0][w];
+        wbase += wsum[1][w];
+        sbase += wsum[2][w];
+    }
     if (i < ntiles) {
         int run = base + incl - c;
         for (int l = 0; l < L; l++) {
@@ -445,12 +458,18 @@ __device__ __forceinline__ void drain_fragments(BlockRaster* br, const unsigned*
 #define EHR_SUBPHASE(i) do { } while (0)
 #endif
 
-template <int RW, int RH, bool SLOW>
+// What the caller already fetched for this thread's job of round 0 (software pipelining across passes): PRE = 1 the
+// queue entry ent[tid], PRE = 2 the entry and its three clip-space vertices.
+struct RoundZero {
+    int4 e;
+    float4 p0, p1, p2;
+};
+
+template <int RW, int RH, bool SLOW, int PRE = 0>
 __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const int4* __restrict__ ent, int n, int W,
                                              int H, int rx0, int ry0, u64* __restrict__ key,
                                              BlockRaster* __restrict__ br, int* __restrict__ meta,
-                                             int4 first = make_int4(0, 0, 0, 0), bool have_first = false) {
-    // `first`: this thread's entry of round 0 (ent[tid]) if the caller already fetched it (prefetch across passes)
+                                             const RoundZero& pre) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float4* pv = src.verts(b);
     unsigned* ring = br->frag[wave];
@@ -470,11 +489,17 @@ __device__ __forceinline__ void raster_queue(const ClipSource& src, int b, const
         int area = 0;
         unsigned pxy[3] = {0, 0, 0}, pbox = 0;
         if (active) {
-            int4 e = (have_first && base == 0) ? first : ent[i];
+            int4 e = (PRE >= 1 && base == 0) ? pre.e : ent[i];
             t = e.x;
-            p[0] = pv[e.y];
-            p[1] = pv[e.z];
-            p[2] = pv[e.w];
+            if (PRE == 2 && base == 0) {
+                p[0] = pre.p0;
+                p[1] = pre.p1;
+                p[2] = pre.p2;
+            } else {
+                p[0] = pv[e.y];
+                p[1] = pv[e.z];
+                p[2] = pv[e.w];
+            }
 #ifdef EHR_PHASE_TIMING
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

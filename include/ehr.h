@@ -144,6 +144,21 @@ int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                     float* loss_b, float* grad_mvp, float* red, float* loss_out, float* grad_out, int defer_adam,
                     void* stream);
 
+/* Next-best-view scoring of the space explorer (modeling/models/rb_solve/space_explorer.py:152-165): for each of Q
+ * candidate joint configurations, the robot (all links merged into one mesh, utils/render_api.py:70-96) is rendered
+ * WITHOUT antialiasing under S camera poses (mask = rast[..., 2] > 0, structures/nvdiffrast_renderer.py:70) and the
+ * per-pixel unbiased variance over the S masks is summed over the image (torch.var(masks, dim=0).sum()).  For binary
+ * masks that is  sum_px c (S - c) / (S (S - 1))  with c = number of poses covering the pixel, so the kernel returns the
+ * exact integer  score[q] = sum_px c (S - c)  and the caller divides.
+ *   verts [V,3], tris [T,3] (global vertex ids), vert_link [V] (link of each vertex; NULL = all 0),
+ *   mvp [Q,S,L,16] = proj(K) @ opencv2blender @ Tc_c2b[s] @ link_pose[q,l], row-major;
+ *   score [Q] int64 (device); count [Q,H,W] uint8 (device, optional; image convention row 0 = top): c per pixel.
+ * Candidates are processed in passes of about chunk_views rendered views (<= 0: default 512) to bound the scratch;
+ * the call synchronises the stream once per pass (queue sizing) and once at the end (error flag). */
+int ehr_mask_variance(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* vert_link,
+                      const float* mvp, int Q, int S, int L, int V, int T, int H, int W, int64_t* score,
+                      uint8_t* count, int chunk_views, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,6 +168,34 @@ def render_mask_loss(verts, tris, tri_off, vert_off, mvp, ref, exact_interp=Fals
     return mask, loss, g
 
 
+def mask_variance(verts, tris, vert_link, mvp, H, W, return_counts=False):
+    """Space-explorer score (easyhec/modeling/models/rb_solve/space_explorer.py:152-165): for every candidate q the
+    merged robot mesh is rasterized without antialiasing under the S camera poses (render_api.py:70-96,
+    nvdiffrast_renderer.py:50-72, mask = rast[..., 2] > 0) and the unbiased per-pixel variance over the S binary masks
+    is summed: sum_px c (S - c) / (S (S - 1)).  Returns the exact integer numerator score [Q] = sum_px c (S - c)
+    (and the count images [Q,H,W] uint8, row 0 = top).
+
+    verts [V,3]; tris [T,3]; vert_link [V]; mvp [Q,S,L,4,4]."""
+    verts, tris, mvp = _f32(verts), _i32(tris), _f32(mvp)
+    vert_link = np.asarray(vert_link).astype(np.int64)
+    Q, S, L = mvp.shape[:3]
+    score = np.zeros((Q,), np.int64)
+    counts = np.zeros((Q, H, W), np.uint8) if return_counts else None
+    for q in range(Q):
+        pos = np.empty((S, verts.shape[0], 4), np.float32)
+        for s in range(S):
+            for l in range(L):
+                sel = np.nonzero(vert_link == l)[0]
+                if sel.size:
+                    pos[s, sel] = transform_pos(mvp[q, s, l], verts[sel])[0]
+        rast, _ = rasterize(pos, tris, (H, W), grad_db=False)
+        c = (rast[..., 2] > 0).sum(0).astype(np.int64)  # [H,W], row 0 = bottom
+        score[q] = int((c * (S - c)).sum())
+        if return_counts:
+            counts[q] = c[::-1].astype(np.uint8)
+    return (score, counts) if return_counts else score
+
+
 def set_num_threads(n):
     lib().ehro_set_num_threads(int(n))
 

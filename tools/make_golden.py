@@ -73,7 +73,24 @@ def ops_random():
     print("ops_random: covered", int((rast[..., 3] > 0).sum()))
 
 
+def score_small():
+    """Space-explorer score (oracle.mask_variance): 4 candidate configurations x 5 camera poses at 160x120."""
+    rb = load_robot("xarm7")
+    H, W, Q, S = 120, 160, 4, 5
+    K = scaled_K(XARM7_K_1280x720, 0.125, W, H, True)
+    _, lp = make_views(rb, Q, seed=7, qpos_scale=0.8)
+    rng = np.random.default_rng(8)
+    Tc0 = camera_Tc_c2b()
+    mvp = np.stack([helpers.mvp_numpy(K, H, W, perturb_pose(Tc0, dt=rng.normal(0, 0.02, 3),
+                                                            drot_deg=rng.normal(0, 2.0, 3)), lp) for _ in range(S)], axis=1)
+    verts, tris, _, _ = helpers.scene_arrays(rb)
+    vl = np.concatenate([np.full(v.shape[0], l, np.int32) for l, (v, _) in enumerate(rb.meshes)])
+    score, counts = oracle.mask_variance(verts, tris, vl, mvp, H, W, return_counts=True)
+    np.savez_compressed(os.path.join(GOLD, "score_xarm7_160x120.npz"), mvp=mvp, score=score, counts=counts, H=H, W=W)
+    print("score_small:", score)
+
+
 if __name__ == "__main__":
-    config1()
-    fused_small()
-    ops_random()
+    which = sys.argv[1:] or ["config1", "fused_small", "ops_random", "score_small"]
+    for name in which:
+        globals()[name]()
