@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--s", type=int, default=10)
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--cpu-q", type=int, default=0, help="also time the CPU oracle on this many candidates")
     a = ap.parse_args()
     H, W = 720, 1280
     rb = load_robot("xarm7")
@@ -48,9 +49,25 @@ def main():
         ts.append(time.time() - t0)
     t = float(np.median(ts))
     n = a.q * a.s
-    print({"renders": n, "seconds": round(t, 5), "renders_per_s": round(n / t, 1), "us_per_render": round(1e6 * t / n, 2),
-           "fk_seconds_host": round(t_fk, 3), "best": int(score.argmax()), "var_max": float(var.max()),
-           "var_min": float(var.min())})
+    out = {"metric": "space-explorer mask renders/sec (non-AA packed robot mask + per-pixel variance over poses)",
+           "value": round(n / t, 1), "unit": "renders/s", "seconds_per_round": round(t, 5),
+           "us_per_render": round(1e6 * t / n, 2), "dtype": "f32 positions, integer coverage/score",
+           "config": {"workload": f"xarm7 {a.q} qpos x {a.s} poses @1280x720", "chunk_views": a.chunk or 512,
+                      "robot_tris": rb.num_tris}, "fk_seconds_host": round(t_fk, 3), "best": int(score.argmax()),
+           "var_max": float(var.max()), "var_min": float(var.min())}
+    if a.cpu_q > 0:
+        from oracle import oracle
+        verts, tris, _, _ = helpers.scene_arrays(rb)
+        vl = np.concatenate([np.full(v.shape[0], l, np.int32) for l, (v, _) in enumerate(rb.meshes)])
+        m = mvp[:a.cpu_q].cpu().numpy()
+        t0 = time.time()
+        s_ref = oracle.mask_variance(verts, tris, vl, m, H, W)
+        tc = time.time() - t0
+        assert (s_ref == score[:a.cpu_q].cpu().numpy()).all(), "GPU score differs from the oracle"
+        out["cpu_baseline"] = {"value": round(a.cpu_q * a.s / tc, 1), "unit": "renders/s", "cores": oracle.num_threads(),
+                               "kind": "port", "sample": f"{a.cpu_q} candidates x {a.s} poses, oracle.mask_variance"}
+    import json
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
