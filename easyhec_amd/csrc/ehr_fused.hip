@@ -594,6 +594,7 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         EHR_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         EHR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         EHR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        EHR_HIP(hipEventCreateWithFlags(&ctx->ev_fill, hipEventDisableTiming));
     }
     ctx->pB = B;
     ctx->pL = L;
@@ -699,7 +700,6 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
         EHR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         fused_empty_kernel<<<dim3(g.nty, B), 256, 0, ctx->side>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
         EHR_LAUNCH_CHECK();
-        EHR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
     }
     // stage 2: fill
     if (T > 0) {
@@ -707,6 +707,10 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
         EHR_LAUNCH_CHECK();
     }
     if (ev) EHR_HIP(hipEventRecord(ev[3], stream));
+    if (overlap) {  // the side stream's second kernel (slow tiles, below) needs the filled queues
+        EHR_HIP(hipEventRecord(ctx->ev_fill, stream));
+        EHR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fill, 0));
+    }
     // stage 3: tiles -- streaming pass over the empty ones, persistent workgroups over the work list
     if (!overlap) {
         fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
@@ -719,12 +723,19 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
                                                                     worklist, opp, ref, mask, tile_part,
                                                                     grad_mvp ? 1 : 0, meta, dbg_skip);
     EHR_LAUNCH_CHECK();
-    // tiles holding a near-clipped or very large triangle (normally none): same kernel with the 64-bit path compiled in
-    fused_tile_kernel<true><<<std::max(1, std::min(ntiles, ctx->num_cus / 8)), EHR_TILE_THREADS, 0, stream>>>(
+    // tiles holding a near-clipped or very large triangle (normally none): same kernel with the 64-bit path compiled in.
+    // Disjoint tiles, so it runs beside the lean kernel on the side stream (behind the empty-tile pass) instead of
+    // adding its launch + drain (~4 us even when its work list is empty) to the critical path.
+    static const int side_slow = getenv("EHR_SIDE_SLOW") ? atoi(getenv("EHR_SIDE_SLOW")) : 1;  // tuning knob
+    hipStream_t sstream = (overlap && side_slow) ? ctx->side : stream;
+    fused_tile_kernel<true><<<std::max(1, std::min(ntiles, ctx->num_cus / 8)), EHR_TILE_THREADS, 0, sstream>>>(
         src, g, verts, counts, offsets, entries, ecap, worklist + ntiles, opp, ref, mask, tile_part, grad_mvp ? 1 : 0,
         meta, dbg_skip);
     EHR_LAUNCH_CHECK();
-    if (overlap) EHR_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
+    if (overlap) {
+        EHR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+        EHR_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
+    }
     if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
     // stage 4: fixed-order reduction
     dim3 rgrid(L + 1, B);

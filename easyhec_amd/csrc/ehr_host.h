@@ -58,7 +58,7 @@ struct ehr_ctx {
     size_t sc_entries_cap = 0;
     // side stream: the empty-tile streaming kernel overlaps the queue fill + tile kernels
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fill = nullptr;
     // measurement hook (ehr_fused_timing): EHR_FUSED_STAGES + 1 events per recorded call
     bool timing = false;
     std::vector<hipEvent_t> ev;

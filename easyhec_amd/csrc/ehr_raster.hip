@@ -228,6 +228,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fill) (void)hipEventDestroy(c->ev_fill);
     if (c->side) (void)hipStreamDestroy(c->side);
     (void)hipSetDevice(cur);
     delete c;
