@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libehr_hip.so")
+LIB_PATH = os.environ.get("EHR_LIB") or os.path.join(_HERE, "libehr_hip.so")  # EHR_LIB: A/B builds of the same ABI
 _lib = None
 
 c_void_p, c_int, c_size_t, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
