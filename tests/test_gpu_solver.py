@@ -147,3 +147,21 @@ def test_reference_franka_offline_example_converges(tmp_path):
     assert l1 < 0.45 * l0 and i1 > 0.62, (l0, l1, i0, i1)
     assert hist[300] < 0.5 * hist[0]                          # the drop happens early, then a plateau
     assert abs(hist[-1] - hist[600]) < 0.05 * hist[600]
+    # the consumer of the result (tools/validate.py:13-48 in the reference): newest checkpoint -> ckpt['model']['dof'] ->
+    # render_api overlay on every colour frame
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tr.save(os.path.join(d, "models", "model_iteration_001000.pth"))
+    os.makedirs(os.path.join(d, "color"))
+    for i in range(shape[0]):
+        Image.fromarray(np.full(shape[1:] + (3,), 128, np.uint8)).save(os.path.join(d, "color", f"{i:06d}.png"))
+    out = os.path.join(d, "overlay")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "validate.py"), "--ckpt_dir", os.path.join(d, "models"),
+                    "--data_dir", d, "--robot", "franka", "--out", out], check=True, timeout=600)
+    ious = []
+    for i in range(shape[0]):
+        img = np.asarray(Image.open(os.path.join(out, f"rendered_mask_{i:06d}.png"))).astype(int)
+        tinted = (img[..., 0] - img[..., 2]) > 40              # red overlay on the grey frame
+        ious.append((tinted & masks[i]).sum() / (tinted | masks[i]).sum())
+    assert np.mean(ious) > 0.6, ious
