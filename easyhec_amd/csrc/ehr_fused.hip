@@ -716,6 +716,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
         fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
         EHR_LAUNCH_CHECK();
     }
+    if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
     static const int grid_mult = getenv("EHR_TILE_GRID_MULT") ? atoi(getenv("EHR_TILE_GRID_MULT")) : 6;  // tuning knob
     const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * std::max(1, grid_mult)));
     static const int dbg_skip = getenv("EHR_DEBUG_SKIP") ? atoi(getenv("EHR_DEBUG_SKIP")) : 0;  // profiling aid only
@@ -723,6 +724,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
                                                                     worklist, opp, ref, mask, tile_part,
                                                                     grad_mvp ? 1 : 0, meta, dbg_skip);
     EHR_LAUNCH_CHECK();
+    if (ev) EHR_HIP(hipEventRecord(ev[5], stream));
     // tiles holding a near-clipped or very large triangle (normally none): same kernel with the 64-bit path compiled in.
     // Disjoint tiles, so it runs beside the lean kernel on the side stream (behind the empty-tile pass) instead of
     // adding its launch + drain (~4 us even when its work list is empty) to the critical path.
@@ -736,7 +738,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
         EHR_HIP(hipEventRecord(ctx->ev_join, ctx->side));
         EHR_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
     }
-    if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
+    if (ev) EHR_HIP(hipEventRecord(ev[6], stream));
     // stage 4: fixed-order reduction
     dim3 rgrid(L + 1, B);
     if (tail) {
@@ -746,7 +748,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
         fused_reduce_kernel<false><<<rgrid, 256, 0, stream>>>(g, counts, tile_part, loss, grad_mvp, meta, none);
     }
     EHR_LAUNCH_CHECK();
-    if (ev) EHR_HIP(hipEventRecord(ev[5], stream));
+    if (ev) EHR_HIP(hipEventRecord(ev[7], stream));
     return EHR_OK;
 }
 

@@ -124,7 +124,7 @@ def mvp_matrices(K, H, W, Tc_c2b, link_poses, n=0.001, f=10.0):
     return proj @ (o2b @ Tc_c2l)                      # nvdiffrast_renderer.py:35,37 (same association)
 
 
-STAGES = ("bin_count", "bin_alloc", "bin_fill", "tile", "reduce")
+STAGES = ("bin_count", "bin_alloc", "bin_fill", "tile_empty", "tile", "tile_slow", "reduce")
 
 
 def set_timing(glctx, enable):

@@ -105,9 +105,10 @@ int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVE
 /* Measurement hook (bench.py's roofline leg): when enabled, every ehr_render_mask_loss call records hipEvents
  * around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED milliseconds
  * per stage since the last read -- ms[0] memset + vertex transform + bin count, ms[1] queue alloc, ms[2] bin fill,
- * ms[3] tile kernels (empty-tile stream + work-list tiles: the dominant stage), ms[4] reduce -- and the number of
- * calls covered, then resets.  Not for use under graph capture. */
-#define EHR_FUSED_STAGES 5
+ * ms[3] empty-tile streaming kernel, ms[4] work-list tile kernel (lean instantiation: the dominant kernel), ms[5] its
+ * slow-path instantiation, ms[6] reduce -- and the number of calls covered, then resets.  While enabled the kernels
+ * run back to back on the launch stream (no side-stream overlap).  Not for use under graph capture. */
+#define EHR_FUSED_STAGES 7
 int ehr_fused_timing(ehr_ctx* ctx, int enable);
 int ehr_fused_timing_read(ehr_ctx* ctx, float* ms, int* ncalls);
 

@@ -1,0 +1,57 @@
+"""Step time of the drop-in three-op path (RBSolver(use_fused=False): dr.rasterize -> dr.interpolate -> dr.antialias per
+(view, link), torch autograd, torch.optim.Adam) on the headline workload -- what a maintainer gets by only swapping the
+import.  python tools/three_op_bench.py [--views 8] [--steps 20]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from easyhec_amd.config import Cfg  # noqa: E402
+from easyhec_amd.rb_solver import RBSolver  # noqa: E402
+from easyhec_amd.robot import load_robot  # noqa: E402
+from easyhec_amd.synthetic import WORKLOADS, camera_Tc_c2b, make_views, perturb_pose  # noqa: E402
+from easyhec_amd.trainer import RBSolverTrainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    wl = WORKLOADS["xarm7_1280x720_8view"]
+    rb = load_robot("xarm7")
+    H, W, K = wl["H"], wl["W"], wl["K"]
+    _, lp = make_views(rb, a.views)
+    Tc = camera_Tc_c2b(radius=wl["radius"], lift=wl["lift"])
+    out = {}
+    for fusedflag in (False, True):
+        cfg = Cfg()
+        cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
+        cfg.model.rbsolver.init_Tc_c2b = perturb_pose(Tc).tolist()
+        cfg.model.rbsolver.use_fused = fusedflag
+        model = RBSolver(cfg, meshes=rb.meshes).to(dev)
+        batch = {"mask": torch.zeros((a.views, H, W), device=dev), "link_poses": torch.tensor(lp, device=dev),
+                 "K": torch.tensor(K, dtype=torch.float32, device=dev)[None].repeat(a.views, 1, 1)}
+        tr = RBSolverTrainer(cfg, model, batch)
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(a.steps):
+            tr.step()
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / a.steps
+        out["fused_autograd" if fusedflag else "three_ops"] = {"ms_per_step": round(dt * 1e3, 3),
+                                                              "frames_per_s": round(a.views / dt, 1)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
