@@ -38,6 +38,20 @@ struct Item {
     float alpha;
 };
 
+// Per-view sums (frame loss, 12 gradient numbers per link) are accumulated in 64-bit FIXED POINT with integer atomics:
+// integer addition is associative, so the result does not depend on which workgroup adds first -- bit-reproducible like
+// a fixed-order reduction, but without a reduction pass over all tiles.  Scale 2^32: addends are rounded to 2.3e-10
+// (absolute), sums up to +-2.1e9 fit; larger magnitudes raise the overflow flag (loss = NaN), never wrap silently.
+#define EHR_FIX_SCALE 4294967296.0
+__device__ __forceinline__ void fix_add(long long* acc, float v, int* meta) {
+    if (!(fabsf(v) < 1.0e9f)) {  // also catches NaN
+        meta[EHR_META_OVERFLOW] = 1;
+        return;
+    }
+    if (v != 0.f) atomicAdd((unsigned long long*)acc, (unsigned long long)__double2ll_rn((double)v * EHR_FIX_SCALE));
+}
+__device__ __forceinline__ float fix_get(long long q) { return (float)((double)q * (1.0 / EHR_FIX_SCALE)); }
+
 // clip-space vertices of every (view, vertex): posc[b][v] = MVP[b, vert_link[v]] * [x, y, z, 1]
 // (easyhec/utils/nvdiffrast_utils.py:14-18 for all links of a view at once)
 __global__ void __launch_bounds__(256) fused_vertex_kernel(const float* __restrict__ verts,
@@ -59,7 +73,7 @@ step_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ 
                    const float* __restrict__ K, const float* __restrict__ link_poses, int V, int L, int H, int W, float n,
                    float f, float4* __restrict__ posc, float* __restrict__ mvp, float* __restrict__ tc_jac,
                    const int* __restrict__ step, float* __restrict__ history, int history_rows, int* __restrict__ zero,
-                   int nzero) {
+                   int nzero, int* __restrict__ zero2, int nzero2) {
     __shared__ float Tc[16];
     __shared__ float M[MAX_LINKS][16];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -87,6 +101,8 @@ step_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ 
         const int per = (nzero + nblk - 1) / nblk;
         const int z0 = blk * per, z1 = min(z0 + per, nzero);
         for (int i = z0 + tid; i < z1; i += 256) zero[i] = 0;
+        if (blk == 0)
+            for (int i = tid; i < nzero2; i += 256) zero2[i] = 0;  // the fixed-point accumulators (a few KB)
     }
     __syncthreads();
     if (tid < L) {
@@ -110,12 +126,14 @@ step_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ 
 // grid = (tile rows, views); one wave handles one 32x8 tile as 64 float4 accesses (full 128-byte lines).
 __global__ void __launch_bounds__(256) fused_empty_kernel(BinGeom g, const int* __restrict__ tile_total,
                                                           const float* __restrict__ ref, float* __restrict__ mask,
-                                                          float* __restrict__ tile_part, int part_stride) {
+                                                          long long* __restrict__ facc, int acc_stride,
+                                                          int* __restrict__ meta) {
     const int ty = blockIdx.x, b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ly = lane >> 3, lx4 = (lane & 7) * 4;  // 8 rows x 8 float4
     const int iy = ty * EHR_TILE_H + ly;
     const bool vec_ok = (g.W & 3) == 0;
+    long long wsum = 0;  // this wave's share of the view's loss, fixed point
     for (int tx = wave; tx < g.ntx; tx += 4) {
         const int tile = ty * g.ntx + tx;
         if (tile_total[b * g.nt + tile] != 0) continue;  // wave-uniform
@@ -136,8 +154,12 @@ __global__ void __launch_bounds__(256) fused_empty_kernel(BinGeom g, const int* 
             }
         }
         s = wave_sum(s);
-        if (lane == 0) tile_part[(size_t)(b * g.nt + tile) * part_stride] = s;
+        if (lane == 0) {
+            if (!(s < 1.0e9f)) meta[EHR_META_OVERFLOW] = 1;
+            wsum += __double2ll_rn((double)s * EHR_FIX_SCALE);
+        }
     }
+    if (lane == 0 && wsum) atomicAdd((unsigned long long*)&facc[(size_t)b * acc_stride + acc_stride - 1], (unsigned long long)wsum);
 }
 
 // Heavy tiles: persistent workgroups walk the work list of non-empty tiles.  SLOW = false is the lean instantiation
@@ -148,7 +170,7 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS, SLOW ? 1 : EHR_LEAN_WAVES)
 fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, const int* __restrict__ counts,
                   const int* __restrict__ offsets, const int4* __restrict__ entries, int entries_cap,
                   const int* __restrict__ worklist, const int32_t* __restrict__ opp, const float* __restrict__ ref,
-                  float* __restrict__ mask, float* __restrict__ tile_part, int want_grad, int* __restrict__ meta,
+                  float* __restrict__ mask, long long* __restrict__ facc, int want_grad, int* __restrict__ meta,
                   int dbg) {
     __shared__ u64 key[RN];
     __shared__ float pairA[2][RN];
@@ -159,12 +181,11 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
     __shared__ int cnt_l[MAX_LINKS];
     __shared__ int off_l[MAX_LINKS];
     __shared__ float gpix[EHR_TILE_W * EHR_TILE_H];
-    __shared__ float wred[4][12];
 
     const int tid = threadIdx.x;
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
     const int L = g.L, W = g.W, H = g.H;
-    const int part_stride = 1 + 12 * L;
+    const int acc_stride = 12 * L + 1;  // per view: 12 numbers per link, then the frame loss
     const int myq = (ly + 1) * RW + (lx + 1);
     const int nwork = meta[SLOW ? EHR_META_NWORK_SLOW : EHR_META_NWORK];
 #ifdef EHR_PHASE_TIMING
@@ -188,7 +209,7 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
         const int ix = tx * EHR_TILE_W + lx, iy = ty * EHR_TILE_H + ly;
         const bool in_img = ix < W && iy < H;
         const int kidx = gt * L;
-        float* part = tile_part + (size_t)gt * part_stride;
+        long long* vacc = facc + (size_t)b * acc_stride;
         const float4* pv = src.verts(b);
 
         __syncthreads();  // previous tile's LDS users are done
@@ -379,10 +400,8 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
         gpix[tid] = gval;
         {
             float s = wave_sum(e2);
-            if ((tid & 63) == 0) wred[tid >> 6][0] = s;
-            __syncthreads();
-            if (tid == 0) part[0] = ((wred[0][0] + wred[1][0]) + wred[2][0]) + wred[3][0];
-            __syncthreads();
+            if ((tid & 63) == 0) fix_add(&vacc[12 * L], s, meta);
+            __syncthreads();  // gpix is read by the backward pass
         }
         EHR_PHASE(5);
         if (!want_grad) continue;
@@ -424,22 +443,22 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
                     for (int c = 0; c < 4; c++) G[4 * r + c] += g1[r] * h1[c] + g2[r] * h2[c];
             }
             seg0 = seg1;
+            // every wave adds its 12 sums itself (lane k holds number k): no LDS staging, no barriers
+            float mine = 0.f;
 #pragma unroll
             for (int k = 0; k < 12; k++) {
                 float s = wave_sum(G[k]);
-                if ((tid & 63) == 0) wred[tid >> 6][k] = s;
+                if ((tid & 63) == k) mine = s;
             }
-            __syncthreads();
-            if (tid < 12) part[1 + 12 * l + tid] = ((wred[0][tid] + wred[1][tid]) + wred[2][tid]) + wred[3][tid];
-            __syncthreads();
+            if ((tid & 63) < 12) fix_add(&vacc[12 * l + (tid & 63)], mine, meta);
         }
         EHR_PHASE(6);
     }
 }
 
-// Fixed-order reduction of the per-tile partials.  grid = (L + 1, B): block (j, b) reduces link j's 12 numbers
-// (j < L) or the loss (j == L).
-struct StepTail {  // what the last reduce block needs to finish a solver step (all device pointers)
+// Last stage, ONE workgroup: fixed-point accumulators -> loss[B] and grad_mvp[B,L,16]; with TAIL also the rest of a
+// solver step (d sum(loss) / d dof = the 8 floats a data-parallel job all-reduces, then Adam unless deferred).
+struct StepTail {  // what the solver-step form needs (all device pointers)
     const float* K;
     const float* link_poses;
     const float* tc_jac;
@@ -455,91 +474,31 @@ struct StepTail {  // what the last reduce block needs to finish a solver step (
 };
 
 template <bool TAIL>
-__global__ void __launch_bounds__(256) fused_reduce_kernel(BinGeom g, const int* __restrict__ counts,
-                                                           const float* __restrict__ tile_part,
+__global__ void __launch_bounds__(256) fused_finish_kernel(BinGeom g, int B, const long long* __restrict__ facc,
                                                            float* __restrict__ loss, float* __restrict__ grad_mvp,
-                                                           int* __restrict__ meta, StepTail tail) {
-    __shared__ double red[256][12];
-    const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, L = g.L;
-    const int part_stride = 1 + 12 * L;
-    double s[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) s[k] = 0.0;
-    // two independent batches of loads per thread (counts, then partials) instead of a dependent chain per tile
-    constexpr int MAXT = 16;  // tiles per thread per batch
-    for (int t0 = 0; t0 < g.nt; t0 += 256 * MAXT) {
-        if (j == L) {
-            float v[MAXT];
-#pragma unroll
-            for (int i = 0; i < MAXT; i++) {
-                int t = t0 + tid + 256 * i;
-                v[i] = (t < g.nt) ? tile_part[(size_t)(b * g.nt + t) * part_stride] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < MAXT; i++) s[0] += (double)v[i];
-        } else {
-            if (!grad_mvp && !TAIL) return;
-            unsigned act = 0;
-#pragma unroll
-            for (int i = 0; i < MAXT; i++) {
-                int t = t0 + tid + 256 * i;
-                if (t < g.nt && counts[(b * g.nt + t) * L + j] != 0) act |= 1u << i;
-            }
-#pragma unroll
-            for (int i = 0; i < MAXT; i++) {
-                if (act & (1u << i)) {
-                    int t = t0 + tid + 256 * i;
-                    const float* p = tile_part + (size_t)(b * g.nt + t) * part_stride + 1 + 12 * j;
-#pragma unroll
-                    for (int k = 0; k < 12; k++) s[k] += (double)p[k];
-                }
-            }
+                                                           const int* __restrict__ meta, StepTail tail) {
+    const int tid = threadIdx.x, L = g.L;
+    const int acc_stride = 12 * L + 1;
+    const bool bad = meta[EHR_META_OVERFLOW] != 0;  // overflow => NaN, never a silently wrong loss
+    const float nanv = __int_as_float(0x7fc00000);
+    for (int i = tid; i < B; i += 256) loss[i] = bad ? nanv : fix_get(facc[(size_t)i * acc_stride + 12 * L]);
+    if (grad_mvp) {
+        for (int i = tid; i < B * L * 16; i += 256) {
+            // rows x, y, w of the 4x4 gradient; the z row never receives gradient on this path
+            const int bl = i >> 4, e = i & 15, r = e >> 2, c = e & 3;
+            const int b = bl / L, l = bl - b * L;
+            float v = 0.f;
+            if (r != 2) v = fix_get(facc[(size_t)b * acc_stride + 12 * l + 4 * (r == 3 ? 2 : r) + c]);
+            grad_mvp[i] = bad ? nanv : v;
         }
-    }
-#pragma unroll
-    for (int k = 0; k < 12; k++) red[tid][k] = s[k];
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) red[tid][k] += red[tid + o][k];
-        }
-        __syncthreads();
-    }
-    if (j == L) {
-        if (tid == 0) {
-            float v = (float)red[0][0];
-            if (meta[EHR_META_OVERFLOW]) v = __int_as_float(0x7fc00000);  // overflow => NaN, never a silently wrong loss
-            loss[b] = v;
-        }
-    } else if (tid < 16) {
-        // rows x, y, w of the 4x4 gradient; the z row never receives gradient on this path
-        int r = tid >> 2, c = tid & 3;
-        float v = 0.f;
-        if (r == 0) v = (float)red[0][c];
-        if (r == 1) v = (float)red[0][4 + c];
-        if (r == 3) v = (float)red[0][8 + c];
-        grad_mvp[((size_t)b * L + j) * 16 + tid] = v;
     }
     if (TAIL) {
-        // Merged last stage: the block that finishes last (ticket) turns grad_mvp / loss into the dof gradient and,
-        // unless the caller wants to all-reduce first, applies Adam.  Release/acquire at agent scope around the
-        // ticket: the other blocks ran on other CUs / XCDs.
-        __shared__ int is_last;
         __shared__ double S[256][16];
         __shared__ double lsum[256];
-        __syncthreads();
-        if (tid == 0) {
-            __threadfence();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must land before the ticket (G16)
-            int t = atomicAdd(&meta[EHR_META_TICKET], 1);
-            is_last = (t == (int)(gridDim.x * gridDim.y) - 1);
-            __threadfence();
-        }
-        __syncthreads();
-        if (!is_last) return;
-        pose_backward_block(grad_mvp, loss, tail.K, tail.link_poses, tail.tc_jac, gridDim.y, L, g.H, g.W, tail.n, tail.f,
-                            tail.red, S, lsum);
+        __threadfence_block();
+        __syncthreads();  // grad_mvp / loss written above are read back by the whole workgroup
+        pose_backward_block(grad_mvp, loss, tail.K, tail.link_poses, tail.tc_jac, B, L, g.H, g.W, tail.n, tail.f, tail.red, S,
+                            lsum);
         __syncthreads();
         if (!tail.defer_adam)
             pose_adam_block(tail.dof, tail.m, tail.v, tail.step, tail.red, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,
@@ -582,7 +541,7 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
         ctx->entries_cap = want;
     }
-    if ((rc = ctx->tile_part.reserve((size_t)B * g.nt * (1 + 12 * (size_t)L) * sizeof(float)))) return rc;
+    if ((rc = ctx->tile_part.reserve((size_t)B * (12 * (size_t)L + 1) * sizeof(long long)))) return rc;  // fixed-point sums
     if ((rc = ctx->tile_list.reserve((size_t)3 * B * g.nt * sizeof(int)))) return rc;  // tile totals | lean work list | slow work list
     if ((rc = ctx->posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
     int dev = 0;
@@ -641,7 +600,8 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     int* tile_total = (int*)ctx->tile_list.ptr;
     int* worklist = tile_total + ntiles;
     float4* posc = (float4*)ctx->posc.ptr;
-    float* tile_part = (float*)ctx->tile_part.ptr;
+    long long* facc = (long long*)ctx->tile_part.ptr;
+    const int acc_stride = 12 * L + 1, nacc_ints = 2 * B * acc_stride;
     const int ecap = (int)std::min(ctx->entries_cap, (size_t)0x7fffffff);
     ClipSource src;
     src.pos = posc;
@@ -672,10 +632,11 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     if (head && V > 0) {
         step_vertex_kernel<<<dim3((V + 255) / 256, B), 256, 0, stream>>>(
             verts, vert_link, head->dof, head->K, head->link_poses, V, L, H, W, head->n, head->f, posc, mvp, head->tc_jac,
-            head->step, head->history, head->history_rows, counts, nzero);
+            head->step, head->history, head->history_rows, counts, nzero, (int*)facc, nacc_ints);
         EHR_LAUNCH_CHECK();
     } else {
         EHR_HIP(hipMemsetAsync(counts, 0, (size_t)nzero * sizeof(int), stream));
+        EHR_HIP(hipMemsetAsync(facc, 0, (size_t)nacc_ints * sizeof(int), stream));
         if (V > 0) {
             fused_vertex_kernel<<<dim3((V + 255) / 256, B), 256, 0, stream>>>(verts, vert_link, mvp, V, L, posc);
             EHR_LAUNCH_CHECK();
@@ -698,7 +659,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     if (overlap) {
         EHR_HIP(hipEventRecord(ctx->ev_fork, stream));
         EHR_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-        fused_empty_kernel<<<dim3(g.nty, B), 256, 0, ctx->side>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
+        fused_empty_kernel<<<dim3(g.nty, B), 256, 0, ctx->side>>>(g, tile_total, ref, mask, facc, acc_stride, meta);
         EHR_LAUNCH_CHECK();
     }
     // stage 2: fill
@@ -713,7 +674,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     }
     // stage 3: tiles -- streaming pass over the empty ones, persistent workgroups over the work list
     if (!overlap) {
-        fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, tile_part, 1 + 12 * L);
+        fused_empty_kernel<<<dim3(g.nty, B), 256, 0, stream>>>(g, tile_total, ref, mask, facc, acc_stride, meta);
         EHR_LAUNCH_CHECK();
     }
     if (ev) EHR_HIP(hipEventRecord(ev[4], stream));
@@ -721,7 +682,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     const int tgrid = std::max(1, std::min(ntiles, ctx->num_cus * std::max(1, grid_mult)));
     static const int dbg_skip = getenv("EHR_DEBUG_SKIP") ? atoi(getenv("EHR_DEBUG_SKIP")) : 0;  // profiling aid only
     fused_tile_kernel<false><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, verts, counts, offsets, entries, ecap,
-                                                                    worklist, opp, ref, mask, tile_part,
+                                                                    worklist, opp, ref, mask, facc,
                                                                     grad_mvp ? 1 : 0, meta, dbg_skip);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[5], stream));
@@ -731,7 +692,7 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     static const int side_slow = getenv("EHR_SIDE_SLOW") ? atoi(getenv("EHR_SIDE_SLOW")) : 1;  // tuning knob
     hipStream_t sstream = (overlap && side_slow) ? ctx->side : stream;
     fused_tile_kernel<true><<<std::max(1, std::min(ntiles, ctx->num_cus / 8)), EHR_TILE_THREADS, 0, sstream>>>(
-        src, g, verts, counts, offsets, entries, ecap, worklist + ntiles, opp, ref, mask, tile_part, grad_mvp ? 1 : 0,
+        src, g, verts, counts, offsets, entries, ecap, worklist + ntiles, opp, ref, mask, facc, grad_mvp ? 1 : 0,
         meta, dbg_skip);
     EHR_LAUNCH_CHECK();
     if (overlap) {
@@ -739,13 +700,12 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
         EHR_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
     }
     if (ev) EHR_HIP(hipEventRecord(ev[6], stream));
-    // stage 4: fixed-order reduction
-    dim3 rgrid(L + 1, B);
+    // stage 4: accumulators -> loss / grad_mvp (+ pose backward and Adam in the solver-step form), one workgroup
     if (tail) {
-        fused_reduce_kernel<true><<<rgrid, 256, 0, stream>>>(g, counts, tile_part, loss, grad_mvp, meta, *tail);
+        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail);
     } else {
         StepTail none = {};
-        fused_reduce_kernel<false><<<rgrid, 256, 0, stream>>>(g, counts, tile_part, loss, grad_mvp, meta, none);
+        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none);
     }
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[7], stream));
