@@ -61,7 +61,6 @@ struct BinGeom {
 #define EHR_META_OVERFLOW 1  // sticky overflow flag
 #define EHR_META_NWORK 2     // non-empty tiles appended to the work list
 #define EHR_META_NWORK_SLOW 3  // ... of which tiles that hold a triangle needing the 64-bit / clipping path
-#define EHR_META_TICKET 6     // arrival counter of the merged reduce + pose-backward kernel
 #define EHR_META_INTS 48     // ints reserved for the meta block (8 words + profiling counters)
 
 // A triangle is "slow" when it needs near-plane clipping or spans more than this many sub-pixels: then (and only
@@ -193,14 +192,20 @@ __global__ void __launch_bounds__(256) bin_kernel(ClipSource src, BinGeom g, int
     }
     __syncthreads();
     // phase 2: one global atomic per distinct queue touched by this workgroup
-    for (int i = threadIdx.x; i < EHR_BIN_SLOTS; i += 256) {
-        const int key = hkey[i];
-        if (key >= 0) {
-            const int c = hcnt[i];
-            if (FILL)
-                hcnt[i] = atomicAdd(&cursors[key], c);
-            else
-                atomicAdd(&counts[key], c);
+    if (FILL) {  // returning atomics: issue all of a thread's before consuming any (one round trip, not one per slot)
+        int res[EHR_BIN_SLOTS / 256];
+#pragma unroll
+        for (int k = 0; k < EHR_BIN_SLOTS / 256; k++) {
+            const int i = threadIdx.x + 256 * k;
+            const int key = hkey[i];
+            res[k] = (key >= 0) ? atomicAdd(&cursors[key], hcnt[i]) : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < EHR_BIN_SLOTS / 256; k++) hcnt[threadIdx.x + 256 * k] = res[k];
+    } else {
+        for (int i = threadIdx.x; i < EHR_BIN_SLOTS; i += 256) {
+            const int key = hkey[i];
+            if (key >= 0) atomicAdd(&counts[key], hcnt[i]);
         }
     }
     if (FILL) {
@@ -218,16 +223,34 @@ __global__ void __launch_bounds__(256) bin_kernel(ClipSource src, BinGeom g, int
         }
     }
     // phase 3: the remaining tiles of large triangles, directly
-    for (int c = EHR_BIN_LOCAL; c < ntile; c++) {
-        const int ty = ty0 + c / nx, tx = tx0 + c % nx;
-        const int key = ((b * g.nt) + ty * g.ntx + tx) * g.L + link;
-        if (FILL) {
-            const int at = offsets[key] + atomicAdd(&cursors[key], 1);
-            if (at < entries_cap)
-                entries[at] = make_int4(t, v0, v1, v2);
-            else
-                meta[EHR_META_OVERFLOW] = 1;
-        } else {
+    if (FILL) {  // four tiles per round trip: the slots come back from returning atomics (~3 us each under load),
+                 // and a serial chain of them per large triangle set this kernel's duration
+        for (int c0 = EHR_BIN_LOCAL; c0 < ntile; c0 += 4) {
+            int at[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = c0 + j;
+                at[j] = -1;
+                if (c < ntile) {
+                    const int ty = ty0 + c / nx, tx = tx0 + c % nx;
+                    const int key = ((b * g.nt) + ty * g.ntx + tx) * g.L + link;
+                    at[j] = offsets[key] + atomicAdd(&cursors[key], 1);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (at[j] >= 0) {
+                    if (at[j] < entries_cap)
+                        entries[at[j]] = make_int4(t, v0, v1, v2);
+                    else
+                        meta[EHR_META_OVERFLOW] = 1;
+                }
+            }
+        }
+    } else {
+        for (int c = EHR_BIN_LOCAL; c < ntile; c++) {
+            const int ty = ty0 + c / nx, tx = tx0 + c % nx;
+            const int key = ((b * g.nt) + ty * g.ntx + tx) * g.L + link;
             atomicAdd(&counts[key], 1);
         }
     }
