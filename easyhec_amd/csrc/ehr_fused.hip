@@ -493,15 +493,31 @@ __global__ void __launch_bounds__(256) fused_finish_kernel(BinGeom g, int B, con
         }
     }
     if (TAIL) {
+        // One dependent round trip in total: the optimiser state and the Jacobian are requested up front, the
+        // gradients come straight from the accumulators (the stores above are fire-and-forget), and Adam reads the
+        // 8 reduced floats back from LDS.
         __shared__ double S[256][16];
         __shared__ double lsum[256];
-        __threadfence_block();
-        __syncthreads();  // grad_mvp / loss written above are read back by the whole workgroup
-        pose_backward_block(grad_mvp, loss, tail.K, tail.link_poses, tail.tc_jac, B, L, g.H, g.W, tail.n, tail.f, tail.red, S,
-                            lsum);
+        __shared__ float red_lds[8];
+        AdamState st;
+        if (!tail.defer_adam) st = pose_adam_fetch(tail.dof, tail.m, tail.v, tail.step);
+        pose_backward_block_t(
+            [&](int i, float* G) {
+                const int b = i / L, l = i - b * L;
+                const long long* a = facc + (size_t)b * acc_stride + 12 * l;
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int r = e >> 2, c = e & 3;
+                    float v = 0.f;
+                    if (r != 2) v = fix_get(a[4 * (r == 3 ? 2 : r) + c]);
+                    G[e] = bad ? nanv : v;
+                }
+            },
+            [&](int b) { return bad ? nanv : fix_get(facc[(size_t)b * acc_stride + 12 * L]); }, tail.K, tail.link_poses,
+            tail.tc_jac, B, L, g.H, g.W, tail.n, tail.f, tail.red, S, lsum, red_lds);
         __syncthreads();
         if (!tail.defer_adam)
-            pose_adam_block(tail.dof, tail.m, tail.v, tail.step, tail.red, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,
+            pose_adam_apply(st, tail.dof, tail.m, tail.v, tail.step, red_lds, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,
                             tail.loss_out, tail.grad_out);
     }
 }

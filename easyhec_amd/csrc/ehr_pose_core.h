@@ -171,12 +171,20 @@ __device__ __forceinline__ void mvp_from_pose(const float* Tc, const float* P, c
 }
 
 // d(sum_b loss_b)/d dof, the loss sum and the frame count from d loss_b / d MVP[b,l]; one 256-thread workgroup,
-// fixed-order reductions.  S: LDS double [256][16]; lsum: LDS double [256].
-__device__ __forceinline__ void pose_backward_block(const float* __restrict__ grad_mvp, const float* __restrict__ loss,
-                                                    const float* __restrict__ K, const float* __restrict__ link_poses,
-                                                    const float* __restrict__ tc_jac, int B, int L, int H, int W,
-                                                    float n, float f, float* __restrict__ red, double (*S)[16],
-                                                    double* lsum) {
+// fixed-order reductions.  S: LDS double [256][16]; lsum: LDS double [256].  get_g(i, G) fills the 16 floats of
+// d loss / d MVP for (view, link) pair i, get_loss(b) returns frame b's loss: the standalone kernel reads them from
+// global memory, the fused finish kernel straight from its accumulators (no store -> barrier -> reload round trip).
+// red_lds (optional, LDS float[8]) receives a copy of red for a following pose_adam_block in the same workgroup.
+template <class GetG, class GetLoss>
+__device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_loss, const float* __restrict__ K,
+                                                      const float* __restrict__ link_poses,
+                                                      const float* __restrict__ tc_jac, int B, int L, int H, int W,
+                                                      float n, float f, float* __restrict__ red, double (*S)[16],
+                                                      double* lsum, float* red_lds) {
+    // Jacobian rows are needed last but depend on nothing computed here: fetch them first
+    float J[16];
+    if (threadIdx.x < 6)
+        for (int k = 0; k < 16; k++) J[k] = tc_jac[16 * (threadIdx.x + 1) + k];
     float P[16];
     projection(K, H, W, n, f, P);
     for (int r = 0; r < 4; r++) {  // PF = proj @ opencv2blender
@@ -187,7 +195,8 @@ __device__ __forceinline__ void pose_backward_block(const float* __restrict__ gr
     for (int k = 0; k < 16; k++) acc[k] = 0.0;
     double la = 0.0;
     for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
-        const float* G = grad_mvp + (size_t)i * 16;
+        float G[16];
+        get_g(i, G);
         const float* lp = link_poses + (size_t)i * 16;
         float M[16];  // d/dTc of <G, PF @ Tc @ lp>  =  PF^T @ G @ lp^T
         for (int r = 0; r < 4; r++)
@@ -203,7 +212,7 @@ __device__ __forceinline__ void pose_backward_block(const float* __restrict__ gr
                 acc[4 * r + c] += (double)s;
             }
     }
-    for (int i = threadIdx.x; i < B; i += blockDim.x) la += (double)loss[i];
+    for (int i = threadIdx.x; i < B; i += blockDim.x) la += (double)get_loss(i);
     for (int k = 0; k < 16; k++) S[threadIdx.x][k] = acc[k];
     lsum[threadIdx.x] = la;
     __syncthreads();
@@ -214,32 +223,64 @@ __device__ __forceinline__ void pose_backward_block(const float* __restrict__ gr
         }
         __syncthreads();
     }
-    if (threadIdx.x < 6) {
-        const float* J = tc_jac + 16 * (threadIdx.x + 1);
-        double g = 0.0;
-        for (int k = 0; k < 16; k++) g += S[0][k] * (double)J[k];
-        red[threadIdx.x] = (float)g;
+    if (threadIdx.x < 8) {
+        float r;
+        if (threadIdx.x < 6) {
+            double g = 0.0;
+            for (int k = 0; k < 16; k++) g += S[0][k] * (double)J[k];
+            r = (float)g;
+        } else {
+            r = (threadIdx.x == 6) ? (float)lsum[0] : (float)B;
+        }
+        red[threadIdx.x] = r;
+        if (red_lds) red_lds[threadIdx.x] = r;
     }
-    if (threadIdx.x == 6) red[6] = (float)lsum[0];
-    if (threadIdx.x == 7) red[7] = (float)B;
+}
+
+__device__ __forceinline__ void pose_backward_block(const float* __restrict__ grad_mvp, const float* __restrict__ loss,
+                                                    const float* __restrict__ K, const float* __restrict__ link_poses,
+                                                    const float* __restrict__ tc_jac, int B, int L, int H, int W,
+                                                    float n, float f, float* __restrict__ red, double (*S)[16],
+                                                    double* lsum) {
+    pose_backward_block_t(
+        [&](int i, float* G) {
+            for (int k = 0; k < 16; k++) G[k] = grad_mvp[(size_t)i * 16 + k];
+        },
+        [&](int b) { return loss[b]; }, K, link_poses, tc_jac, B, L, H, W, n, f, red, S, lsum, nullptr);
 }
 
 // torch.optim.Adam with L2 weight decay on dof, gradient of the MEAN per-frame loss = red[0..5] / red[7].
-// Call with >= 7 threads of one workgroup; contains a barrier.
-__device__ __forceinline__ void pose_adam_block(float* __restrict__ dof, float* __restrict__ m, float* __restrict__ v,
-                                                int* __restrict__ step, const float* __restrict__ red, float lr,
+// Call with >= 7 threads of one workgroup; contains a barrier.  `red` may point to LDS (written by this workgroup
+// before a barrier) or to global memory.
+struct AdamState {  // one thread's share of the optimiser state, fetched ahead of use
+    float p, m, v;
+    int t;
+};
+__device__ __forceinline__ AdamState pose_adam_fetch(const float* dof, const float* m, const float* v, const int* step) {
+    AdamState st;
+    st.p = st.m = st.v = 0.f;
+    st.t = step[0] + 1;
+    if (threadIdx.x < 6) {
+        st.p = dof[threadIdx.x];
+        st.m = m[threadIdx.x];
+        st.v = v[threadIdx.x];
+    }
+    return st;
+}
+__device__ __forceinline__ void pose_adam_apply(const AdamState& st, float* __restrict__ dof, float* __restrict__ m,
+                                                float* __restrict__ v, int* __restrict__ step, const float* red, float lr,
                                                 float b1, float b2, float eps, float wd, float* __restrict__ loss_out,
                                                 float* __restrict__ grad_out) {
     const int i = threadIdx.x;
-    const int t = step[0] + 1;
+    const int t = st.t;
     const float nfr = red[7];
     if (i < 6) {
         float g = red[i] / nfr;
         if (grad_out) grad_out[i] = g;
-        float p = dof[i];
+        float p = st.p;
         g = g + wd * p;
-        float mi = b1 * m[i] + (1.f - b1) * g;
-        float vi = b2 * v[i] + (1.f - b2) * g * g;
+        float mi = b1 * st.m + (1.f - b1) * g;
+        float vi = b2 * st.v + (1.f - b2) * g * g;
         m[i] = mi;
         v[i] = vi;
         float bc1 = 1.f - powf(b1, (float)t);
@@ -251,6 +292,13 @@ __device__ __forceinline__ void pose_adam_block(float* __restrict__ dof, float* 
     if (i == 6 && loss_out) loss_out[0] = red[6] / nfr;
     __syncthreads();
     if (i == 0) step[0] = t;
+}
+__device__ __forceinline__ void pose_adam_block(float* __restrict__ dof, float* __restrict__ m, float* __restrict__ v,
+                                                int* __restrict__ step, const float* __restrict__ red, float lr,
+                                                float b1, float b2, float eps, float wd, float* __restrict__ loss_out,
+                                                float* __restrict__ grad_out) {
+    const AdamState st = pose_adam_fetch(dof, m, v, step);
+    pose_adam_apply(st, dof, m, v, step, red, lr, b1, b2, eps, wd, loss_out, grad_out);
 }
 
 }  // namespace ehr
