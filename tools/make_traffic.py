@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"fused_vertex_kernel": "fused_vertex_kernel", "bin_kernel<1, false>": "bin_kernel<count>",
          "bin_alloc_kernel": "bin_alloc_kernel", "bin_kernel<1, true>": "bin_kernel<fill>",
          "fused_empty_kernel": "fused_empty_kernel", "fused_tile_kernel<false>": "fused_tile_kernel<lean>",
-         "fused_tile_kernel<true>": "fused_tile_kernel<slow>", "fused_reduce_kernel": "fused_reduce_kernel"}
+         "fused_tile_kernel<true>": "fused_tile_kernel<slow>", "fused_finish_kernel": "fused_finish_kernel"}
 
 
 def mean_last(path, counter, last=50):
