@@ -245,3 +245,55 @@ def test_franka_config4_full_size(oracle):
     assert np.allclose(loss, ((mask.astype(np.float64) - ref) ** 2).sum(axis=(1, 2)), rtol=1e-6)
     again = run(fused, ctx, scene, mvp, ref, dev)
     assert (again[0] == mask).all() and (again[1] == loss).all() and (again[2] == grad).all()
+
+
+def test_fused_edge_cases(env, oracle, xarm7):
+    """Empty and ragged inputs: nothing in view, a single link / single view, a lone huge triangle that is queued in
+    every tile of the image, sizes that are not multiples of the 32x8 tile, and the largest supported square image."""
+    fused, ctx, scene, dev = env
+    # (1) robot behind the camera: every tile is empty -> loss = sum(ref^2), zero gradient, no NaN
+    H, W, B = 96, 160, 2
+    K, lp, Tc, mvp = workload(xarm7, H, W, 0.125, B, seed=3, perturb=False)
+    back = np.eye(4)
+    back[2, 3] = -6.0                                                 # push the whole scene 6 m behind the camera
+    mvp_behind = helpers.mvp_numpy(K, H, W, back @ Tc, lp)
+    rng = np.random.default_rng(0)
+    ref = (rng.uniform(size=(B, H, W)) > 0.7).astype(np.float32)
+    verts, tris, toff, voff = helpers.scene_arrays(xarm7)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(verts, tris, toff, voff, mvp_behind, ref)
+    mask, loss, grad = run(fused, ctx, scene, mvp_behind, ref, dev)
+    assert (m_ref == 0).all() and (mask == 0).all() and (grad == 0).all() and np.isfinite(loss).all()
+    assert np.allclose(loss, ref.reshape(B, -1).sum(1)) and np.allclose(loss, l_ref)
+    # (2) one link, one view, ragged size
+    v0, f0 = xarm7.meshes[2]
+    sc1 = fused.LinkScene([v0], [f0], dev)
+    H, W = 75, 101
+    K, lp, Tc, mvp = workload(xarm7, H, W, 0.08, 1, seed=5)
+    mvp1 = mvp[:, 2:3].copy()
+    ref = np.zeros((1, H, W), np.float32)
+    toff1, voff1 = np.array([0, f0.shape[0]], np.int32), np.array([0, v0.shape[0]], np.int32)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(v0, f0, toff1, voff1, mvp1, ref)
+    mask, loss, grad = run(fused, ctx, sc1, mvp1, ref, dev)
+    assert (m_ref > 0).sum() > 20 and (mask == m_ref).all()
+    assert np.abs(loss - l_ref).max() <= 1e-6 * np.abs(l_ref).max()
+    assert np.abs(grad - g_ref).max() <= 1e-5 * max(np.abs(g_ref).max(), 1e-30)
+    # (3) one triangle covering the whole image (queued in every tile; partly outside the frustum sideways)
+    vt = np.array([[-30.0, -20.0, 0.0], [30.0, -20.0, 0.0], [0.0, 40.0, 0.0]], np.float32)
+    ft = np.array([[0, 1, 2]], np.int32)
+    sct = fused.LinkScene([vt], [ft], dev)
+    H, W = 200, 328
+    P = helpers.projection(np.array([[150.0, 0, W / 2], [0, 150.0, H / 2], [0, 0, 1]]), H, W)
+    pose = np.eye(4)
+    pose[2, 3] = 3.0
+    mvpt = (P @ np.diag([1.0, -1.0, -1.0, 1.0]) @ pose).astype(np.float32)[None, None]
+    ref = np.ones((1, H, W), np.float32)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(vt, ft, np.array([0, 1], np.int32), np.array([0, 3], np.int32), mvpt, ref)
+    mask, loss, grad = run(fused, ctx, sct, mvpt, ref, dev)
+    assert (m_ref == 1).all() and (mask == 1).all() and (loss == 0).all() and (l_ref == 0).all()
+    # (4) the largest square image of the documented range (2048 x 2048), one view of the whole robot
+    H = W = 2048
+    K, lp, Tc, mvp = workload(xarm7, H, W, 1.6, 1, seed=9)
+    ref = np.zeros((1, H, W), np.float32)
+    mask, loss, grad = run(fused, ctx, scene, mvp, ref, dev)
+    assert np.isfinite(loss).all() and np.isfinite(grad).all() and 0.01 < (mask > 0.5).mean() < 0.6
+    assert abs(float(loss[0]) - float((mask.astype(np.float64) ** 2).sum())) <= 1e-6 * float(loss[0])

@@ -195,3 +195,29 @@ def test_mask_variance_golden_fixture(env):
     _, score, counts = se.mask_variance(ctx, scene, torch.tensor(g["mvp"], device=dev), int(g["H"]), int(g["W"]),
                                         return_counts=True)
     assert (score.cpu().numpy() == g["score"]).all() and (counts.cpu().numpy() == g["counts"]).all()
+
+
+def test_mask_variance_edge_cases(env, oracle, xarm7):
+    """Argument validation at the C ABI, a single candidate, the maximum number of poses, nothing in view."""
+    se, ctx, scene, dev = env
+    H, W = 64, 96
+    mvp = torch.tensor(candidate_mvps(xarm7, H, W, 0.07, 1, 2, seed=1), device=dev)
+    with pytest.raises(RuntimeError, match="S must be in"):
+        se.mask_variance(ctx, scene, mvp[:, :1].expand(-1, 256, -1, -1, -1).contiguous(), H, W)
+    with pytest.raises(ValueError):
+        se.mask_variance(ctx, scene, mvp[:, :, :3], H, W)               # wrong number of links
+    with pytest.raises(RuntimeError):
+        se.mask_variance(ctx, scene, mvp.cpu(), H, W)                    # no CPU path
+    # S = 255 (the 8-bit count limit): 255 copies of two alternating poses -> c in {0, 127, 128, 255}
+    big = mvp[:, [0, 1] * 127 + [0]].contiguous()
+    _, score, counts = se.mask_variance(ctx, scene, big, H, W, return_counts=True, chunk_views=64)
+    _, _, ca = se.mask_variance(ctx, scene, mvp[:, :1], H, W, return_counts=True)
+    _, _, cb = se.mask_variance(ctx, scene, mvp[:, 1:], H, W, return_counts=True)
+    expect = 128 * ca.long() + 127 * cb.long()
+    assert (counts.long() == expect).all()
+    assert int(score[0]) == int((expect * (255 - expect)).sum())
+    # nothing in view: all-zero counts and score, no error
+    far = mvp.clone()
+    far[..., 3, :] *= -1.0                                               # w < 0 for every vertex
+    _, s0, c0 = se.mask_variance(ctx, scene, far, H, W, return_counts=True)
+    assert int(s0.abs().sum()) == 0 and int(c0.sum()) == 0
