@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="reference-shaped torch autograd step instead of the HIP launch chain")
     ap.add_argument("--workload", default=WORKLOAD, help="side measurements only; the headline is the default")
-    ap.add_argument("--graph", action="store_true", help="replay the launch chain as a captured hipGraph (experimental)")
+    ap.add_argument("--graph", action="store_true", help="replay the launch chain as a natively captured hipGraph (saves host time only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

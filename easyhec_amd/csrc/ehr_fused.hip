@@ -807,6 +807,59 @@ int ehr_fused_status(ehr_ctx* ctx) {
     return EHR_OK;
 }
 
+// ---- hipGraph capture of library launch chains ------------------------------------------------------------------
+
+int ehr_graph_begin(ehr_ctx* ctx, void** capture_stream) {
+    if (!ctx || !capture_stream) return fail(EHR_ERR_INVALID, "ehr_graph_begin: NULL argument");
+    if (ctx->capturing) return fail(EHR_ERR_INVALID, "ehr_graph_begin: a capture is already open on this context");
+    if (ctx->timing) return fail(EHR_ERR_INVALID, "ehr_graph_begin: disable ehr_fused_timing first");
+    if (!ctx->cap_stream) EHR_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+    if (ctx->gexec) {
+        EHR_HIP(hipGraphExecDestroy(ctx->gexec));
+        ctx->gexec = nullptr;
+    }
+    EHR_HIP(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    *capture_stream = (void*)ctx->cap_stream;
+    return EHR_OK;
+}
+
+int ehr_graph_end(ehr_ctx* ctx) {
+    if (!ctx || !ctx->capturing) return fail(EHR_ERR_INVALID, "ehr_graph_end: no open capture");
+    ctx->capturing = false;
+    hipGraph_t graph = nullptr;
+    EHR_HIP(hipStreamEndCapture(ctx->cap_stream, &graph));
+    if (!graph) return fail(EHR_ERR_HIP, "ehr_graph_end: the capture was invalidated");
+    hipError_t e = hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        ctx->gexec = nullptr;
+        return fail(EHR_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    return EHR_OK;
+}
+
+int ehr_graph_launch(ehr_ctx* ctx, void* stream) {
+    if (!ctx || !ctx->gexec) return fail(EHR_ERR_INVALID, "ehr_graph_launch: no instantiated graph");
+    EHR_HIP(hipGraphLaunch(ctx->gexec, (hipStream_t)stream));
+    return EHR_OK;
+}
+
+int ehr_graph_release(ehr_ctx* ctx) {
+    if (!ctx) return EHR_OK;
+    if (ctx->capturing) {
+        hipGraph_t graph = nullptr;
+        (void)hipStreamEndCapture(ctx->cap_stream, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        ctx->capturing = false;
+    }
+    if (ctx->gexec) {
+        EHR_HIP(hipGraphExecDestroy(ctx->gexec));
+        ctx->gexec = nullptr;
+    }
+    return EHR_OK;
+}
+
 int ehr_fused_timing(ehr_ctx* ctx, int enable) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_fused_timing: ctx is NULL");
     ctx->timing = enable != 0;

@@ -59,6 +59,10 @@ struct ehr_ctx {
     // side stream: the empty-tile streaming kernel overlaps the queue fill + tile kernels
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fill = nullptr;
+    // natively captured launch chain (ehr_graph_*): capture stream and the instantiated graph
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool capturing = false;
     // measurement hook (ehr_fused_timing): EHR_FUSED_STAGES + 1 events per recorded call
     bool timing = false;
     std::vector<hipEvent_t> ev;

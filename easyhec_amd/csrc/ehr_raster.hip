@@ -229,6 +229,8 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_fill) (void)hipEventDestroy(c->ev_fill);
+    if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     if (c->side) (void)hipStreamDestroy(c->side);
     (void)hipSetDevice(cur);
     delete c;

@@ -55,9 +55,10 @@ class FusedPoseStep:
         self._graph = None
 
     # -- one step -------------------------------------------------------------------------------------------------
-    def _enqueue(self, want_mask):
+    def _enqueue(self, want_mask, stream=None):
         lib = _lib.lib()
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if stream is None:
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         m, sc = self.model, self.scene
         dof = m.dof.data
         hist = m.history_ops
@@ -83,31 +84,40 @@ class FusedPoseStep:
         """Enqueue one optimisation step.  Returns the (device, 1-element) mean mask loss evaluated BEFORE the update,
         like ``loss`` in trainer/rbsolver.py:33-41.  Never synchronises."""
         with torch.cuda.device(self.dev):
-            if self._graph is not None and not want_mask:
-                self._graph.replay()
+            if self._graph and not want_mask:
+                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                _lib.check(_lib.lib().ehr_graph_launch(self.glctx.handle, stream), "ehr_graph_launch")
             else:
                 self._enqueue(want_mask)
         return self.loss
 
     def capture(self):
-        """EXPERIMENTAL: capture the step into a hipGraph (torch.cuda.CUDAGraph) so that a replay costs one launch on
-        the host.  The chain is GPU-bound, so this buys nothing measurable today, and with several rasterizer contexts
-        alive in one process a replay has produced GPU memory faults on ROCm 7.2 (open issues) -- keep it
-        off unless the process owns a single context.  Not available with data parallelism."""
-        if self._graph is not None:
+        """Record the step's launch chain (7 kernels on the main stream, 2 on the side stream, their fork/join events)
+        into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
+        with one host call.  Iteration state lives on the device, so replays are ordinary optimisation steps.  The
+        chain is GPU-bound, so this saves host time, not step time.  Single-process only: the data-parallel step has a
+        collective between the chain and Adam."""
+        if self._graph:
             return
-        s = torch.cuda.Stream(device=self.dev)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                self._enqueue(False)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        # undo the two warm-up updates? No: they are ordinary optimisation steps (state stays consistent).
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._enqueue(False)
-        self._graph = g
+        if self.distributed:
+            raise RuntimeError("capture(): not available with data parallelism")
+        lib = _lib.lib()
+        with torch.cuda.device(self.dev):
+            torch.cuda.synchronize()
+            cap = ctypes.c_void_p()
+            _lib.check(lib.ehr_graph_begin(self.glctx.handle, ctypes.byref(cap)), "ehr_graph_begin")
+            try:
+                self._enqueue(False, stream=cap)
+            except Exception:
+                lib.ehr_graph_release(self.glctx.handle)
+                raise
+            _lib.check(lib.ehr_graph_end(self.glctx.handle), "ehr_graph_end")
+        self._graph = True
+
+    def release_graph(self):
+        if self._graph:
+            _lib.check(_lib.lib().ehr_graph_release(self.glctx.handle), "ehr_graph_release")
+            self._graph = None
 
     @property
     def steps_done(self):

@@ -145,6 +145,18 @@ int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                     float* loss_b, float* grad_mvp, float* red, float* loss_out, float* grad_out, int defer_adam,
                     void* stream);
 
+/* hipGraph capture of launch chains.  ehr_graph_begin opens a capture on a stream the context owns and returns it; every
+ * library call made with THAT stream until ehr_graph_end (e.g. one ehr_solver_step, or ehr_solver_step with defer_adam
+ * followed by ehr_pose_adam) is recorded instead of executed, including the chain's side-stream fork/join.  All device
+ * pointers and scalars of the recorded calls are baked in: the buffers must stay alive and in place; iteration state
+ * (dof, Adam moments, step counter, history row) lives on the device, so replays advance the optimisation exactly like
+ * eager calls.  ehr_graph_launch enqueues one replay on `stream`.  One graph per context; ehr_graph_begin discards the
+ * previous one.  The plan (ehr_fused_plan) must not change between capture and replay. */
+int ehr_graph_begin(ehr_ctx* ctx, void** capture_stream);
+int ehr_graph_end(ehr_ctx* ctx);
+int ehr_graph_launch(ehr_ctx* ctx, void* stream);
+int ehr_graph_release(ehr_ctx* ctx);
+
 /* Next-best-view scoring of the space explorer (modeling/models/rb_solve/space_explorer.py:152-165): for each of Q
  * candidate joint configurations, the robot (all links merged into one mesh, utils/render_api.py:70-96) is rendered
  * WITHOUT antialiasing under S camera poses (mask = rast[..., 2] > 0, structures/nvdiffrast_renderer.py:70) and the

@@ -118,3 +118,36 @@ def test_merged_step_equals_the_separate_kernels(xarm7):
             assert torch.equal(getattr(fa, name), getattr(fb, name)), (it, name)
         assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(ma.history_ops[:8], mb.history_ops[:8])
     fused.check_status(fa.glctx)
+
+
+def test_graph_replay_equals_eager_launches(xarm7):
+    """The step captured as a hipGraph by the library (ehr_graph_begin / _end / _launch: main-stream chain + the
+    side-stream kernels and their fork/join events) replays to the same bits as eager launches, with several
+    rasterizer contexts alive in the process and interleaved with eager work on another context."""
+    from easyhec_amd import fused
+    from easyhec_amd.fast import FusedPoseStep
+    cfg, make, batch = problem(xarm7, 3, 240, 320, 0.25)
+    ma, mb, mc = make(), make(), make()
+    fa, fb, fc = FusedPoseStep(ma, batch), FusedPoseStep(mb, batch), FusedPoseStep(mc, batch)
+    fb.capture()
+    for it in range(25):
+        fa.step()
+        fb.step()                      # one ehr_graph_launch
+        if it % 5 == 0:
+            fc.step()                  # unrelated eager work on a third context in between
+    torch.cuda.synchronize()
+    for name in ["mvp", "tc_jac", "loss_b", "grad_mvp", "red", "loss", "grad", "exp_avg", "exp_avg_sq", "step_t"]:
+        assert torch.equal(getattr(fa, name), getattr(fb, name)), name
+    assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(ma.history_ops[:30], mb.history_ops[:30])
+    assert int(fb.step_t.item()) == 25
+    fused.check_status(fb.glctx)
+    # a step that wants the mask falls back to eager launches and keeps the trajectory
+    fa.step(want_mask=True)
+    fb.step(want_mask=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(fa.mask, fb.mask)
+    fb.release_graph()
+    fa.step()
+    fb.step()
+    torch.cuda.synchronize()
+    assert torch.equal(ma.dof.data, mb.dof.data)
