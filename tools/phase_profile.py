@@ -12,12 +12,13 @@ dev = torch.device("cuda:0")
 rb = load_robot("xarm7")
 wl = WORKLOADS["xarm7_1280x720_8view"]
 H, W, K = wl["H"], wl["W"], wl["K"]
-_, lp = make_views(rb, 8)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+_, lp = make_views(rb, B)
 Tc = camera_Tc_c2b(radius=wl["radius"], lift=wl["lift"])
 mvp = torch.tensor(helpers.mvp_numpy(K, H, W, perturb_pose(Tc), lp), device=dev, requires_grad=True)
 ctx = dr.RasterizeCudaContext()
 scene = fused.LinkScene([v for v, _ in rb.meshes], [f for _, f in rb.meshes], dev)
-ref = torch.zeros((8, H, W), device=dev)
+ref = torch.zeros((B, H, W), device=dev)
 for _ in range(3):
     fused.render_mask_loss(ctx, scene, mvp, ref)
 fused.check_status(ctx)   # prints + resets the phase counters in a -DEHR_PHASE_TIMING build
