@@ -165,3 +165,33 @@ def test_reference_franka_offline_example_converges(tmp_path):
         tinted = (img[..., 0] - img[..., 2]) > 40              # red overlay on the grey frame
         ious.append((tinted & masks[i]).sum() / (tinted | masks[i]).sum())
     assert np.mean(ious) > 0.6, ious
+
+
+def test_online_loop_solver_plus_explorer(xarm7):
+    """The reference's outer loop (trainer/rbsolve_iter.py:157-167) with simulated hardware: every round adds the frame
+    the space explorer asked for, re-solves from the configured initial pose over all frames, and scores the next
+    candidates from that round's pose history.  More frames must not hurt, and the pose must end within 1 mm / 0.1 deg."""
+    from easyhec_amd import render_api
+    from easyhec_amd.config import XARM7_K_1280x720
+    from easyhec_amd.online import OnlineCalibration
+    from easyhec_amd.synthetic import camera_Tc_c2b, perturb_pose
+    H, W = 360, 640
+    K = np.array(XARM7_K_1280x720, dtype=np.float64)
+    K[:2] *= 0.5
+    Tc_gt = camera_Tc_c2b()
+    init = perturb_pose(Tc_gt, dt=(0.03, -0.02, 0.03), drot_deg=(4.0, -3.0, 3.0))
+    rng = np.random.default_rng(1)
+    asked = []
+
+    def capture(qpos):
+        asked.append(np.array(qpos))
+        return render_api.nvdiffrast_render_xarm_api(None, Tc_gt, qpos, H, W, K)
+
+    loop = OnlineCalibration(xarm7, K, H, W, init, capture, lambda r: (xarm7.sample_qpos(200, rng, scale=0.9), None),
+                             num_epochs=600, explore_iters=4, sample=8, start=100)
+    Tc = loop.fit(np.zeros(7))
+    assert [r["frames"] for r in loop.log] == [1, 2, 3, 4] and len(asked) == 4
+    assert all(r["variance"] > 0 and r["variance"] >= r["var_mean"] for r in loop.log[:-1])
+    assert len({tuple(np.round(q, 6)) for q in asked}) == 4          # the explorer moved the robot every round
+    emm, edeg = pose_error(Tc_gt, Tc)
+    assert emm <= 1.0 and edeg <= 0.1, (emm, edeg)
