@@ -111,6 +111,34 @@ class UrdfChain:
             poses[l] = T
         return poses
 
+    def link_poses_batch(self, qposes, link_indices):
+        """[N, len(link_indices), 4, 4] float64 for N joint vectors at once (same arithmetic as
+        :meth:`compute_forward_kinematics`, vectorised over the batch: the space explorer needs FK of ~1000 candidate
+        configurations per round, space_explorer.py:98-150)."""
+        Q = np.atleast_2d(np.asarray(qposes, dtype=np.float64))
+        N = Q.shape[0]
+        q = np.zeros((N, self.dof))
+        q[:, :min(self.dof, Q.shape[1])] = Q[:, :self.dof]
+        col = {id(j): i for i, j in enumerate(self.active)}
+        eye = np.broadcast_to(np.eye(4), (N, 4, 4))
+        poses = {self.root: eye}
+        for l in self.link_order[1:]:
+            j = self._joint_of_child[l]
+            T = poses[j["parent"]] @ j["origin"]
+            if j["type"] in ("revolute", "continuous"):
+                a = j["axis"] / (np.linalg.norm(j["axis"]) + 1e-30)
+                Kx = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+                ang = q[:, col[id(j)]]
+                R = np.tile(np.eye(4), (N, 1, 1))
+                R[:, :3, :3] = np.eye(3) + np.sin(ang)[:, None, None] * Kx + (1 - np.cos(ang))[:, None, None] * (Kx @ Kx)
+                T = T @ R
+            elif j["type"] == "prismatic":
+                P = np.tile(np.eye(4), (N, 1, 1))
+                P[:, :3, 3] = (j["axis"] / (np.linalg.norm(j["axis"]) + 1e-30))[None] * q[:, col[id(j)], None]
+                T = T @ P
+            poses[l] = T
+        return np.stack([poses[self.link_order[i]] for i in link_indices], axis=1).astype(np.float64)
+
     def link_poses(self, qpos, link_indices):
         """[len(link_indices),4,4] poses for SAPIEN-style link indices (``use_links`` in the reference configs)."""
         poses = self.compute_forward_kinematics(qpos)

@@ -79,7 +79,7 @@ class SpaceExplorer:
 
     def link_poses(self, qposes):
         """FK of every candidate: [Q,L,4,4] base<-link (sapien_kin.py:26-30 through the URDF chain)."""
-        return torch.as_tensor(np.stack([self.robot.link_poses(q) for q in np.asarray(qposes)]), dtype=torch.float32)
+        return torch.as_tensor(self.robot.link_poses_batch(np.asarray(qposes)), dtype=torch.float32)
 
     def mvp(self, Tc_c2b, link_poses):
         """[Q,S,L,4,4] = proj(K) @ opencv2blender @ Tc_c2b[s] @ link_poses[q,l]."""

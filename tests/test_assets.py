@@ -122,3 +122,14 @@ def test_franka_collada_meshes_stay_nearly_unmerged():
     assert 2.5 * fr.num_tris < fr.num_verts <= 3 * fr.num_tris
     xa = load_robot("xarm7")
     assert xa.num_verts < 0.6 * xa.num_tris            # STL: merged by position
+
+
+def test_batched_fk_equals_per_configuration_fk(xarm7):
+    """Vectorised FK (space explorer: ~1000 candidate configurations per round) against the per-configuration chain."""
+    from easyhec_amd.robot import load_robot
+    for robot in (xarm7, load_robot("franka")):
+        q = robot.sample_qpos(50, np.random.default_rng(3), scale=1.0)
+        a = np.stack([robot.link_poses(x) for x in q])
+        b = robot.link_poses_batch(q)
+        assert a.shape == b.shape == (50, robot.num_links, 4, 4) and np.abs(a - b).max() <= 1e-12
+        assert np.abs(robot.link_poses_batch(q[:1, :3])[0] - robot.link_poses(q[0, :3])).max() <= 1e-12  # zero padding
