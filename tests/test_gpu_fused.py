@@ -179,7 +179,7 @@ def test_full_size_properties(env, xarm7):
     assert np.abs(np.minimum(s, 1.0) - mask[:2])[ok].max() <= 2.4e-7
 
 
-def test_overflow_is_reported_not_silent(env):
+def test_overflow_is_reported_not_silent(env, xarm7):
     """More blended pairs in one tile than its LDS list holds (a pathological checkerboard of pixel-sized quads in
     every one of 10 links): the loss becomes NaN and the status call raises -- never a silently wrong gradient."""
     fused, _, _, dev = env
@@ -213,6 +213,29 @@ def test_overflow_is_reported_not_silent(env):
                                     torch.zeros((1, H, W), device=dev))
     assert torch.isfinite(l2).all() and float(m2.max()) <= 1.0
     fused.check_status(ctx3)
+    # the fixed-point accumulators saturate loudly too: the robot scaled by 1e9 (and the clip matrices' first three
+    # columns by 1e-9) renders the same picture, but its gradients w.r.t. the matrix entries exceed the representable
+    # +-2^31 -> NaN gradient + raised status, never a wrapped sum
+    Hs, Ws = 120, 160
+    K, lp, Tc, mvp_s = workload(xarm7, Hs, Ws, 0.125, 1, seed=2)
+    normal = fused.LinkScene([v for v, _ in xarm7.meshes], [f for _, f in xarm7.meshes], dev)
+    big = fused.LinkScene([v * 1e9 for v, _ in xarm7.meshes], [f for _, f in xarm7.meshes], dev)
+    scale = np.diag([1e-9, 1e-9, 1e-9, 1.0]).astype(np.float32)
+    ref = torch.zeros((1, Hs, Ws), device=dev)
+    ctx4, ctx5 = dr.RasterizeCudaContext(), dr.RasterizeCudaContext()
+    t_n = torch.tensor(mvp_s, device=dev, requires_grad=True)
+    t_b = torch.tensor(mvp_s @ scale, device=dev, requires_grad=True)
+    m_n, l_n = fused.render_mask_loss(ctx4, normal, t_n, ref)
+    m_b, l_b = fused.render_mask_loss(ctx5, big, t_b, ref)
+    l_n.sum().backward()
+    l_b.sum().backward()
+    torch.cuda.synchronize()
+    assert (m_n > 0).sum() > 100 and (m_b - m_n).abs().max() <= 1e-3   # same picture (up to the rescaling's rounding)
+    assert torch.isfinite(t_n.grad).all() and float(t_n.grad.abs().max()) > 0
+    assert torch.isnan(t_b.grad).all()
+    fused.check_status(ctx4)
+    with pytest.raises(RuntimeError, match="overflow"):
+        fused.check_status(ctx5)
 
 
 def test_franka_config4_full_size(oracle):
