@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) interp_grad_kernel(const float* __restric
                 float d = dy[pix * A + k];
                 float a0 = attr[aoff + (size_t)v0 * A + k], a1 = attr[aoff + (size_t)v1 * A + k],
                       a2 = attr[aoff + (size_t)v2 * A + k];
-                if (d != 0.f) {
+                if (grad_attr && d != 0.f) {  // grad_attr == NULL: the attributes are constants (EasyHeC's all-ones colours)
                     atomicAdd(&grad_attr[aoff + (size_t)v0 * A + k], b0 * d);
                     atomicAdd(&grad_attr[aoff + (size_t)v1 * A + k], b1 * d);
                     atomicAdd(&grad_attr[aoff + (size_t)v2 * A + k], b2 * d);
@@ -312,7 +312,7 @@ int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri
 
 int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba, int V,
                          int T, int A, int H, int W, float* grad_attr, float* grad_rast, void* stream_) {
-    if (!attr || !rast || !tri || !dy || !grad_attr || !grad_rast)
+    if (!attr || !rast || !tri || !dy || !grad_rast)
         return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: NULL tensor");
     if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: attr batch %d must be 1 or %d", Ba, B);
     size_t P = (size_t)H * W, n = P * B;

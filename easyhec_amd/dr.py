@@ -151,7 +151,9 @@ class _InterpolateFunc(torch.autograd.Function):
         attr, rast, tri = ctx.saved_tensors
         B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
         Ba, V, A = attr.shape
-        g_attr = torch.zeros_like(attr)
+        # EasyHeC interpolates constant all-ones colours (nvdiffrast_renderer.py:41-42): no attribute gradient is
+        # wanted, so neither the zero-fill nor the per-pixel atomics are paid
+        g_attr = torch.zeros_like(attr) if ctx.needs_input_grad[0] else None
         g_rast = torch.empty_like(rast)
         dy = dy.contiguous()
         with torch.cuda.device(rast.device):

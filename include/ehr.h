@@ -61,7 +61,8 @@ int ehr_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, 
 /* replaces dr.interpolate -- nvdiffrast_renderer.py:42.  attr [Ba,V,A] with Ba == B or 1; out [B,H,W,A]. */
 int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int B, int Ba, int V, int T, int A,
                         int H, int W, float* out, void* stream);
-/* grad_attr [Ba,V,A] is ACCUMULATED into (caller zero-fills); grad_rast [B,H,W,4] is overwritten. */
+/* grad_attr [Ba,V,A] is ACCUMULATED into (caller zero-fills) and may be NULL when the attributes need no gradient
+ * (EasyHeC interpolates constant colours); grad_rast [B,H,W,4] is overwritten. */
 int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba, int V,
                          int T, int A, int H, int W, float* grad_attr, float* grad_rast, void* stream);
 
