@@ -32,7 +32,8 @@ SIGNATURES = {
                                   c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ehr_antialias_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "ehr_fused_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float]),
+    "ehr_fused_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
     "ehr_render_mask_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),

@@ -16,9 +16,7 @@
 
 #include <algorithm>
 
-#include "ehr_host.h"
-#include "ehr_pose_core.h"
-#include "ehr_raster_core.h"
+#include "ehr_fused_core.h"
 
 namespace ehr {
 
@@ -37,20 +35,6 @@ struct Item {
     int v1, v2;  // the two vertices of the crossing silhouette edge (global ids)
     float alpha;
 };
-
-// Per-view sums (frame loss, 12 gradient numbers per link) are accumulated in 64-bit FIXED POINT with integer atomics:
-// integer addition is associative, so the result does not depend on which workgroup adds first -- bit-reproducible like
-// a fixed-order reduction, but without a reduction pass over all tiles.  Scale 2^32: addends are rounded to 2.3e-10
-// (absolute), sums up to +-2.1e9 fit; larger magnitudes raise the overflow flag (loss = NaN), never wrap silently.
-#define EHR_FIX_SCALE 4294967296.0
-__device__ __forceinline__ void fix_add(long long* acc, float v, int* meta) {
-    if (!(fabsf(v) < 1.0e9f)) {  // also catches NaN
-        meta[EHR_META_OVERFLOW] = 1;
-        return;
-    }
-    if (v != 0.f) atomicAdd((unsigned long long*)acc, (unsigned long long)__double2ll_rn((double)v * EHR_FIX_SCALE));
-}
-__device__ __forceinline__ float fix_get(long long q) { return (float)((double)q * (1.0 / EHR_FIX_SCALE)); }
 
 // clip-space vertices of every (view, vertex): posc[b][v] = MVP[b, vert_link[v]] * [x, y, z, 1]
 // (easyhec/utils/nvdiffrast_utils.py:14-18 for all links of a view at once)
@@ -456,94 +440,33 @@ fused_tile_kernel(ClipSource src, BinGeom g, const float* __restrict__ verts, co
     }
 }
 
-// Last stage, ONE workgroup: fixed-point accumulators -> loss[B] and grad_mvp[B,L,16]; with TAIL also the rest of a
-// solver step (d sum(loss) / d dof = the 8 floats a data-parallel job all-reduces, then Adam unless deferred).
-struct StepTail {  // what the solver-step form needs (all device pointers)
-    const float* K;
-    const float* link_poses;
-    const float* tc_jac;
-    float* red;
-    float* dof;
-    float* m;
-    float* v;
-    int* step;
-    float* loss_out;
-    float* grad_out;
-    float n, f, lr, b1, b2, eps, wd;
-    int defer_adam;
-};
-
-template <bool TAIL>
-__global__ void __launch_bounds__(256) fused_finish_kernel(BinGeom g, int B, const long long* __restrict__ facc,
-                                                           float* __restrict__ loss, float* __restrict__ grad_mvp,
-                                                           const int* __restrict__ meta, StepTail tail) {
-    const int tid = threadIdx.x, L = g.L;
-    const int acc_stride = 12 * L + 1;
-    const bool bad = meta[EHR_META_OVERFLOW] != 0;  // overflow => NaN, never a silently wrong loss
-    const float nanv = __int_as_float(0x7fc00000);
-    for (int i = tid; i < B; i += 256) loss[i] = bad ? nanv : fix_get(facc[(size_t)i * acc_stride + 12 * L]);
-    if (grad_mvp) {
-        for (int i = tid; i < B * L * 16; i += 256) {
-            // rows x, y, w of the 4x4 gradient; the z row never receives gradient on this path
-            const int bl = i >> 4, e = i & 15, r = e >> 2, c = e & 3;
-            const int b = bl / L, l = bl - b * L;
-            float v = 0.f;
-            if (r != 2) v = fix_get(facc[(size_t)b * acc_stride + 12 * l + 4 * (r == 3 ? 2 : r) + c]);
-            grad_mvp[i] = bad ? nanv : v;
-        }
-    }
-    if (TAIL) {
-        // One dependent round trip in total: the optimiser state and the Jacobian are requested up front, the
-        // gradients come straight from the accumulators (the stores above are fire-and-forget), and Adam reads the
-        // 8 reduced floats back from LDS.
-        __shared__ double S[256][16];
-        __shared__ double lsum[256];
-        __shared__ float red_lds[8];
-        AdamState st;
-        if (!tail.defer_adam) st = pose_adam_fetch(tail.dof, tail.m, tail.v, tail.step);
-        pose_backward_block_t(
-            [&](int i, float* G) {
-                const int b = i / L, l = i - b * L;
-                const long long* a = facc + (size_t)b * acc_stride + 12 * l;
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int r = e >> 2, c = e & 3;
-                    float v = 0.f;
-                    if (r != 2) v = fix_get(a[4 * (r == 3 ? 2 : r) + c]);
-                    G[e] = bad ? nanv : v;
-                }
-            },
-            [&](int b) { return bad ? nanv : fix_get(facc[(size_t)b * acc_stride + 12 * L]); }, tail.K, tail.link_poses,
-            tail.tc_jac, B, L, g.H, g.W, tail.n, tail.f, tail.red, S, lsum, red_lds);
-        __syncthreads();
-        if (!tail.defer_adam)
-            pose_adam_apply(st, tail.dof, tail.m, tail.v, tail.step, red_lds, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,
-                            tail.loss_out, tail.grad_out);
-    }
-}
-
 }  // namespace ehr
 
 using namespace ehr;
 
 extern "C" {
 
-static BinGeom make_geom(int H, int W, int L) {
-    BinGeom g;
-    g.W = W;
-    g.H = H;
-    g.ntx = (W + EHR_TILE_W - 1) / EHR_TILE_W;
-    g.nty = (H + EHR_TILE_H - 1) / EHR_TILE_H;
-    g.nt = g.ntx * g.nty;
-    g.L = L;
-    return g;
-}
-
-int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack) {
+int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
+                   const int32_t* tris, const int32_t* tri_link, const int32_t* opp) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_fused_plan: ctx is NULL");
     if (B <= 0 || L <= 0 || L > MAX_LINKS || V < 0 || T < 0 || H <= 0 || W <= 0 || H > 32768 || W > 32768)
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: bad sizes (1 <= L <= %d)", MAX_LINKS);
     if (!(slack >= 1.f)) slack = 4.f;
+    if (ctx->gexec) {  // a captured chain holds the old plan's pointers and shape
+        EHR_HIP(hipGraphExecDestroy(ctx->gexec));
+        ctx->gexec = nullptr;
+    }
+    if (ctx->path_vbuf) {
+        int rc0 = vbuf_plan(ctx, B, L, V, T, H, W, slack, verts, tris, tri_link, opp);
+        if (rc0) return rc0;
+        ctx->pB = B;
+        ctx->pL = L;
+        ctx->pV = V;
+        ctx->pT = T;
+        ctx->pH = H;
+        ctx->pW = W;
+        return EHR_OK;
+    }
     BinGeom g = make_geom(H, W, L);
     size_t nkeys = (size_t)B * g.nt * L;
     if (nkeys > 0x3fffffff) return fail(EHR_ERR_INVALID, "ehr_fused_plan: too many (view, tile, link) queues");
@@ -580,17 +503,6 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     return EHR_OK;
 }
 
-struct StepHead {  // inputs of the merged first stage (pose forward inside the vertex kernel)
-    const float* dof;
-    const float* K;
-    const float* link_poses;
-    float* tc_jac;
-    const int* step;
-    float* history;
-    int history_rows;
-    float n, f;
-};
-
 // The launch chain of the fused op.  head/tail == nullptr: generic form (mvp given, stops at loss / grad_mvp).
 // head/tail != nullptr: solver-step form (pose forward merged into the vertex kernel, pose backward (+ Adam) merged into
 // the reduction): 7 launches instead of 12.
@@ -604,6 +516,9 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     if (ctx->pB != B || ctx->pL != L || ctx->pV != V || ctx->pT != T || ctx->pH != H || ctx->pW != W)
         return fail(EHR_ERR_INVALID, "fused op: shape differs from the planned one; call ehr_fused_plan first");
     hipStream_t stream = (hipStream_t)stream_;
+    if (ctx->path_vbuf)
+        return vbuf_chain(ctx, verts, tris, tri_link, vert_link, opp, mvp, ref, B, L, V, T, H, W, mask, loss, grad_mvp,
+                          head, tail, stream);
     BinGeom g = make_geom(H, W, L);
     const int ntiles = B * g.nt;
     const int nkeys = ntiles * L;
@@ -718,10 +633,10 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     if (ev) EHR_HIP(hipEventRecord(ev[6], stream));
     // stage 4: accumulators -> loss / grad_mvp (+ pose backward and Adam in the solver-step form), one workgroup
     if (tail) {
-        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail);
+        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail, 1, nullptr);
     } else {
         StepTail none = {};
-        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none);
+        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none, 1, nullptr);
     }
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[7], stream));
@@ -779,7 +694,18 @@ int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
 
 int ehr_fused_status(ehr_ctx* ctx) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_fused_status: ctx is NULL");
-    if (!ctx->counts.ptr || ctx->pB == 0) return EHR_OK;
+    if (ctx->pB == 0) return EHR_OK;
+    if (ctx->path_vbuf) {
+        if (!ctx->vb_acc.ptr) return EHR_OK;
+        EHR_HIP(hipDeviceSynchronize());
+        int m4[4] = {0, 0, 0, 0};
+        int rc0 = vbuf_meta_read(ctx, m4);
+        if (rc0) return rc0;
+        if (m4[EHR_META_OVERFLOW])
+            return fail(EHR_ERR_OVERFLOW, "fused path: an accumulator or the blended-pair spill pool overflowed");
+        return EHR_OK;
+    }
+    if (!ctx->counts.ptr) return EHR_OK;
     EHR_HIP(hipDeviceSynchronize());
     BinGeom g = make_geom(ctx->pH, ctx->pW, ctx->pL);
     const size_t nkeys = (size_t)ctx->pB * g.nt * ctx->pL;
@@ -836,11 +762,14 @@ int ehr_graph_end(ehr_ctx* ctx) {
         ctx->gexec = nullptr;
         return fail(EHR_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
     }
+    ctx->gexec_reallocs = Scratch::reallocs;
     return EHR_OK;
 }
 
 int ehr_graph_launch(ehr_ctx* ctx, void* stream) {
     if (!ctx || !ctx->gexec) return fail(EHR_ERR_INVALID, "ehr_graph_launch: no instantiated graph");
+    if (ctx->gexec_reallocs != Scratch::reallocs)  // a drop-in op or a re-plan moved scratch the graph points into
+        return fail(EHR_ERR_INVALID, "ehr_graph_launch: library scratch was reallocated after the capture; capture again");
     EHR_HIP(hipGraphLaunch(ctx->gexec, (hipStream_t)stream));
     return EHR_OK;
 }

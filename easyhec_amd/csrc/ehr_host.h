@@ -9,6 +9,8 @@
 
 #include "../../include/ehr.h"
 
+struct ehr_ctx;
+
 namespace ehr {
 
 void set_error(const std::string& msg);
@@ -34,7 +36,20 @@ struct Scratch {
     size_t cap = 0;
     int reserve(size_t bytes);  // may hipFree + hipMalloc (synchronises); never called on the fused hot path
     void release();
+    static unsigned long long reallocs;  // bumped whenever any Scratch moves: captured graphs hold raw pointers
 };
+
+struct StepHead;
+struct StepTail;
+#define VB_LOSS_SLOTS 32          // partial frame-loss sums per view (spreads same-address atomics)
+#define VB_MAX_UNITS 512          // views x links one context plans for
+#define VB_SPILL_ITEMS (1 << 20)  // pool of blended-pair items for tiles that overflow their LDS list (16 MB)
+int vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
+              const int32_t* tris, const int32_t* tri_link, const int32_t* opp);
+int vbuf_meta_read(ehr_ctx* ctx, int* meta4);
+int vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link, const int32_t* vert_link,
+               const int32_t* opp, float* mvp, const float* ref, int B, int L, int V, int T, int H, int W, float* mask,
+               float* loss, float* grad_mvp, const StepHead* head, const StepTail* tail, hipStream_t stream);
 
 }  // namespace ehr
 
@@ -53,6 +68,20 @@ struct ehr_ctx {
     ehr::Scratch posc;       // float4 [B * V] clip-space vertices of the current step
     ehr::Scratch tile_part;  // float [B * NT * (1 + 12 * L)] per-tile partial loss + MVP gradients
     ehr::Scratch tile_list;  // int32 [2 * B * NT]: per-tile entry totals | work list of non-empty tiles
+    // visibility-buffer chain of the fused op (ehr_vbuf.hip); its own scratch, never shared with the drop-in ops
+    bool path_vbuf = true;   // EHR_FUSED_PATH=tile selects the round-1 LDS-tile chain (A/B measurements)
+    ehr::Scratch vb_clus;    // i32 cluster index: ctri [NC][64] | clink [NC] | coff [L + 1] (static, built by the plan)
+    ehr::Scratch vb_idx;     // int4 [T] padded triangle indices | int4 [T] padded edge topology (static)
+    const void* vb_plan_tris = nullptr;  // the scene the static index was built for
+    const void* vb_plan_opp = nullptr;
+    int vb_nc = 0;           // number of clusters
+    int vb_jcap = 0;         // job slots
+    ehr::Scratch vb_boxes;   // uint2 pixel boxes of the current step: tbox [B][NC][64] | cbox [B][NC]
+    ehr::Scratch vb_units;   // i32 [B][L][4] pixel boxes of the links (re-armed by the finish kernel)
+    ehr::Scratch vb_acc;     // i64 [B][12 L + VB_LOSS_SLOTS] fixed-point sums, then the meta words
+    ehr::Scratch vb_posc;    // float4 [B][V] clip-space vertices
+    ehr::Scratch vb_jobs;    // per (view, link, tile) job slot: value tile | blended pairs | count | spill base
+    ehr::Scratch vb_spill;   // blended pairs of jobs that exceed their slot
     // space-explorer scoring (ehr_mask_variance) keeps its own scratch so that it never disturbs a solver plan
     ehr::Scratch sc_counts, sc_offsets, sc_entries, sc_posc;
     size_t sc_entries_cap = 0;
@@ -62,6 +91,7 @@ struct ehr_ctx {
     // natively captured launch chain (ehr_graph_*): capture stream and the instantiated graph
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
+    unsigned long long gexec_reallocs = 0;  // Scratch::reallocs when the graph was instantiated
     bool capturing = false;
     // measurement hook (ehr_fused_timing): EHR_FUSED_STAGES + 1 events per recorded call
     bool timing = false;

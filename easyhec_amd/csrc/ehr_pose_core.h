@@ -274,7 +274,12 @@ __device__ __forceinline__ void pose_adam_apply(const AdamState& st, float* __re
     const int i = threadIdx.x;
     const int t = st.t;
     const float nfr = red[7];
-    if (i < 6) {
+    // A reported failure (queue / accumulator overflow => NaN loss and gradient) must not destroy the calibration:
+    // the parameters, the moments and the step counter stay as they are, only the NaN loss is published.
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) ok = ok && (fabsf(red[k]) < 3.0e38f);
+    if (i < 6 && ok) {
         float g = red[i] / nfr;
         if (grad_out) grad_out[i] = g;
         float p = st.p;
@@ -289,9 +294,10 @@ __device__ __forceinline__ void pose_adam_apply(const AdamState& st, float* __re
         float denom = sqrtf(vi) / sqrtf(bc2) + eps;
         dof[i] = p - step_size * (mi / denom);
     }
-    if (i == 6 && loss_out) loss_out[0] = red[6] / nfr;
+    if (i < 6 && !ok && grad_out) grad_out[i] = __int_as_float(0x7fc00000);
+    if (i == 6 && loss_out) loss_out[0] = ok ? red[6] / nfr : __int_as_float(0x7fc00000);
     __syncthreads();
-    if (i == 0) step[0] = t;
+    if (i == 0 && ok) step[0] = t;
 }
 __device__ __forceinline__ void pose_adam_block(float* __restrict__ dof, float* __restrict__ m, float* __restrict__ v,
                                                 int* __restrict__ step, const float* __restrict__ red, float lr,

@@ -22,8 +22,11 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+unsigned long long Scratch::reallocs = 0;
+
 int Scratch::reserve(size_t bytes) {
     if (bytes <= cap) return EHR_OK;
+    reallocs++;
     if (ptr) {
         EHR_HIP(hipDeviceSynchronize());
         EHR_HIP(hipFree(ptr));
@@ -199,6 +202,12 @@ int ehr_ctx_create(int device, ehr_ctx** out) {
     EHR_HIP(hipSetDevice(device));
     ehr_ctx* c = new ehr_ctx();
     c->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+        const char* path = getenv("EHR_FUSED_PATH");
+        c->path_vbuf = !(path && path[0] == 't');
+    }
     hipError_t e = hipHostMalloc((void**)&c->host_pinned, 8 * sizeof(int), hipHostMallocDefault);
     (void)hipSetDevice(cur);
     if (e != hipSuccess) {
@@ -224,6 +233,14 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->sc_offsets.release();
     c->sc_entries.release();
     c->sc_posc.release();
+    c->vb_clus.release();
+    c->vb_idx.release();
+    c->vb_jobs.release();
+    c->vb_boxes.release();
+    c->vb_acc.release();
+    c->vb_posc.release();
+    c->vb_spill.release();
+    c->vb_units.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

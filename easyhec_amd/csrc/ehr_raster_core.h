@@ -61,6 +61,7 @@ struct BinGeom {
 #define EHR_META_OVERFLOW 1  // sticky overflow flag
 #define EHR_META_NWORK 2     // non-empty tiles appended to the work list
 #define EHR_META_NWORK_SLOW 3  // ... of which tiles that hold a triangle needing the 64-bit / clipping path
+#define EHR_META_SPILL 4     // visibility-buffer chain: items allocated from the spill pool
 #define EHR_META_INTS 48     // ints reserved for the meta block (8 words + profiling counters)
 
 // A triangle is "slow" when it needs near-plane clipping or spans more than this many sub-pixels: then (and only

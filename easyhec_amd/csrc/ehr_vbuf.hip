@@ -1,0 +1,1389 @@
+// ehr_vbuf.hip -- the fused hot path, visibility-buffer form (round 2).  Same arithmetic and outputs as the LDS-tile
+// chain in ehr_fused.hip, restating
+//   /root/reference/easyhec/modeling/models/rb_solve/rb_solver.py:60-72   (per-link render, sum, clamp, SSE)
+//   /root/reference/easyhec/structures/nvdiffrast_renderer.py:33-47        (rasterize -> interpolate -> antialias -> flip)
+//   /root/reference/easyhec/utils/nvdiffrast_utils.py:14-18                (transform_pos)
+// but without triangle binning and without a per-tile rasterizer.  The xArm7 / Franka meshes project to micro-triangles
+// (median bounding box 8 px, a quarter of them cover no pixel centre at all), for which building and draining per-tile
+// queues costs more than the coverage tests themselves.  Here:
+//
+//   vb_vertex_kernel   [pose forward] + clip-space vertices + housekeeping: the depth keys written by the PREVIOUS
+//                      step are reset (only the tiles that step marked), accumulators zeroed.
+//   vb_raster_kernel   one thread per (view, triangle): snap, exact integer coverage over its pixel box, and for every
+//                      covered pixel centre one 64-bit atomic-min of  ordered(z/w) << 32 | triangle  into the
+//                      (view, link) key image in HBM/L2.  The minimum is order independent, so the result is the
+//                      oracle's nearest-wins / lowest-index-wins z-buffer bit for bit.  Boxes above VB_SMALL_BOX
+//                      pixels are walked by the whole wave (64 pixels per step) instead of one lane.  Every triangle
+//                      also marks the 32x8 tiles its box (+1 pixel) touches in a per-tile link bitmask.
+//   vb_resolve_kernel  one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers).
+//                      Unmarked tiles stream (mask = 0, loss += ref^2).  For each marked link the wave loads the
+//                      tile + halo keys, finds covered/uncovered pixel pairs with wave-uniform bit arithmetic on the
+//                      coverage bitmap, runs the silhouette analysis on the compacted hits, gathers the antialias
+//                      blend per pixel in the oracle's order, composites, and back-propagates the blended pairs to
+//                      12 numbers per link which go to the view's fixed-point accumulators.
+//   fused_finish_kernel (shared with the tile chain)  accumulators -> loss / grad_mvp [-> pose backward -> Adam].
+#include <stdlib.h>
+
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#include "ehr_fused_core.h"
+
+namespace ehr {
+
+constexpr int VB_RW = EHR_TILE_W + 2;  // tile + 1-pixel halo
+constexpr int VB_RH = EHR_TILE_H + 2;
+constexpr int VB_RN = VB_RW * VB_RH;   // 340
+constexpr int VB_WORDS = (VB_RN + 63) / 64;  // 6 coverage words
+constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min y, max x, max y, padding to a 64-byte line
+constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
+constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
+constexpr u64 VB_EMPTY = ~0ull;
+#define VB_SMALL_BOX 16                // pixel boxes up to this size are walked by the triangle's own lane
+#define VB_FAST_EXTENT 8192            // snapped extent (1/16 px) up to which 32-bit edge functions are exact
+
+#define VB_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#ifdef VB_PHASE_TIMING  // profiling build only (-DVB_PHASE_TIMING): cycles per phase, kept per wave, summed at its end
+#define VB_PHASE(i)                                                          \
+    do {                                                                     \
+        const long long now_ = __builtin_readcyclecounter();                 \
+        ph_acc[i] += now_ - ph_last;                                         \
+        ph_last = __builtin_readcyclecounter();                              \
+    } while (0)
+#else
+#define VB_PHASE(i) do { } while (0)
+#endif
+
+struct VbItem {
+    int packed;  // bits 0-9 q (region index of pixel0) | 10 d | 11-12 di | 13 tri1 | 14 (c1 - c0 > 0)
+    int v1, v2;  // the two vertices of the crossing silhouette edge (global ids)
+    float alpha;
+};
+
+// ---- compile-time bitmaps over the 34x10 region (bit i = region pixel i, row-major) ------------------------------
+constexpr bool vb_interior(int i) {
+    return (i % VB_RW) >= 1 && (i % VB_RW) <= EHR_TILE_W && (i / VB_RW) >= 1 && (i / VB_RW) <= EHR_TILE_H;
+}
+constexpr u64 vb_word_h(int k) {  // horizontal pair (i, i+1): same row, at least one pixel interior
+    u64 w = 0;
+    for (int j = 0; j < 64; j++) {
+        const int i = 64 * k + j;
+        if (i + 1 < VB_RN && (i % VB_RW) != VB_RW - 1 && (vb_interior(i) || vb_interior(i + 1))) w |= 1ull << j;
+    }
+    return w;
+}
+constexpr u64 vb_word_v(int k) {  // vertical pair (i, i+RW)
+    u64 w = 0;
+    for (int j = 0; j < 64; j++) {
+        const int i = 64 * k + j;
+        if (i + VB_RW < VB_RN && (vb_interior(i) || vb_interior(i + VB_RW))) w |= 1ull << j;
+    }
+    return w;
+}
+
+template <int S>
+__device__ __forceinline__ void vb_shr(const u64 in[VB_WORDS], u64 out[VB_WORDS]) {
+#pragma unroll
+    for (int k = 0; k < VB_WORDS; k++) out[k] = (in[k] >> S) | (k + 1 < VB_WORDS ? in[k + 1] << (64 - S) : 0ull);
+}
+
+__device__ __forceinline__ int vb_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float vb_readlane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float4 vb_readlane(const float4& v, int lane) {
+    return make_float4(vb_readlane(v.x, lane), vb_readlane(v.y, lane), vb_readlane(v.z, lane), vb_readlane(v.w, lane));
+}
+__device__ __forceinline__ int vb_mbcnt(u64 m) {  // set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// ---- stage 1: vertices, screen boxes of triangles / clusters / links ---------------------------------------------
+
+struct VbClusters {          // static acceleration index built by ehr_fused_plan (host): triangles grouped into
+    const int32_t* ctri;     // [NC * 64] clusters of <= 64 spatially close triangles of one link (-1 = padding)
+    const int32_t* clink;    // [NC] link of every cluster
+    const int32_t* coff;     // [L + 1] first cluster of every link
+    const float* laabb;      // [L][6] object-space bounding box of every link (min xyz, max xyz)
+    int NC;
+};
+
+__device__ __forceinline__ uint2 vb_pack_box(int x0, int y0, int x1, int y1) {
+    return make_uint2((unsigned)x0 | ((unsigned)y0 << 16), (unsigned)x1 | ((unsigned)y1 << 16));
+}
+#define VB_BOX_EMPTY make_uint2(0xffffffffu, 0u)  // x0 = y0 = 65535 > any pixel, x1 = y1 = 0: overlaps nothing
+
+// grid = (nvb + ceil(NC / 4), B): the first nvb workgroups of a view transform its vertices (posc), the others take
+// four clusters each -- one wave per cluster, one lane per triangle -- and publish the pixel bounding box of every
+// triangle (tbox, empty for triangles that cover no pixel centre column/row), of every cluster (cbox) and, through a
+// handful of integer atomics, of every link (lbox; reset by the finish kernel).  The cluster path transforms its own
+// vertices with the same fma chain, so it does not wait for posc.  HEAD: the solver-step form (pose forward from dof,
+// writes mvp / tc_jac / history row); otherwise mvp is an input.
+// 32-bit edge functions of a triangle whose snapped extent is <= VB_FAST_EXTENT, relative to the centre of pixel
+// (bx0, by0), which lies inside the triangle's bounding box: |coordinates| <= 2^13, products < 2^27.
+struct VbEdges {
+    int e0, e1, e2, sx0, sx1, sx2, sy0, sy1, sy2;
+};
+__device__ __forceinline__ VbEdges vb_edges(int X0, int Y0, int X1, int Y1, int X2, int Y2, int bx0, int by0, int W,
+                                            int H) {
+    VbEdges r;
+    const int ox = 16 * bx0 + 8 - 8 * W, oy = 16 * by0 + 8 - 8 * H;
+    X0 -= ox; X1 -= ox; X2 -= ox;
+    Y0 -= oy; Y1 -= oy; Y2 -= oy;
+    {
+        const int dX = X1 - X0, dY = Y1 - Y0;
+        r.e0 = dX * (0 - Y0) - dY * (0 - X0) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
+        r.sx0 = -16 * dY;
+        r.sy0 = 16 * dX;
+    }
+    {
+        const int dX = X2 - X1, dY = Y2 - Y1;
+        r.e1 = dX * (0 - Y1) - dY * (0 - X1) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
+        r.sx1 = -16 * dY;
+        r.sy1 = 16 * dX;
+    }
+    {
+        const int dX = X0 - X2, dY = Y0 - Y2;
+        r.e2 = dX * (0 - Y2) - dY * (0 - X2) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
+        r.sx2 = -16 * dY;
+        r.sy2 = 16 * dX;
+    }
+    return r;
+}
+
+// Per-triangle raster record written by the cluster pass, read by the tile waves (so a triangle is set up once per
+// step, not once per tile it touches):
+//   trec[2 i]     = { e0, e1, e2, dX0 | dY0 << 16 }   edge functions (tie rule folded in) at the centre of the box's
+//   trec[2 i + 1] = { dX1 | dY1 << 16, dX2 | dY2 << 16, triangle id, kind }   first pixel; kind 0 = 32-bit fast path,
+//                                                      1 = needs clipping / 64-bit (handled from the vertices)
+//   tdep[3 i ..]  = the three clip-space vertices (depth is evaluated from them per covered pixel)
+struct VbRecs {
+    uint2* tbox;   // [B][NC][64] pixel box, VB_BOX_EMPTY if the triangle cannot cover a pixel centre
+    uint2* cbox;   // [B][NC] union over the cluster
+    int4* trec;    // [2][B][NC][64]: component-major, so that consecutive slots read consecutive 16-byte words
+    float4* tdep;  // [3][B][NC][64]
+    size_t n;      // B * NC * 64 (component stride)
+};
+
+template <bool HEAD>
+__global__ void __launch_bounds__(256)
+vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vert_link,
+                 const int32_t* __restrict__ tris, VbClusters cl, StepHead head, float* __restrict__ mvp, int V, int nvb,
+                 BinGeom g, float4* __restrict__ posc, VbRecs rc, int* __restrict__ lbox, int* __restrict__ zacc,
+                 int nzacc, int* __restrict__ meta, int B, int gx, int xcd_views) {
+    __shared__ float Tc[16];
+    __shared__ float M[32][16];
+    // 1-D grid of B * gx workgroups.  xcd_views > 0 (B a multiple of 8): workgroup w runs on XCD w % 8 (observed, used
+    // for L2 locality only) and that XCD takes views [xcd * B / 8, (xcd + 1) * B / 8) -- the same views whose jobs stage 2
+    // gives to that XCD, so the records it reads were written through the same L2.
+    int b, bx;
+    if (xcd_views > 0) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        b = xcd * xcd_views + k / gx;
+        bx = k - (k / gx) * gx;
+    } else {
+        b = blockIdx.x / gx;
+        bx = blockIdx.x - b * gx;
+    }
+    (void)B;
+    const int tid = threadIdx.x, L = g.L, H = g.H, W = g.W;
+    const bool first = bx == 0 && b == 0;
+    const bool vpath = bx < nvb;
+    // geometry loads first: they do not depend on the pose, so their latency hides under the pose arithmetic below
+    const int v = bx * 256 + tid;
+    const int c = (bx - nvb) * 4 + (tid >> 6), lane = tid & 63;
+    int l = -1, t = -1;
+    float vx[3] = {0.f, 0.f, 0.f}, vy[3] = {0.f, 0.f, 0.f}, vz[3] = {0.f, 0.f, 0.f};
+    bool have = false;
+    if (vpath) {
+        if (v < V) {
+            l = vert_link[v];
+            vx[0] = verts[3 * v];
+            vy[0] = verts[3 * v + 1];
+            vz[0] = verts[3 * v + 2];
+            have = true;
+        }
+    } else if (c < cl.NC) {
+        t = cl.ctri[(size_t)c * 64 + lane];
+        l = cl.clink[c];
+        if (t >= 0) {
+            const int v0 = tris[3 * t], v1 = tris[3 * t + 1], v2 = tris[3 * t + 2];
+            if ((unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V) {
+                const int vi[3] = {v0, v1, v2};
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    vx[k] = verts[3 * vi[k]];
+                    vy[k] = verts[3 * vi[k] + 1];
+                    vz[k] = verts[3 * vi[k] + 2];
+                }
+                have = true;
+            }
+        }
+    }
+    if (HEAD && tid < 6) {
+        Dual<1> T6[16];
+        se3_exp_dual<1>(head.dof, 1e-4f, T6, tid);
+        if (tid == 0)
+            for (int i = 0; i < 16; i++) Tc[i] = T6[i].v;
+        if (first) {
+            for (int i = 0; i < 16; i++) {
+                if (tid == 0) head.tc_jac[i] = T6[i].v;
+                head.tc_jac[16 * (tid + 1) + i] = T6[i].d[0];
+            }
+            if (tid == 0 && head.history && head.step) {
+                int row = head.step[0];
+                if (row >= 0 && row < head.history_rows)
+                    for (int k = 0; k < 6; k++) head.history[6 * row + k] = head.dof[k];
+            }
+        }
+    }
+    if (first) {
+        for (int i = tid; i < nzacc; i += 256) zacc[i] = 0;  // fixed-point accumulators (a few KB)
+        if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
+        if (tid < 8) meta[32 + tid] = 0;                     // job cursors of the 8 XCDs
+    }
+    __syncthreads();
+    if (HEAD) {
+        if (tid < L) {
+            float P[16], C[16];
+            projection(head.K, H, W, head.n, head.f, P);
+            mvp_from_pose(Tc, P, head.link_poses + ((size_t)b * L + tid) * 16, C);
+            for (int k = 0; k < 16; k++) M[tid][k] = C[k];
+            if (bx == 0)
+                for (int k = 0; k < 16; k++) mvp[((size_t)b * L + tid) * 16 + k] = C[k];
+        }
+    } else {
+        for (int i = tid; i < L * 16; i += 256) M[i >> 4][i & 15] = mvp[(size_t)b * L * 16 + i];
+    }
+    __syncthreads();
+    const bool lv = (unsigned)l < (unsigned)L;
+    if (vpath) {
+        if (v >= V) return;
+        float4 o = make_float4(0.f, 0.f, 0.f, -1.f);  // invalid link -> behind the camera, never drawn
+        if (lv) o = transform_vertex(M[l], vx[0], vy[0], vz[0]);
+        posc[(size_t)b * V + v] = o;
+        return;
+    }
+    if (c >= cl.NC) return;
+    int x0 = 0xffff, y0 = 0xffff, x1 = 0, y1 = 0;  // empty (overlaps nothing)
+    int4 r0 = make_int4(-1, -1, -1, 0), r1 = make_int4(0, 0, t, 0);
+    float4 p0 = make_float4(0.f, 0.f, 0.f, -1.f), p1 = p0, p2 = p0;
+    if (have && lv) {
+        p0 = transform_vertex(M[l], vx[0], vy[0], vz[0]);
+        p1 = transform_vertex(M[l], vx[1], vy[1], vz[1]);
+        p2 = transform_vertex(M[l], vx[2], vy[2], vz[2]);
+        const bool simple = (p0.w > 0.f) && (p1.w > 0.f) && (p2.w > 0.f) && (p0.z + p0.w >= 0.f) &&
+                            (p1.z + p1.w >= 0.f) && (p2.z + p2.w >= 0.f);
+        if (!simple) {  // near-plane clipping decides where it lands: keep it a candidate everywhere
+            x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
+            r1.w = 1;
+        } else {
+            const Coverage cv = setup_coverage(p0, p1, p2, W, H);
+            if (cv.valid) {
+                x0 = cv.ix0; y0 = cv.iy0; x1 = cv.ix1; y1 = cv.iy1;
+                const i64 ex = (i64)max(cv.X[0], max(cv.X[1], cv.X[2])) - min(cv.X[0], min(cv.X[1], cv.X[2]));
+                const i64 ey = (i64)max(cv.Y[0], max(cv.Y[1], cv.Y[2])) - min(cv.Y[0], min(cv.Y[1], cv.Y[2]));
+                if (ex > VB_FAST_EXTENT || ey > VB_FAST_EXTENT) {
+                    r1.w = 1;
+                } else {
+                    const VbEdges ed = vb_edges(cv.X[0], cv.Y[0], cv.X[1], cv.Y[1], cv.X[2], cv.Y[2], x0, y0, W, H);
+                    r0 = make_int4(ed.e0, ed.e1, ed.e2, (int)(((unsigned)(ed.sy0 / 16) & 0xffffu) | ((unsigned)(-ed.sx0 / 16) << 16)));
+                    r1.x = (int)(((unsigned)(ed.sy1 / 16) & 0xffffu) | ((unsigned)(-ed.sx1 / 16) << 16));
+                    r1.y = (int)(((unsigned)(ed.sy2 / 16) & 0xffffu) | ((unsigned)(-ed.sx2 / 16) << 16));
+                }
+            }
+        }
+    }
+    const size_t slot = ((size_t)b * cl.NC + c) * 64 + lane;
+    rc.tbox[slot] = vb_pack_box(x0, y0, x1, y1);
+    if (x0 <= x1) {
+        rc.trec[slot] = r0;
+        rc.trec[rc.n + slot] = r1;
+        rc.tdep[slot] = p0;
+        rc.tdep[rc.n + slot] = p1;
+        rc.tdep[2 * rc.n + slot] = p2;
+    }
+    const bool ne = x0 <= x1;
+    int a = ne ? x0 : INT_MAX, bq = ne ? y0 : INT_MAX, cc = ne ? x1 : -1, d = ne ? y1 : -1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a = min(a, __shfl_xor(a, off, 64));
+        bq = min(bq, __shfl_xor(bq, off, 64));
+        cc = max(cc, __shfl_xor(cc, off, 64));
+        d = max(d, __shfl_xor(d, off, 64));
+    }
+    if (lane == 0) {
+        const bool cne = a <= cc;
+        rc.cbox[(size_t)b * cl.NC + c] = cne ? vb_pack_box(a, bq, cc, d) : VB_BOX_EMPTY;
+        if (cne && lv) {  // link box: integer atomics, one 64-byte line per (view, link) so that links do not serialise
+            int* bx = lbox + VB_LBOX_STRIDE * ((size_t)b * L + l);
+            atomicMin(bx + 0, a);
+            atomicMin(bx + 1, bq);
+            atomicMax(bx + 2, cc);
+            atomicMax(bx + 3, d);
+        }
+    }
+}
+
+// ---- stage 2: one wave per tile: cull, rasterize into LDS, resolve --------------------------------------------------
+
+struct VbRegion {
+    int x0, y0, x1, y1;  // pixels of the region inside the image (inclusive); region origin = (rx0, ry0) below
+};
+
+// General path, whole wave per triangle, wave-uniform arguments: near-plane clipping, 64-bit edge functions.  Rare
+// (triangles crossing the near plane or spanning more than 512 pixels).
+__device__ __noinline__ void vb_raster_wide(float4 pa, float4 pb, float4 pc, int t, int W, int H, VbRegion rg, int rx0,
+                                            int ry0, u64* key) {
+    const int lane = lane_id();
+    const float4 p[3] = {pa, pb, pc};
+    const ClipPoly c = clip_near_poly(p);
+    for (int s = 0; s + 2 < c.n; s++) {
+        Coverage cv = (s == 0) ? setup_coverage(c.q0, c.q1, c.q2, W, H) : setup_coverage(c.q0, c.q2, c.q3, W, H);
+        if (!cv.valid) continue;
+        const int bx0 = max(cv.ix0, rg.x0), by0 = max(cv.iy0, rg.y0);
+        const int bx1 = min(cv.ix1, rg.x1), by1 = min(cv.iy1, rg.y1);
+        if (bx0 > bx1 || by0 > by1) continue;
+        const int bw = bx1 - bx0 + 1, npx = bw * (by1 - by0 + 1);
+        const EdgeEval ee = setup_edges(cv, bx0, by0, W, H);
+        for (int i0 = 0; i0 < npx; i0 += 64) {
+            const int i = i0 + lane;
+            if (i < npx) {
+                const int dy = i / bw, dx = i - dy * bw;
+                const i64 e0 = ee.e[0] + dx * ee.sx[0] + dy * ee.sy[0];
+                const i64 e1 = ee.e[1] + dx * ee.sx[1] + dy * ee.sy[1];
+                const i64 e2 = ee.e[2] + dx * ee.sx[2] + dy * ee.sy[2];
+                if ((e0 | e1 | e2) >= 0) {
+                    const int ix = bx0 + dx, iy = by0 + dy;
+                    depth_test_write(p, t, ix, iy, W, H, &key[(iy - ry0) * VB_RW + (ix - rx0)]);
+                }
+            }
+        }
+    }
+}
+
+// LDS scratch of the wave-level balanced rasterizer (aliases the blend-weight / hit arrays, which are only live
+// after a link's coverage is complete).
+struct alignas(16) VbRaster {
+    float4 pf[64][3];      // clip-space vertices of the staged jobs (depth)
+    int e[64][3];          // edge functions at the first pixel of the job's box inside the region
+    unsigned dxy[64][3];   // dX | dY << 16 of the three edges
+    unsigned box[64];      // box inside the region: x0 | y0 << 8 | w << 16 | h << 24 (region-relative)
+    int tri[64];
+    int pre[65];           // exclusive prefix of the jobs' work units (+ total)
+    unsigned ring[128];    // covered units waiting for their depth test: first pixel | 4-bit coverage << 12 | job << 16
+};
+
+// Depth-test `n` (<= 64) ring entries, one per lane.  An entry is a run of up to 4 horizontally adjacent pixels of one
+// staged job.
+__device__ __forceinline__ void vb_drain(VbRaster& R, int head, int n, int W, int H, int rx0, int ry0, u64* key) {
+    const int lane = lane_id();
+    if (lane < n) {
+        const unsigned f = R.ring[(head + lane) & 127];
+        const int pix = f & 0xfffu, j = f >> 16;
+        const unsigned m4 = (f >> 12) & 15u;
+        const float4 p[3] = {R.pf[j][0], R.pf[j][1], R.pf[j][2]};
+        const int t = R.tri[j];
+        const int py = pix / VB_RW, px = pix - py * VB_RW;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (m4 & (1u << i)) depth_test_write(p, t, rx0 + px + i, ry0 + py, W, H, &key[pix + i]);
+    }
+}
+
+// One round of the wave-level rasterizer: up to 64 candidate triangles (lane `sv` holds one, described by its pixel
+// box `bx` and record slot) are rasterized into the region's LDS depth/id buffer -- ds_min_u64 on
+// ordered(z/w) << 32 | triangle, which is order independent, so the result is the oracle's nearest-wins /
+// lowest-index-wins z-buffer bit for bit.  The triangles' boxes (clamped to the region) are cut into units of 4
+// horizontally adjacent pixels; a wave-wide prefix sum splits the concatenated unit sequence EVENLY over the 64 lanes
+// (a third of the candidates have boxes above 16 pixels, so one lane per triangle would leave most lanes idle), each
+// lane walks its contiguous run stepping 32-bit edge functions, covered units are compacted through an LDS ring with
+// ballot/popcount and depth-tested 64 at a time.  Same scheme as round 1's block-wide raster_queue, at wave scope (no
+// workgroup barriers) and fed by the per-triangle records of the cluster pass instead of a per-tile setup.
+__device__ __forceinline__ void vb_raster_round(bool sv, size_t slot, const VbRecs& rc, const VbRegion& rg,
+                                                int rx0, int ry0, int W, int H, VbRaster& R, u64* key,
+                                                long long* ph_acc, long long& ph_last) {
+    const int lane = lane_id();
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    (void)ph_acc;
+    (void)ph_last;
+    int units = 0;
+    bool wide = false;
+    if (sv) {
+        const uint2 bx = rc.tbox[slot];
+        const int4 r0 = rc.trec[slot], r1 = rc.trec[rc.n + slot];
+        const float4 q0 = rc.tdep[slot], q1 = rc.tdep[rc.n + slot], q2 = rc.tdep[2 * rc.n + slot];
+        const int tid_tri = r1.z;
+        if (r1.w != 0) {
+            wide = true;
+        } else {
+            const int ix0 = bx.x & 0xffffu, iy0 = bx.x >> 16, ix1 = bx.y & 0xffffu, iy1 = bx.y >> 16;
+            const int cx0 = max(ix0, rg.x0), cy0 = max(iy0, rg.y0);
+            const int bw = min(ix1, rg.x1) - cx0 + 1, bh = min(iy1, rg.y1) - cy0 + 1;  // > 0: the boxes overlap
+            const unsigned w[3] = {(unsigned)r0.w, (unsigned)r1.x, (unsigned)r1.y};
+            const int ev[3] = {r0.x, r0.y, r0.z};
+            const int ox = cx0 - ix0, oy = cy0 - iy0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int dX = (int)(short)(w[k] & 0xffffu), dY = (int)(short)(w[k] >> 16);
+                R.e[lane][k] = ev[k] - 16 * dY * ox + 16 * dX * oy;
+                R.dxy[lane][k] = w[k];
+            }
+            R.box[lane] = (unsigned)(cx0 - rx0) | ((unsigned)(cy0 - ry0) << 8) | ((unsigned)bw << 16) | ((unsigned)bh << 24);
+            R.tri[lane] = tid_tri;
+            R.pf[lane][0] = q0;
+            R.pf[lane][1] = q1;
+            R.pf[lane][2] = q2;
+            units = ((bw + 3) >> 2) * bh;
+        }
+    }
+    VB_PHASE(2);  // record loads + staging
+    int incl = units;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    const int S = vb_readlane(incl, 63);
+    if (S > 0) {
+        R.pre[lane] = incl - units;
+        if (lane == 63) R.pre[64] = S;
+        VB_WAVE_SYNC();
+        const int K = (S + 63) >> 6;
+        const int start = lane * K, end = min(start + K, S);
+        int j = 0, bw = 1, bh = 1, gw = 1, gx = 0, dy = 0, pix = 0, rowpix = 0;
+        int e0 = -1, e1 = -1, e2 = -1, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0, er0 = 0, er1 = 0, er2 = 0;
+        if (start < end) {
+            int lo = 0, hi = 63;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (R.pre[mid] <= start)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            j = lo;
+            const unsigned b4 = R.box[j];
+            const int x0r = b4 & 255, y0r = (b4 >> 8) & 255;
+            bw = (b4 >> 16) & 255;
+            bh = b4 >> 24;
+            gw = (bw + 3) >> 2;
+            const unsigned w0 = R.dxy[j][0], w1 = R.dxy[j][1], w2 = R.dxy[j][2];
+            sx0 = -16 * (int)(short)(w0 >> 16); sy0 = 16 * (int)(short)(w0 & 0xffffu);
+            sx1 = -16 * (int)(short)(w1 >> 16); sy1 = 16 * (int)(short)(w1 & 0xffffu);
+            sx2 = -16 * (int)(short)(w2 >> 16); sy2 = 16 * (int)(short)(w2 & 0xffffu);
+            const int o = start - R.pre[j];
+            dy = o / gw;
+            gx = o - dy * gw;
+            er0 = R.e[j][0] + dy * sy0;
+            er1 = R.e[j][1] + dy * sy1;
+            er2 = R.e[j][2] + dy * sy2;
+            e0 = er0 + 4 * gx * sx0;
+            e1 = er1 + 4 * gx * sx1;
+            e2 = er2 + 4 * gx * sx2;
+            rowpix = (y0r + dy) * VB_RW + x0r;
+            pix = rowpix + 4 * gx;
+        }
+        int qhead = 0, qcount = 0;
+        VB_PHASE(3);  // prefix + search
+#pragma nounroll
+        for (int it = 0; it < K; it++) {
+            const bool act = start + it < end;
+            unsigned m4 = 0;
+            if (act) {
+                const int a1 = e0 + sx0, a2 = a1 + sx0, a3 = a2 + sx0;
+                const int b1 = e1 + sx1, b2 = b1 + sx1, b3 = b2 + sx1;
+                const int c1 = e2 + sx2, c2 = c1 + sx2, c3 = c2 + sx2;
+                m4 = ((e0 | e1 | e2) >= 0 ? 1u : 0u) | ((a1 | b1 | c1) >= 0 ? 2u : 0u) | ((a2 | b2 | c2) >= 0 ? 4u : 0u) |
+                     ((a3 | b3 | c3) >= 0 ? 8u : 0u);
+                const int rem = bw - 4 * gx;  // pixels of this unit that lie inside the box
+                if (rem < 4) m4 &= (1u << rem) - 1u;
+            }
+            const bool inside = m4 != 0;
+            const u64 m = __ballot(inside);
+            if (m) {
+                if (inside) R.ring[(qhead + qcount + __popcll(m & lt)) & 127] = (unsigned)pix | (m4 << 12) | ((unsigned)j << 16);
+                qcount += __popcll(m);
+                if (qcount >= 64) {
+                    VB_WAVE_SYNC();
+                    vb_drain(R, qhead, 64, W, H, rx0, ry0, key);
+                    qhead = (qhead + 64) & 127;
+                    qcount -= 64;
+                }
+            }
+            if (act && start + it + 1 < end) {
+                gx++;
+                pix += 4;
+                e0 += 4 * sx0;
+                e1 += 4 * sx1;
+                e2 += 4 * sx2;
+                if (gx == gw) {
+                    gx = 0;
+                    dy++;
+                    rowpix += VB_RW;
+                    pix = rowpix;
+                    er0 += sy0;
+                    er1 += sy1;
+                    er2 += sy2;
+                    e0 = er0;
+                    e1 = er1;
+                    e2 = er2;
+                    if (dy == bh) {  // next job with a non-empty box
+                        do {
+                            j++;
+                        } while (R.pre[j + 1] == R.pre[j]);
+                        const unsigned b4 = R.box[j];
+                        const int x0r = b4 & 255, y0r = (b4 >> 8) & 255;
+                        bw = (b4 >> 16) & 255;
+                        bh = b4 >> 24;
+                        gw = (bw + 3) >> 2;
+                        const unsigned w0 = R.dxy[j][0], w1 = R.dxy[j][1], w2 = R.dxy[j][2];
+                        sx0 = -16 * (int)(short)(w0 >> 16); sy0 = 16 * (int)(short)(w0 & 0xffffu);
+                        sx1 = -16 * (int)(short)(w1 >> 16); sy1 = 16 * (int)(short)(w1 & 0xffffu);
+                        sx2 = -16 * (int)(short)(w2 >> 16); sy2 = 16 * (int)(short)(w2 & 0xffffu);
+                        er0 = e0 = R.e[j][0];
+                        er1 = e1 = R.e[j][1];
+                        er2 = e2 = R.e[j][2];
+                        dy = 0;
+                        rowpix = y0r * VB_RW + x0r;
+                        pix = rowpix;
+                    }
+                }
+            }
+        }
+        if (qcount) {
+            VB_WAVE_SYNC();
+            vb_drain(R, qhead, qcount, W, H, rx0, ry0, key);
+        }
+        VB_WAVE_SYNC();  // the staging area is rewritten by the next round
+        VB_PHASE(4);  // walk + depth
+    }
+    u64 wm = __ballot(wide);  // rare: near-plane clipping / very large extents, one triangle at a time
+    while (wm) {
+        const int s = __ffsll((unsigned long long)wm) - 1;
+        wm &= wm - 1;
+        const unsigned wl = vb_readlane((int)(unsigned)(slot & 0xffffffffu), s), wh = vb_readlane((int)(unsigned)(slot >> 32), s);
+        const size_t ws = ((size_t)wh << 32) | wl;
+        vb_raster_wide(rc.tdep[ws], rc.tdep[rc.n + ws], rc.tdep[2 * rc.n + ws], rc.trec[rc.n + ws].z, W, H, rg, rx0, ry0,
+                       key);
+    }
+}
+
+struct VbResolveLds {
+    float pairA[2 * VB_RN];      // blend weight of pair (q, d) at [d * RN + q]
+    unsigned short hits[2 * VB_RN];
+};
+struct alignas(16) VbWaveLds {
+    u64 key[VB_RN];              // depth/id of each region pixel: ordered(z/w) << 32 | triangle, all-ones = uncovered
+    union {
+        VbRaster R;              // while the link is being rasterized
+        VbResolveLds Z;          // afterwards
+    } u;
+    unsigned sq[128];            // survivors of the box culling waiting for a full round: record slots (ring)
+};
+
+// tiles (+ 1-pixel halo) a link's pixel box touches: the jobs of that (view, link)
+__device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W, int H, int& tx0, int& ty0, int& nx, int& ny) {
+    const int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
+    if (x0 > x1 || y0 > y1) return false;
+    tx0 = max(x0 - 1, 0) / EHR_TILE_W;
+    ty0 = max(y0 - 1, 0) / EHR_TILE_H;
+    nx = min(x1 + 1, W - 1) / EHR_TILE_W - tx0 + 1;
+    ny = min(y1 + 1, H - 1) / EHR_TILE_H - ty0 + 1;
+    return true;
+}
+
+// Stage 2: one WAVE per job = (view, link, 32x8 tile the link's screen box touches); persistent waves over the job list,
+// which is never materialised (every workgroup derives it from the link boxes with a prefix sum over B * L counts).
+// A job culls the link's cluster boxes, then the triangle boxes of the surviving clusters, rasterizes the survivors
+// into the wave's LDS depth/id buffer (tile + 1-pixel halo), finds the covered/uncovered pixel pairs with wave-uniform
+// bit arithmetic on the coverage bitmap, runs the silhouette analysis on the compacted hits and gathers the link's
+// antialiased value per pixel in the oracle's order.  It leaves, in the job's slot (view, link, tile): the 256 values
+// (jval), the blended pairs the backward pass needs (jitems) and their number (jn; -1 = the link contributes nothing
+// here).  No workgroup barriers after the prologue; thousands of independent waves hide each other's latency.
+#ifndef VB_JOB_WAVES
+#define VB_JOB_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, VB_JOB_WAVES)
+vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const int4* __restrict__ tri4,
+              const int4* __restrict__ opp4, VbClusters cl, VbRecs rc, const int* __restrict__ lbox,
+              int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems, int* __restrict__ jspill,
+              int* __restrict__ jbase, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
+              int* __restrict__ meta, int dbg) {
+    __shared__ VbWaveLds lds_all[4];
+    __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
+    __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
+    __shared__ int lcoff[33];                 // first cluster of every link
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    VbWaveLds& S = lds_all[wave];
+#define KT(i) (reinterpret_cast<const unsigned*>(S.key)[2 * (i)])  // triangle id of region pixel i (all-ones = uncovered)
+    const int W = g.W, H = g.H, L = g.L, U = B * L;
+    // ---- prologue (every workgroup, redundantly): tile range and job count of every (view, link), prefix sum
+    if (tid <= L) lcoff[tid] = cl.coff[tid];
+    for (int u = tid; u < U; u += 256) {
+        int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
+        const bool ne = vb_unit_tiles(lbox + VB_LBOX_STRIDE * (size_t)u, W, H, tx0, ty0, nx, ny);
+        upre[u + 1] = ne ? nx * ny : 0;
+        utile[u] = (unsigned)tx0 | ((unsigned)ty0 << 10) | ((unsigned)(ne ? nx : 1) << 22);
+    }
+    if (tid == 0) upre[0] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        int run = 0;
+        for (int base = 0; base < U; base += 64) {
+            const int i = base + lane;
+            int incl = (i < U) ? upre[i + 1] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            if (i < U) upre[i + 1] = run + incl;
+            run += vb_readlane(incl, 63);
+        }
+    }
+    __syncthreads();
+    int total = upre[U];
+    if (blockIdx.x == 0) {
+        // job slots are numbered like the jobs: stage 3 finds a (view, link, tile) slot from the link's first job
+        for (int u = tid; u < U; u += 256) jbase[u] = upre[u];
+        if (tid == 0) {
+            meta[5] = total;  // diagnostics (EHR_VB_PRINT)
+            if (total > jcap) meta[EHR_META_OVERFLOW] = 1;  // cannot happen with one slot per (view, link, tile)
+        }
+    }
+    total = min(total, jcap);
+    // XCD-aware order: workgroup w runs on XCD w % 8 (observed, used for L2 locality only): every XCD takes a contiguous
+    // eighth of the job list, so that a view's vertices, boxes and records stay in one L2.  Inside that eighth the jobs are
+    // dealt round-robin; claiming them dynamically (one returning atomic per job on the XCD's cursor, EHR_VB_DEBUG & 8)
+    // balances better but measured 20 % slower: 500 waves hit each cursor at once (~12 ns per same-address atomic).
+    const int per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
+    const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
+    int* const cursor = meta + 32 + xcd;
+    long long ph_last = __builtin_readcyclecounter();
+    long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)ph_last;
+    (void)ph_acc;
+    int sjob = jbeg + (blockIdx.x >> 3) * 4 + wave;
+    for (;;) {
+        int job = 0;
+        if (!(dbg & 8)) {
+            job = sjob;
+            sjob += (gridDim.x >> 3) * 4;
+        } else {
+            if (lane == 0) job = jbeg + atomicAdd(cursor, 1);
+            job = __builtin_amdgcn_readfirstlane(job);
+        }
+        if (job >= jend) break;
+        VB_PHASE(0);  // claim / previous job's tail
+        int u;
+        {
+            int lo = 0, hi = U - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (upre[mid] <= job)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            u = lo;
+        }
+        const int b = u / L, l = u - b * L;
+        int tx, ty;
+        {
+            const unsigned ut = utile[u];
+            const int nx = (int)(ut >> 22), k = job - upre[u];
+            ty = (int)((ut >> 10) & 4095u) + k / nx;
+            tx = (int)(ut & 1023u) + k - (k / nx) * nx;
+        }
+        const size_t slot = (size_t)job;
+        const int r = lane >> 3, c4 = (lane & 7) * 4;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        VbRegion rg;  // tile + 1-pixel halo, inside the image
+        rg.x0 = max(rx0, 0);
+        rg.y0 = max(ry0, 0);
+        rg.x1 = min(rx0 + VB_RW - 1, W - 1);
+        rg.y1 = min(ry0 + VB_RH - 1, H - 1);
+        const int myq = (r + 1) * VB_RW + (c4 + 1);
+        const float4* const pv = posc + (size_t)b * V;
+        int nitems = 0;       // wave-uniform
+        int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
+        bool drawn = false;   // wave-uniform: some triangle's box touches the region
+        // ---- coverage + depth of this link inside the region: cull clusters, then triangles, rasterize into LDS
+        VB_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
+        }
+        VB_WAVE_SYNC();
+        {
+            const int c0 = lcoff[l], c1 = lcoff[l + 1];
+            const uint2* const cb = rc.cbox + (size_t)b * cl.NC;
+            const unsigned rlo = (unsigned)rg.x0 | ((unsigned)rg.y0 << 16), rhi = (unsigned)rg.x1 | ((unsigned)rg.y1 << 16);
+            // Survivors of the triangle-box test are queued (record slots) until 64 are waiting, so that every round of
+            // the rasterizer is full; the triangle boxes of up to four candidate clusters are fetched per round trip.
+            const size_t vbase = (size_t)b * cl.NC * 64;
+            int qh = 0, qn = 0;  // wave-uniform ring state
+            drawn = false;
+            for (int cbase = c0; cbase < c1; cbase += 64) {
+                const int c = cbase + lane;
+                bool hit = false;
+                if (c < c1) {
+                    const uint2 bx = cb[c];
+                    hit = (bx.x & 0xffffu) <= (rhi & 0xffffu) && (bx.y & 0xffffu) >= (rlo & 0xffffu) &&
+                          (bx.x >> 16) <= (rhi >> 16) && (bx.y >> 16) >= (rlo >> 16);
+                }
+                u64 cm = __ballot(hit);
+                VB_PHASE(1);  // cluster box culling
+                while (cm) {  // wave-uniform
+                    int cc[4];
+                    uint2 tb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        cc[k] = -1;
+                        tb[k] = VB_BOX_EMPTY;
+                        if (cm) {
+                            cc[k] = cbase + __ffsll((unsigned long long)cm) - 1;
+                            cm &= cm - 1;
+                            tb[k] = rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (cc[k] < 0) continue;  // wave-uniform
+                        const bool sv = (tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
+                                        (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16);
+                        const u64 sm = __ballot(sv);
+                        if (!sm) continue;
+                        if (sv) S.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(cc[k] * 64 + lane);
+                        qn += __popcll(sm);
+                        drawn = true;
+                        VB_PHASE(7);  // triangle box culling
+                        if (qn >= 64) {
+                            VB_WAVE_SYNC();
+                            vb_raster_round(true, vbase + S.sq[(qh + lane) & 127], rc, rg, rx0, ry0, W, H, S.u.R, S.key, ph_acc, ph_last);
+                            qh = (qh + 64) & 127;
+                            qn -= 64;
+                        }
+                    }
+                }
+            }
+            if (qn) {
+                VB_WAVE_SYNC();
+                const bool sv = lane < qn;
+                vb_raster_round(sv, vbase + (sv ? S.sq[(qh + lane) & 127] : 0u), rc, rg, rx0, ry0, W, H, S.u.R, S.key, ph_acc, ph_last);
+            }
+        }
+        if (!drawn) {  // the link's box touches this tile, its triangles do not
+            if (lane == 0) jn[slot] = -1;
+            continue;
+        }
+        VB_WAVE_SYNC();
+        VB_PHASE(1);
+        for (int i = lane; i < 2 * VB_RN; i += 64) S.u.Z.pairA[i] = 0.f;  // aliases the raster scratch
+        // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
+        u64 Iw[VB_WORDS];
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
+            const int x = rx0 + qx, y = ry0 + qy;
+            Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
+        }
+        u64 Vh[VB_WORDS], Vv[VB_WORDS];
+        {
+            // compile-time bitmaps (forced: a constexpr call with a loop index is otherwise evaluated at run time)
+            constexpr u64 KH[VB_WORDS] = {vb_word_h(0), vb_word_h(1), vb_word_h(2), vb_word_h(3), vb_word_h(4), vb_word_h(5)};
+            constexpr u64 KV[VB_WORDS] = {vb_word_v(0), vb_word_v(1), vb_word_v(2), vb_word_v(3), vb_word_v(4), vb_word_v(5)};
+            static_assert(VB_WORDS == 6, "tables above");
+            u64 s1[VB_WORDS], s34[VB_WORDS];
+            vb_shr<1>(Iw, s1);
+            vb_shr<VB_RW>(Iw, s34);
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                Vh[k] = Iw[k] & s1[k] & KH[k];
+                Vv[k] = Iw[k] & s34[k] & KV[k];
+            }
+        }
+        u64 C[VB_WORDS];
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            C[k] = __ballot(i < (unsigned)VB_RN && S.key[i] != VB_EMPTY);
+        }
+        // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
+        //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
+        u64 Hw[2 * VB_WORDS];
+        int nh = 0;
+        {
+            u64 s1[VB_WORDS], s34[VB_WORDS];
+            vb_shr<1>(C, s1);
+            vb_shr<VB_RW>(C, s34);
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                Hw[k] = (C[k] ^ s1[k]) & Vh[k];
+                Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
+                nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
+            }
+        }
+        VB_WAVE_SYNC();
+        float val[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) val[j] = (KT(myq + j) != 0xffffffffu) ? 1.f : 0.f;
+        if (dbg & 2) nh = 0;
+        if (nh != 0) {
+            // ---- dense hit list, ordered by (direction, region index)
+            {
+                int base = 0;
+#pragma unroll
+                for (int s = 0; s < 2 * VB_WORDS; s++) {
+                    const u64 w = Hw[s];
+                    if (w) {
+                        if ((w >> lane) & 1)
+                            S.u.Z.hits[base + vb_mbcnt(w)] = (unsigned short)(((s % VB_WORDS) * 64 + lane) | ((s / VB_WORDS) << 15));
+                        base += __popcll(w);
+                    }
+                }
+            }
+            VB_WAVE_SYNC();
+            // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
+            for (int hbase = 0; hbase < nh; hbase += 64) {
+                const int h = hbase + lane;
+                VbItem it;
+                it.packed = 0;
+                it.v1 = 0;
+                it.v2 = 0;
+                it.alpha = 0.f;
+                bool keep = false;
+                if (h < nh) {
+                    const int hq = S.u.Z.hits[h];
+                    const int d = hq >> 15, q = hq & 0x7fff;
+                    const int qy = q / VB_RW, qx = q - qy * VB_RW;
+                    const int nq = q + (d ? VB_RW : 1);
+                    const unsigned k0 = KT(q), k1 = KT(nq);
+                    const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
+                    const int t = (int)(chose0 ? k0 : k1);
+                    int px = rx0 + qx, py = ry0 + qy;
+                    if (!chose0) {
+                        px += 1 - d;
+                        py += d;
+                    }
+                    float4 p[3], o[3];
+                    const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
+                    const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
+                    const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
+                    if (a.found) {
+                        S.u.Z.pairA[d * VB_RN + q] = a.alpha;
+                        // keep for the backward pass if the destination pixel is interior to this tile
+                        const int oq = (a.alpha > 0.f) ? q : nq;
+                        const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+                        const bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
+                        if (oi && a.alpha != 0.f) {
+                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
+                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
+                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
+                            it.alpha = a.alpha;
+                            keep = want_grad != 0;
+                        }
+                    }
+                }
+                const u64 km = __ballot(keep);
+                if (km) {
+                    const int at = nitems + vb_mbcnt(km);
+                    const int nnew = nitems + __popcll(km);
+                    if (nnew > VB_JOB_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this job
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
+                        spill_base = __builtin_amdgcn_readfirstlane(base);
+                    }
+                    if (keep) {
+                        if (at < VB_JOB_ITEMS) {
+                            jitems[slot * VB_JOB_ITEMS + at] = it;
+                        } else {
+                            const int gi = at - VB_JOB_ITEMS;
+                            if (gi < VB_SPILL_BLOCK && spill_base + gi < spill_cap)
+                                spill[spill_base + gi] = it;
+                            else
+                                meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
+                        }
+                    }
+                    nitems = min(nnew, VB_JOB_ITEMS + VB_SPILL_BLOCK);
+                }
+            }
+            VB_WAVE_SYNC();
+            // ---- gather the antialiased value of this link at my pixels (fixed order: down, left, right, up pair)
+            {
+                float cn[6], cd[4], cu[4];
+#pragma unroll
+                for (int j = 0; j < 6; j++) cn[j] = (KT(myq - 1 + j) != 0xffffffffu) ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    cd[j] = (KT(myq - VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                    cu[j] = (KT(myq + VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float c = cn[j + 1];
+                    float v = c;
+                    float a;
+                    a = S.u.Z.pairA[VB_RN + myq + j - VB_RW];
+                    if (a < 0.f) v += a * (c - cd[j]);
+                    a = S.u.Z.pairA[myq + j - 1];
+                    if (a < 0.f) v += a * (c - cn[j]);
+                    a = S.u.Z.pairA[myq + j];
+                    if (a > 0.f) v += a * (cn[j + 2] - c);
+                    a = S.u.Z.pairA[VB_RN + myq + j];
+                    if (a > 0.f) v += a * (cu[j] - c);
+                    val[j] = v;
+                }
+            }
+        }
+        VB_PHASE(5);  // pairs, analysis, gather
+        // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
+        const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
+        if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
+        if (lane == 0) {
+            jn[slot] = nz ? nitems : -1;
+            if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
+        }
+        VB_WAVE_SYNC();
+        VB_PHASE(6);  // publish
+    }
+#ifdef VB_PHASE_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 8; i++)
+            if (ph_acc[i]) atomicAdd((unsigned long long*)(meta + 8) + i, (unsigned long long)ph_acc[i]);
+#endif
+#undef KT
+}
+
+// Stage 3: one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers): sums the links'
+// values in link order, clamps, accumulates the frame loss, writes the mask, and back-propagates the tile's blended
+// pairs to 12 numbers per link which go to the view's fixed-point accumulators.  Tiles no link box touches just stream
+// (mask = 0, loss += ref^2).  vec_ok: W % 4 == 0 and 16-byte aligned images.
+__global__ void __launch_bounds__(256)
+vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const float* __restrict__ verts,
+                    const int* __restrict__ lbox, const int* __restrict__ jn, const float* __restrict__ jval,
+                    const VbItem* __restrict__ jitems, const int* __restrict__ jspill, const int* __restrict__ jbase,
+                    int jcap, const float* __restrict__ ref,
+                    float* __restrict__ mask, long long* __restrict__ facc, int nls, int want_grad, int vec_ok,
+                    const VbItem* __restrict__ spill, int* __restrict__ meta, int dbg) {
+    __shared__ float gpix_all[4][EHR_TILE_W * EHR_TILE_H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* const gpix = gpix_all[wave];
+    const int W = g.W, H = g.H, L = g.L;
+    // XCD-aware order (locality only): every XCD takes a contiguous run of tiles
+    const int nwg = gridDim.x, per = (nwg + 7) >> 3;
+    const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int gw = wg * 4 + wave;  // (view, tile)
+    if (wg >= nwg || gw >= B * g.nt) return;
+    const int b = gw / g.nt, tile = gw - b * g.nt;
+    const int tx = tile % g.ntx, ty = tile / g.ntx;
+    const int acc_stride = 12 * L + nls;
+    long long* const vacc = facc + (size_t)b * acc_stride;
+    long long* const lacc = vacc + 12 * L + (tile % nls);
+
+    const int r = lane >> 3, c4 = (lane & 7) * 4;
+    const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
+    const bool row_in = iy < H;
+    const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
+    float rf[4] = {0.f, 0.f, 0.f, 0.f};
+    bool pin[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pin[j] = row_in && (ix + j) < W;
+    if (vec_ok) {
+        if (pin[0]) {
+            const float4 r4 = *reinterpret_cast<const float4*>(ref + im);
+            rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (pin[j]) rf[j] = ref[im + j];
+    }
+    const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+    // links whose screen box touches the tile + halo region (lane l tests link l): exactly the jobs stage 2 ran
+    unsigned tmask;
+    int myn = -1, myslot = 0;
+    {
+        const int gx0 = max(rx0, 0), gy0 = max(ry0, 0), gx1 = min(rx0 + VB_RW - 1, W - 1), gy1 = min(ry0 + VB_RH - 1, H - 1);
+        if (lane < L) {
+            const int* bx = lbox + VB_LBOX_STRIDE * ((size_t)b * L + lane);
+            const bool hit = bx[0] <= gx1 && bx[2] >= gx0 && bx[1] <= gy1 && bx[3] >= gy0;
+            if (hit && !(dbg & 1)) {
+                int tx0, ty0, nx, ny;
+                vb_unit_tiles(bx, W, H, tx0, ty0, nx, ny);
+                myslot = jbase[b * L + lane] + (ty - ty0) * nx + (tx - tx0);
+                if (myslot < jcap) myn = jn[myslot];
+            }
+        }
+        tmask = (unsigned)__ballot(myn >= 0);  // links that contribute a value here
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned todo = tmask;
+    while (todo) {  // sum in link order
+        const int l = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const size_t slot = (size_t)vb_readlane(myslot, l);
+        const float4 v4 = *reinterpret_cast<const float4*>(jval + slot * 256 + r * EHR_TILE_W + c4);
+        acc[0] += v4.x;
+        acc[1] += v4.y;
+        acc[2] += v4.z;
+        acc[3] += v4.w;
+    }
+    // ---- composite, loss, mask write (image convention: row 0 = top)
+    float e2 = 0.f, gv[4];
+    float mv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        gv[j] = 0.f;
+        mv[j] = 0.f;
+        if (pin[j]) {
+            const float m = acc[j] > 1.f ? 1.f : acc[j];
+            const float e = m - rf[j];
+            e2 += e * e;
+            gv[j] = (acc[j] <= 1.f) ? 2.f * e : 0.f;
+            mv[j] = m;
+        }
+    }
+    if (mask) {
+        if (vec_ok) {
+            if (pin[0]) *reinterpret_cast<float4*>(mask + im) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (pin[j]) mask[im + j] = mv[j];
+        }
+    }
+    {
+        const float s = wave_sum(e2);
+        if (lane == 0) fix_add(lacc, s, meta);
+    }
+    const unsigned bmask = (unsigned)__ballot(myn > 0);  // links with blended pairs to back-propagate
+    if (!want_grad || bmask == 0 || (dbg & 4)) return;
+
+    // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
+    const float4* const pv = posc + (size_t)b * V;
+#pragma unroll
+    for (int j = 0; j < 4; j++) gpix[r * EHR_TILE_W + c4 + j] = gv[j];
+    VB_WAVE_SYNC();
+    unsigned links = bmask;
+    while (links) {
+        const int l = __ffs(links) - 1;
+        links &= links - 1;
+        const size_t slot = (size_t)vb_readlane(myslot, l);
+        const int n = vb_readlane(myn, l);
+        const int sbase = (n > VB_JOB_ITEMS) ? jspill[slot] : 0;
+        float G[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) G[k] = 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const VbItem itm = (i < VB_JOB_ITEMS) ? jitems[slot * VB_JOB_ITEMS + i] : spill[sbase + (i - VB_JOB_ITEMS)];
+            const int q = itm.packed & 1023, d = (itm.packed >> 10) & 1;
+            const int tri1 = (itm.packed >> 13) & 1;
+            const float dc = ((itm.packed >> 14) & 1) ? 1.f : -1.f;
+            const int nq = q + (d ? VB_RW : 1);
+            const int oq = (itm.alpha > 0.f) ? q : nq;
+            const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+            const float gi = gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
+            const float dd = gi * dc;
+            if (gi == 0.f || dd == 0.f) continue;
+            const int qy = q / VB_RW, qx = q - qy * VB_RW;
+            int px = rx0 + qx, py = ry0 + qy;
+            if (tri1) {
+                px += 1 - d;
+                py += d;
+            }
+            float g1[3], g2[3];
+            aa_pos_grad(pv[itm.v1], pv[itm.v2], px, py, d, itm.alpha, dd, W, H, g1, g2);
+            const float* a1 = verts + 3 * (size_t)itm.v1;
+            const float* a2 = verts + 3 * (size_t)itm.v2;
+            const float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) G[4 * rr + c] += g1[rr] * h1[c] + g2[rr] * h2[c];
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const float s = wave_sum(G[k]);
+            if (lane == k) mine = s;
+        }
+        if (lane < 12) fix_add(&vacc[12 * l + lane], mine, meta);
+    }
+}
+
+// [T][3] int32 -> [T] int4 (one aligned 16-byte gather per triangle in the silhouette analysis)
+__global__ void vb_pad_kernel(const int32_t* __restrict__ a, int T, int4* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T) out[t] = make_int4(a[3 * t], a[3 * t + 1], a[3 * t + 2], 0);
+}
+
+}  // namespace ehr
+using namespace ehr;
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+
+static inline unsigned vb_spread10(unsigned v) {  // 10 bits -> every third bit
+    v &= 1023u;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+// Static acceleration index of a scene: per link, the triangles sorted along a Morton curve of their centroids (object
+// space, so it holds for every pose) and cut into clusters of 64.  Triangle ids stay the caller's: depth ties and the
+// antialias topology are unaffected.
+static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* verts, const int32_t* tris,
+                             const int32_t* tri_link) {
+    std::vector<float> hv((size_t)3 * std::max(V, 1));
+    std::vector<int32_t> ht((size_t)3 * std::max(T, 1)), hl((size_t)std::max(T, 1));
+    if (V > 0) EHR_HIP(hipMemcpy(hv.data(), verts, (size_t)3 * V * sizeof(float), hipMemcpyDeviceToHost));
+    if (T > 0) {
+        EHR_HIP(hipMemcpy(ht.data(), tris, (size_t)3 * T * sizeof(int32_t), hipMemcpyDeviceToHost));
+        EHR_HIP(hipMemcpy(hl.data(), tri_link, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    std::vector<int32_t> ctri, clink, coff((size_t)L + 1, 0);
+    std::vector<float> aabb((size_t)6 * L);
+    for (int l = 0; l < L; l++)
+        for (int k = 0; k < 3; k++) {
+            aabb[6 * (size_t)l + k] = 3.4e38f;
+            aabb[6 * (size_t)l + 3 + k] = -3.4e38f;
+        }
+    int t = 0;
+    for (int l = 0; l < L; l++) {
+        coff[l] = (int32_t)clink.size();
+        const int t0 = t;
+        while (t < T && hl[t] == l) t++;
+        if (t < T && hl[t] < l) return fail(EHR_ERR_INVALID, "ehr_fused_plan: tri_link must be sorted by link");
+        const int n = t - t0;
+        if (n == 0) continue;
+        std::vector<float> cen((size_t)3 * n);
+        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                float c = 0.f;
+                for (int j = 0; j < 3; j++) {
+                    const int v = ht[3 * (size_t)(t0 + i) + j];
+                    const float x = ((unsigned)v < (unsigned)V) ? hv[3 * (size_t)v + k] : 0.f;
+                    c += x;
+                    if ((unsigned)v < (unsigned)V) {
+                        aabb[6 * (size_t)l + k] = std::min(aabb[6 * (size_t)l + k], x);
+                        aabb[6 * (size_t)l + 3 + k] = std::max(aabb[6 * (size_t)l + 3 + k], x);
+                    }
+                }
+                c *= (1.f / 3.f);
+                if (!(c == c)) c = 0.f;
+                cen[3 * (size_t)i + k] = c;
+                lo[k] = std::min(lo[k], c);
+                hi[k] = std::max(hi[k], c);
+            }
+        std::vector<std::pair<unsigned, int>> order((size_t)n);
+        for (int i = 0; i < n; i++) {
+            unsigned code = 0;
+            for (int k = 0; k < 3; k++) {
+                const float ext = hi[k] - lo[k];
+                float f = ext > 0.f ? (cen[3 * (size_t)i + k] - lo[k]) / ext : 0.f;
+                f = std::min(std::max(f, 0.f), 1.f);
+                code |= vb_spread10((unsigned)(f * 1023.f)) << k;
+            }
+            order[i] = std::make_pair(code, t0 + i);
+        }
+        std::sort(order.begin(), order.end());
+        for (int i = 0; i < n; i++) {
+            if ((i & 63) == 0) clink.push_back(l);
+            ctri.push_back(order[i].second);
+        }
+        while (ctri.size() & 63) ctri.push_back(-1);
+    }
+    if (t != T) return fail(EHR_ERR_INVALID, "ehr_fused_plan: tri_link holds a link outside [0, %d) or is not sorted", L);
+    coff[L] = (int32_t)clink.size();
+    const int NC = (int)clink.size();
+    ctx->vb_nc = NC;
+    int rc;
+    const size_t n_ctri = (size_t)std::max(NC, 1) * 64;
+    if ((rc = ctx->vb_clus.reserve((n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) * sizeof(int32_t)))) return rc;
+    int32_t* d = (int32_t*)ctx->vb_clus.ptr;
+    if (NC > 0) {
+        EHR_HIP(hipMemcpy(d, ctri.data(), (size_t)NC * 64 * sizeof(int32_t), hipMemcpyHostToDevice));
+        EHR_HIP(hipMemcpy(d + n_ctri, clink.data(), (size_t)NC * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    EHR_HIP(hipMemcpy(d + n_ctri + std::max(NC, 1), coff.data(), ((size_t)L + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    EHR_HIP(hipMemcpy(d + n_ctri + std::max(NC, 1) + L + 1, aabb.data(), aabb.size() * sizeof(float), hipMemcpyHostToDevice));
+    return EHR_OK;
+}
+
+int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
+                   const int32_t* tris, const int32_t* tri_link, const int32_t* opp) {
+    if (H > 32767 || W > 32767) return fail(EHR_ERR_INVALID, "ehr_fused_plan: resolution above 32767 is unsupported");
+    if ((V > 0 && !verts) || (T > 0 && (!tris || !tri_link || !opp)))
+        return fail(EHR_ERR_INVALID, "ehr_fused_plan: the scene arrays (verts, tris, tri_link, opp) are required");
+    int rc;
+    if ((rc = vb_build_clusters(ctx, L, V, T, verts, tris, tri_link))) return rc;
+    const int NC = std::max(ctx->vb_nc, 1);
+    if ((rc = ctx->vb_acc.reserve(((size_t)B * (12 * (size_t)L + VB_LOSS_SLOTS)) * sizeof(long long) + EHR_META_INTS * sizeof(int)))) return rc;
+    if ((rc = ctx->vb_posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
+    // per step and (view, cluster slot): tdep 48 B | trec 32 B | tbox 8 B, then cbox 8 B per (view, cluster)
+    if ((rc = ctx->vb_boxes.reserve((size_t)B * NC * (64 * 88 + 8)))) return rc;
+    if ((rc = ctx->vb_spill.reserve((size_t)VB_SPILL_ITEMS * sizeof(VbItem)))) return rc;
+    if ((rc = ctx->vb_units.reserve((size_t)VB_LBOX_STRIDE * B * L * sizeof(int)))) return rc;
+    {  // job slots, compact (numbered like the jobs): value tile 1 KB | items 1 KB | count | spill base; then the links' first jobs
+        BinGeom g = make_geom(H, W, L);
+        // a job = a (link, tile) pair whose boxes touch: `slack` tiles-worth of links per view (default 4 = every pixel
+        // under four link boxes), never more than all of them
+        (void)slack;  // every (view, link, tile) can have its slot: nothing to overflow
+        const double want = (double)L * (double)B * g.nt;
+        if (want > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles exceeds 2e9");
+        ctx->vb_jcap = (int)want;
+        const size_t nslot = (size_t)ctx->vb_jcap;
+        if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + 2 * sizeof(int)) +
+                                       (size_t)B * L * sizeof(int)))) return rc;
+    }
+    if ((rc = ctx->vb_idx.reserve((size_t)2 * std::max(T, 1) * sizeof(int4)))) return rc;
+    if (T > 0) {
+        vb_pad_kernel<<<(T + 255) / 256, 256>>>(tris, T, (int4*)ctx->vb_idx.ptr);
+        vb_pad_kernel<<<(T + 255) / 256, 256>>>(opp, T, (int4*)ctx->vb_idx.ptr + T);
+        EHR_LAUNCH_CHECK();
+    }
+    ctx->vb_plan_tris = tris;
+    ctx->vb_plan_opp = opp;
+    EHR_HIP(hipMemset(ctx->vb_acc.ptr, 0, ctx->vb_acc.cap));
+    std::vector<int> boxes((size_t)VB_LBOX_STRIDE * B * L);  // link boxes start "empty"; the finish kernel re-arms them
+    for (size_t i = 0; i < boxes.size(); i++) boxes[i] = (i & 2) ? INT_MIN : INT_MAX;
+    EHR_HIP(hipMemcpy(ctx->vb_units.ptr, boxes.data(), boxes.size() * sizeof(int), hipMemcpyHostToDevice));
+    EHR_HIP(hipDeviceSynchronize());
+    return EHR_OK;
+}
+
+int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
+    const size_t off = (size_t)ctx->pB * (12 * (size_t)ctx->pL + VB_LOSS_SLOTS) * sizeof(long long);
+    EHR_HIP(hipMemcpy(meta4, (char*)ctx->vb_acc.ptr + off, 4 * sizeof(int), hipMemcpyDeviceToHost));
+    if (getenv("EHR_VB_PRINT")) {  // diagnostics
+        int m8[8];
+        EHR_HIP(hipMemcpy(m8, (char*)ctx->vb_acc.ptr + off, sizeof(m8), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ehr vbuf] overflow %d spill %d jobs %d\n", m8[EHR_META_OVERFLOW], m8[EHR_META_SPILL], m8[5]);
+        int cur[8];
+        EHR_HIP(hipMemcpy(cur, (char*)ctx->vb_acc.ptr + off + 32 * sizeof(int), sizeof(cur), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ehr vbuf] job cursors %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
+#ifdef VB_PHASE_TIMING
+        unsigned long long ph[9];
+        EHR_HIP(hipMemcpy(ph, (char*)ctx->vb_acc.ptr + off + 8 * sizeof(int), sizeof(ph), hipMemcpyDeviceToHost));
+        const char* names[8] = {"job prologue", "cluster culling", "records+staging", "prefix+search", "walk+depth", "resolve", "publish", "triangle culling"};
+
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; i++) tot += ph[i];
+        for (int i = 0; i < 8; i++)
+            fprintf(stderr, "[ehr phase] %-16s %14llu cycles %5.1f %%\n", names[i], ph[i], tot ? 100.0 * ph[i] / tot : 0.0);
+        EHR_HIP(hipMemset((char*)ctx->vb_acc.ptr + off + 8 * sizeof(int), 0, sizeof(ph)));
+#endif
+    }
+    return EHR_OK;
+}
+
+int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
+                    const int32_t* vert_link, const int32_t* opp, float* mvp, const float* ref, int B, int L, int V,
+                    int T, int H, int W, float* mask, float* loss, float* grad_mvp, const StepHead* head,
+                    const StepTail* tail, hipStream_t stream) {
+    (void)tri_link;
+    if (tris != ctx->vb_plan_tris || opp != ctx->vb_plan_opp)
+        return fail(EHR_ERR_INVALID, "fused op: the scene arrays differ from the planned ones; call ehr_fused_plan again");
+    BinGeom g = make_geom(H, W, L);
+    const int ntiles = B * g.nt;
+    long long* facc = (long long*)ctx->vb_acc.ptr;
+    const int acc_stride = 12 * L + VB_LOSS_SLOTS, nacc_ints = 2 * B * acc_stride;
+    int* meta = (int*)(facc + (size_t)B * acc_stride);
+    float4* posc = (float4*)ctx->vb_posc.ptr;
+    int* lbox = (int*)ctx->vb_units.ptr;
+    VbItem* spill = (VbItem*)ctx->vb_spill.ptr;
+    const int NC = ctx->vb_nc, NC1 = std::max(NC, 1);
+    VbClusters cl;
+    cl.ctri = (const int32_t*)ctx->vb_clus.ptr;
+    cl.clink = cl.ctri + (size_t)NC1 * 64;
+    cl.coff = cl.clink + NC1;
+    cl.laabb = (const float*)(cl.coff + L + 1);
+    cl.NC = NC;
+    VbRecs recs;
+    recs.n = (size_t)B * NC1 * 64;
+    recs.tdep = (float4*)ctx->vb_boxes.ptr;
+    recs.trec = (int4*)(recs.tdep + recs.n * 3);
+    recs.tbox = (uint2*)(recs.trec + recs.n * 2);
+    recs.cbox = recs.tbox + recs.n;
+
+    hipEvent_t* ev = nullptr;
+    if (ctx->timing) {
+        const size_t need = ctx->ev_used + EHR_FUSED_STAGES + 1;
+        while (ctx->ev.size() < need) {
+            hipEvent_t e;
+            EHR_HIP(hipEventCreate(&e));
+            ctx->ev.push_back(e);
+        }
+        ev = ctx->ev.data() + ctx->ev_used;
+        ctx->ev_used = need;
+        EHR_HIP(hipEventRecord(ev[0], stream));
+    }
+    const int vec_ok = ((W & 3) == 0) && (((uintptr_t)ref & 15) == 0) && (!mask || ((uintptr_t)mask & 15) == 0);
+    // stage 0: [pose forward] + vertices + screen boxes
+    const int nvb = (std::max(V, 1) + 255) / 256;
+    const int gx = nvb + (NC + 3) / 4;
+    static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
+    const int xcd_views = (xcd_align && (B % 8) == 0) ? B / 8 : 0;
+    const dim3 vgrid(gx * B);
+    if (head) {
+        vb_vertex_kernel<true><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, *head, mvp, V, nvb, g, posc, recs,
+                                                         lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views);
+    } else {
+        StepHead none = {};
+        vb_vertex_kernel<false><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, none, mvp, V, nvb, g, posc, recs,
+                                                          lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views);
+    }
+    EHR_LAUNCH_CHECK();
+    if (ev) EHR_HIP(hipEventRecord(ev[1], stream));
+    // stage 1: jobs = (view, link, tile) -> per-link values and blended pairs
+    static const int dbg = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;  // measurement aid only
+    static const int job_grid = getenv("EHR_VB_JOB_GRID") ? atoi(getenv("EHR_VB_JOB_GRID")) : 4;   // tuning knob
+    const size_t nslot = (size_t)ctx->vb_jcap;
+    float* jval = (float*)ctx->vb_jobs.ptr;
+    VbItem* jitems = (VbItem*)(jval + nslot * 256);
+    int* jn = (int*)(jitems + nslot * VB_JOB_ITEMS);
+    int* jspill = jn + nslot;
+    int* jbase = jspill + nslot;
+    vb_job_kernel<<<((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7, 256, 0, stream>>>(
+        g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T, cl, recs, lbox, jn, jval, jitems, jspill, jbase, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
+        VB_SPILL_ITEMS, meta, dbg);
+    EHR_LAUNCH_CHECK();
+    if (ev) {
+        for (int k = 2; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
+    }
+    // stage 2: composite, loss, mask, backward
+    int nwg = (ntiles + 3) / 4;
+    nwg = (nwg + 7) & ~7;  // a multiple of 8 keeps the XCD remap a bijection
+    vb_composite_kernel<<<nwg, 256, 0, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, ctx->vb_jcap, ref, mask,
+                                                 facc,
+                                                 VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, meta, dbg);
+    EHR_LAUNCH_CHECK();
+    if (ev) {
+        EHR_HIP(hipEventRecord(ev[5], stream));
+        EHR_HIP(hipEventRecord(ev[6], stream));
+    }
+    // stage 2: accumulators -> loss / grad_mvp (+ pose backward and Adam in the solver-step form), one workgroup;
+    // it also re-arms the link boxes for the next step
+    if (tail) {
+        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail, VB_LOSS_SLOTS, lbox);
+    } else {
+        StepTail none = {};
+        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none, VB_LOSS_SLOTS, lbox);
+    }
+    EHR_LAUNCH_CHECK();
+    if (ev) EHR_HIP(hipEventRecord(ev[7], stream));
+    return EHR_OK;
+}

@@ -51,7 +51,7 @@ class FusedPoseStep:
         self.loss = torch.zeros((1,), device=dev)
         self.grad = torch.zeros((6,), device=dev)
         self.mask = torch.empty((self.B, self.H, self.W), device=dev)
-        fused._ensure_plan(self.glctx, self.B, self.L, self.scene.num_verts, self.scene.num_tris, self.H, self.W)
+        fused._ensure_plan(self.glctx, self.scene, self.B, self.H, self.W)
         self._graph = None
 
     # -- one step -------------------------------------------------------------------------------------------------

@@ -46,17 +46,23 @@ class LinkScene:
 class _Plan:
     """Per-context plan for one (B, L, T, H, W) shape: sizes the ctx scratch once so the hot call never allocates."""
 
-    def __init__(self, glctx, B, L, V, T, H, W, slack=4.0):
-        self.key = (B, L, V, T, H, W)
+    def __init__(self, glctx, scene, B, H, W, slack=4.0):
+        self.key = _plan_key(scene, B, H, W)
         with torch.cuda.device(glctx.device):
-            _lib.check(_lib.lib().ehr_fused_plan(glctx.handle, B, L, V, T, H, W, ctypes.c_float(slack)),
-                       "ehr_fused_plan")
+            _lib.check(_lib.lib().ehr_fused_plan(glctx.handle, B, scene.num_links, scene.num_verts, scene.num_tris, H, W,
+                                                 ctypes.c_float(slack), _lib.ptr(scene.verts), _lib.ptr(scene.tris),
+                                                 _lib.ptr(scene.tri_link), _lib.ptr(scene.opp)), "ehr_fused_plan")
 
 
-def _ensure_plan(glctx, B, L, V, T, H, W):
+def _plan_key(scene, B, H, W):
+    # the plan also holds a static index of the scene's triangles, so it is tied to the scene's buffers
+    return (B, H, W, scene.num_links, scene.num_verts, scene.num_tris, scene.verts.data_ptr(), scene.tris.data_ptr())
+
+
+def _ensure_plan(glctx, scene, B, H, W):
     plan = getattr(glctx, "_plan", None)
-    if plan is None or plan.key != (B, L, V, T, H, W):
-        glctx._plan = _Plan(glctx, B, L, V, T, H, W)
+    if plan is None or plan.key != _plan_key(scene, B, H, W):
+        glctx._plan = _Plan(glctx, scene, B, H, W)
 
 
 def check_status(glctx):
@@ -82,7 +88,7 @@ class _RenderMaskLoss(torch.autograd.Function):
     def forward(ctx, glctx, scene, mvp, ref, want_mask):
         B, L = mvp.shape[0], mvp.shape[1]
         H, W = ref.shape[1], ref.shape[2]
-        _ensure_plan(glctx, B, L, scene.num_verts, scene.num_tris, H, W)
+        _ensure_plan(glctx, scene, B, H, W)
         mask = torch.empty((B, H, W), dtype=torch.float32, device=mvp.device) if want_mask else None
         loss = torch.empty((B,), dtype=torch.float32, device=mvp.device)
         need_grad = mvp.requires_grad

@@ -97,7 +97,8 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  * captured in a hipGraph.  If a bin queue overflows at run time, loss[] is set to NaN (never a silently wrong
  * image) and ehr_fused_status() returns EHR_ERR_OVERFLOW after the stream is synchronised; re-plan with a larger
  * `slack`. */
-int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack);
+int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
+                   const int32_t* tris, const int32_t* tri_link, const int32_t* opp);
 int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
                          const int32_t* vert_link, const int32_t* opp, const float* mvp, const float* ref, int B,
                          int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream);

@@ -179,9 +179,11 @@ def test_full_size_properties(env, xarm7):
     assert np.abs(np.minimum(s, 1.0) - mask[:2])[ok].max() <= 2.4e-7
 
 
-def test_overflow_is_reported_not_silent(env, xarm7):
-    """More blended pairs in one tile than its LDS list holds (a pathological checkerboard of pixel-sized quads in
-    every one of 10 links): the loss becomes NaN and the status call raises -- never a silently wrong gradient."""
+def test_overflow_is_reported_not_silent(env, oracle, xarm7):
+    """A pathological checkerboard of pixel-sized quads in every one of 10 links (four blended pairs per covered
+    pixel, 10 links deep in one tile).  Round 1's per-tile LDS list overflowed here (reported NaN); the per-job item
+    slots + spill pool of the visibility-buffer chain hold it, so the result must now simply equal the oracle's.  The
+    limits that remain (fixed-point accumulator range) still fail loudly: second half of the test."""
     fused, _, _, dev = env
     from easyhec_amd import dr
     H, W, L = 8, 32, 10
@@ -200,19 +202,20 @@ def test_overflow_is_reported_not_silent(env, xarm7):
         fs.append(np.array(f, np.int32))
     ctx2 = dr.RasterizeCudaContext()
     scene = fused.LinkScene(vs, fs, dev)
-    mvp = torch.eye(4, device=dev)[None, None].repeat(1, L, 1, 1).contiguous().requires_grad_(True)
-    mask, loss = fused.render_mask_loss(ctx2, scene, mvp, torch.zeros((1, H, W), device=dev))
-    torch.cuda.synchronize()
-    assert torch.isnan(loss).all()
-    with pytest.raises(RuntimeError, match="overflow"):
-        fused.check_status(ctx2)
-    # the same scene with 2 links fits and is finite
-    sc2 = fused.LinkScene(vs[:2], fs[:2], dev)
-    ctx3 = dr.RasterizeCudaContext()
-    m2, l2 = fused.render_mask_loss(ctx3, sc2, mvp[:, :2].detach().contiguous().requires_grad_(True),
-                                    torch.zeros((1, H, W), device=dev))
-    assert torch.isfinite(l2).all() and float(m2.max()) <= 1.0
-    fused.check_status(ctx3)
+    mvp_np = np.tile(np.eye(4, dtype=np.float32)[None, None], (1, L, 1, 1))
+    mvp_np[0, :, 3, 3] = 1.0 + 0.01 * np.arange(L)          # distinct w per link: distinct blend weights
+    rng = np.random.default_rng(5)
+    ref = (rng.uniform(size=(1, H, W)) > 0.5).astype(np.float32)
+    verts = np.concatenate(vs)
+    voff = np.cumsum([0] + [len(v) for v in vs]).astype(np.int32)
+    toff = np.cumsum([0] + [len(f) for f in fs]).astype(np.int32)
+    tris = np.concatenate([f + voff[i] for i, f in enumerate(fs)]).astype(np.int32)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(verts, tris, toff, voff, mvp_np, ref)
+    mask, loss, grad = run(fused, ctx2, scene, mvp_np, ref, dev)
+    assert (mask == m_ref).all()
+    assert np.abs(loss - l_ref).max() <= 1e-6 * np.abs(l_ref).max()
+    assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+    fused.check_status(ctx2)
     # the fixed-point accumulators saturate loudly too: the robot scaled by 1e9 (and the clip matrices' first three
     # columns by 1e-9) renders the same picture, but its gradients w.r.t. the matrix entries exceed the representable
     # +-2^31 -> NaN gradient + raised status, never a wrapped sum

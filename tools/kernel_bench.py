@@ -26,3 +26,4 @@ for _ in range(50):
     fused.render_mask_loss(ctx, scene, mvp, ref)
 ms, n = fused.read_timing(ctx)
 print(os.environ.get("EHR_TILE_GRID_MULT", "-"), {k: round(v / n * 1e3, 1) for k, v in ms.items()}, "us per call", flush=True)
+fused.check_status(ctx)
