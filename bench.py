@@ -78,28 +78,64 @@ def build_problem(rank, world, dev, eager=False, graph=True, workload=WORKLOAD):
                 Tc_init=Tc_init, ref=ref, glctx=renderer.glctx, n_views=n_views)
 
 
-def cpu_baseline(p, budget_s=12.0):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(p, budget_s=10.0):
     """The CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on the same 8-view batch
-    at the initial pose, fwd+bwd, OpenMP over views.  Bounded sample: repeats until ~budget_s of wall time."""
+    at the initial pose, fwd+bwd, OpenMP over views: all host cores the oracle can use (`value`) and one thread
+    (`value_1thread`, SURVEY 8d asks for both).  Bounded samples: each leg repeats until ~budget_s of wall time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
     from oracle import oracle
     verts, tris, toff, voff = helpers.scene_arrays(p["robot"])
     mvp = helpers.mvp_numpy(p["K"], p["H"], p["W"], p["Tc_init"], p["link_poses"])
     ref = p["ref"].cpu().numpy()
-    cores = min(oracle.num_threads(), mvp.shape[0])
-    oracle.render_mask_loss(verts, tris, toff, voff, mvp, ref)  # warm-up
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        oracle.render_mask_loss(verts, tris, toff, voff, mvp, ref)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 200:
-            break
-    fps = reps * mvp.shape[0] / el
+    nthreads = oracle.num_threads()
+    cores = min(nthreads, mvp.shape[0])
+
+    def leg(threads, views):
+        oracle.set_num_threads(threads)
+        oracle.render_mask_loss(verts, tris, toff, voff, mvp[:views], ref[:views])  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            oracle.render_mask_loss(verts, tris, toff, voff, mvp[:views], ref[:views])
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or reps >= 200:
+                break
+        return reps * views / el, reps, el
+
+    fps, reps, el = leg(nthreads, mvp.shape[0])
+    fps1, reps1, el1 = leg(1, 1)
+    oracle.set_num_threads(nthreads)
     return {"value": round(fps, 3), "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "sample": f"{reps} x ({mvp.shape[0]} views 1280x720, fwd+bwd) of the same batch at the initial pose, "
-                      f"{el:.1f} s wall, OpenMP over views"}
+            "value_1thread": round(fps1, 3), "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+            "sample": f"{reps} x ({mvp.shape[0]} views 1280x720, fwd+bwd) of the same batch at the initial pose, {el:.1f} s "
+                      f"wall, OpenMP over views ({cores} threads busy); 1-thread leg: {reps1} x 1 view, {el1:.1f} s"}
+
+
+def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
+    """Device-to-device copy rate of this box (read + write bytes per second), the practical HBM ceiling quoted beside
+    the 8 TB/s spec."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -116,13 +152,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU path to time)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    have_gpu = torch.cuda.is_available() and local_rank < torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank) if have_gpu else None
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
     if world > 1:
+        # rendezvous first (127.0.0.1, env:// as the driver launches it): one process per GPU, RCCL ("nccl") over xGMI.
+        # Without a device the group still forms (gloo) so that a mis-launch is reported by every rank, not as a hang.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if have_gpu:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if not have_gpu:
+        msg = (f"bench.py rank {rank}/{world}: no HIP device for LOCAL_RANK={local_rank} "
+               f"({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible) -- the process group formed, "
+               "but there is no CPU path to time (the render path is HIP only)")
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(msg)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from easyhec_amd import fused
@@ -144,10 +193,23 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     fused.check_status(p["glctx"])
+    per_rank_ms, allreduce_us = None, None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [round(float(x.item()) / args.steps * 1e3, 4) for x in allr]
+        elapsed = max(float(x.item()) for x in allr)  # the job is as slow as its slowest rank
+        # the step's ONE collective on its own: 8 floats, latency-bound
+        buf = torch.zeros(8, device=dev)
+        for _ in range(20):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(200):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - ta) / 200 * 1e6
     final_loss = float(tr.last_loss)
 
     # roofline leg: hipEvents around each kernel of the fused op, same K steps again (continuing the optimisation)
@@ -163,17 +225,20 @@ def main():
         frames = p["n_views"] * args.steps
         fps = frames / elapsed
         bytes_frame = algorithmic_bytes_per_frame(p["robot"], p["H"], p["W"])
-        # the dominant kernel, fused_tile_kernel<lean>, bracketed by its own pair of events (compare with rocprofv3's
-        # average for it in profiles/); in production the empty-tile stream and the slow-path instantiation run beside
-        # it on a side stream, so its duration IS the duration of the stage that touches every pixel
-        tile_ms = stage_ms["tile"] / max(ncalls, 1)
+        # the dominant kernel (fused.DOMINANT_KERNEL), bracketed by its own pair of hipEvents on the launch stream
+        # (compare with rocprofv3's average for it in profiles/)
+        tile_ms = stage_ms[fused.DOMINANT_STAGE] / max(ncalls, 1)
         bytes_launch = bytes_frame * p["B"]
         achieved = bytes_launch / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-        traffic = None
+        step_gbs = fps * bytes_frame / 1e9  # SURVEY 8d's own definition: frames/s x bytes_frame (whole step, all kernels)
+        copy_gbs = measured_copy_bandwidth(dev)
+        traffic, traffic_kernel = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_lean_kernel")
+                tj = json.load(open(tpath))
+                traffic = tj.get("hbm_bytes_whole_op")        # PMC-measured HBM bytes of ALL kernels of one step
+                traffic_kernel = tj.get("hbm_bytes_dominant_kernel")
             except Exception:
                 traffic = None
         out = {
@@ -187,12 +252,19 @@ def main():
                        "step": "torch autograd" if args.eager else ("HIP launch chain" + (", hipGraph replay" if tr.fast is not None and args.graph and world == 1 else "")),
                        "parallelism": f"dp{world} over views, one 8-float all-reduce/step" if world > 1 else "single GPU",
                        "final_mask_loss": round(final_loss, 3)},
-            "roofline": {"bound": "hbm", "kernel": "fused_tile_kernel<false>", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": fused.DOMINANT_KERNEL, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": bytes_launch,
-                         "kernel_ms": round(tile_ms, 5),
-                         "stage_ms": {k: round(v / max(ncalls, 1), 5) for k, v in stage_ms.items()}},
+                         # the same algorithmic bytes over the WHOLE step (driver-timed value x bytes_frame): the honest
+                         # figure for "how close is the step to streaming its images once", next to the per-kernel one
+                         "achieved_step": round(step_gbs, 2), "frac_step": round(step_gbs / HBM_PEAK_GBS, 5),
+                         "peak_measured_copy": round(copy_gbs, 1), "frac_step_vs_measured_copy": round(step_gbs / copy_gbs, 5),
+                         "traffic": traffic, "traffic_dominant_kernel": traffic_kernel,
+                         "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": round(tile_ms, 5),
+                         "stage_ms": {k: round(v / max(ncalls, 1), 5) for k, v in stage_ms.items() if not k.startswith("unused")}},
         }
+        if per_rank_ms is not None:
+            out["per_rank_ms_per_step"] = per_rank_ms
+            out["allreduce_8float_us"] = round(allreduce_us, 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p)
         print(json.dumps(out))

@@ -15,11 +15,19 @@ __all__ = ["XarmRealDataset", "collate_all"]
 
 
 def _read_mask(path):
+    """``cv2.imread(path, 2) > 0`` (xarm_real.py:40; flag 2 = IMREAD_ANYDEPTH: one grey channel, 16-bit kept): alpha is
+    dropped, palettes are resolved, colour is reduced with OpenCV's BGR2GRAY fixed-point weights (so a pixel such as
+    (1, 0, 0) is background, as it is for the reference)."""
     from PIL import Image
     with Image.open(path) as im:
+        if im.mode in ("P", "PA"):
+            im = im.convert("RGBA" if "transparency" in im.info or im.mode == "PA" else "RGB")
+        if im.mode in ("RGBA", "LA"):
+            im = im.convert(im.mode[:-1])  # drop alpha
         a = np.asarray(im)
     if a.ndim == 3:
-        a = a.max(axis=2)
+        a = a.astype(np.int64)
+        a = (a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14  # cv::COLOR_RGB2GRAY, 8-bit
     return a > 0
 
 

@@ -38,10 +38,12 @@ class FusedPoseStep:
         self.near, self.far = near, far
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
-        # optimiser state (torch.optim.Adam names)
+        # optimiser state (torch.optim.Adam names).  step_t counts the optimisation steps taken AND is the row of
+        # ``history_ops`` the next step records its pose in (the reference's first all-zero row, rb_solver.py:50-51):
+        # it starts at the model's history cursor so that a solver built on a loaded checkpoint appends.
         self.exp_avg = torch.zeros(6, device=dev)
         self.exp_avg_sq = torch.zeros(6, device=dev)
-        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_t = torch.full((1,), int(model.history_cursor()), dtype=torch.int32, device=dev)
         # work buffers, allocated once
         self.mvp = torch.empty((self.B, self.L, 4, 4), device=dev)
         self.grad_mvp = torch.empty((self.B, self.L, 4, 4), device=dev)
@@ -83,6 +85,7 @@ class FusedPoseStep:
     def step(self, want_mask=False):
         """Enqueue one optimisation step.  Returns the (device, 1-element) mean mask loss evaluated BEFORE the update,
         like ``loss`` in trainer/rbsolver.py:33-41.  Never synchronises."""
+        self.model._hist_n = None  # the chain writes history_ops rows itself: the host cursor is stale from here on
         with torch.cuda.device(self.dev):
             if self._graph and not want_mask:
                 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -125,7 +128,19 @@ class FusedPoseStep:
 
     def state_dict(self):
         """torch.optim.Adam-shaped state for checkpoints (trainer/rbsolver.py:95-114)."""
-        return {"state": {0: {"step": self.step_t.float().clone(), "exp_avg": self.exp_avg.clone(),
-                              "exp_avg_sq": self.exp_avg_sq.clone()}},
+        return {"state": {0: {"step": self.step_t.float().cpu().reshape(()), "exp_avg": self.exp_avg.cpu().clone(),
+                              "exp_avg_sq": self.exp_avg_sq.cpu().clone()}},
                 "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd,
+                                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                                  "differentiable": False, "fused": None, "decoupled_weight_decay": False,
                                   "params": [0]}]}
+
+    def load_state_dict(self, sd):
+        """Inverse of :meth:`state_dict`; also accepts a ``torch.optim.Adam.state_dict()`` of the same parameter."""
+        st = sd.get("state", {})
+        if len(st) == 0:
+            return  # a fresh optimiser
+        st = st[sorted(st.keys())[0]]
+        self.exp_avg.copy_(torch.as_tensor(st["exp_avg"], dtype=torch.float32).reshape(6))
+        self.exp_avg_sq.copy_(torch.as_tensor(st["exp_avg_sq"], dtype=torch.float32).reshape(6))
+        self.step_t.fill_(int(round(float(torch.as_tensor(st["step"]).reshape(-1)[0]))))

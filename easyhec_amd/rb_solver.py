@@ -42,7 +42,19 @@ class RBSolver(nn.Module):
         self.renderer = None  # created on first forward, on the parameters' device (needs a HIP device)
         self._scene = None
         self.register_buffer("history_ops", torch.zeros(10000, 6))
+        # next free row of history_ops.  The reference finds it on every forward as the first all-zero row
+        # (rb_solver.py:50-51, one .item() sync per step); here it is a host counter that is re-derived from the buffer
+        # (one sync) whenever it may be stale: after load_state_dict and after steps of the HIP launch chain, which
+        # writes the rows itself (None = unknown).
         self._hist_n = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_hist_n", None))
+
+    def history_cursor(self):
+        """First all-zero row of ``history_ops`` (rb_solver.py:50): where the next pose is recorded."""
+        if self._hist_n is None:
+            zero_rows = (self.history_ops == 0).all(dim=1).nonzero()
+            self._hist_n = int(zero_rows[0, 0]) if zero_rows.numel() > 0 else self.history_ops.shape[0]
+        return self._hist_n
 
     # -- device-side lazies -------------------------------------------------------------------------------------
     def _ensure_renderer(self):
@@ -84,9 +96,10 @@ class RBSolver(nn.Module):
     def forward(self, dps, with_outputs=True):
         assert dps.get("global_step", 0) == 0
         renderer = self._ensure_renderer()
-        if self._hist_n < self.history_ops.shape[0]:  # rb_solver.py:50-51 without the .item() sync
-            self.history_ops[self._hist_n] = self.dof.detach()
-            self._hist_n += 1
+        put_id = self.history_cursor()  # rb_solver.py:50-51 without the per-step .item() sync
+        if put_id < self.history_ops.shape[0]:
+            self.history_ops[put_id] = self.dof.detach()
+            self._hist_n = put_id + 1
         Tc_c2b = self.Tc_c2b()
         masks_ref = dps["mask"]
         link_poses = dps["link_poses"]

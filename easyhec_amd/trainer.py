@@ -72,11 +72,12 @@ class RBSolverTrainer:
 
     # one optimisation step == one "epoch" of the reference (trainer/rbsolver.py:29-43)
     def step(self, with_outputs=False):
-        if self.fast is not None and not with_outputs:
-            loss_value = self.fast.step()[0]
+        if self.fast is not None:
+            # ONE optimiser state whatever is asked for: the launch chain also produces the rendered masks
+            loss_value = self.fast.step(want_mask=with_outputs)[0]
             self.global_steps += 1
             self.last_loss = loss_value
-            return {}, loss_value
+            return (self._fast_outputs() if with_outputs else {}), loss_value
         self.optimizer.zero_grad(set_to_none=False)
         output, loss_dict = self.model(self.batch, with_outputs=with_outputs)
         loss = sum(v for v in loss_dict.values())
@@ -103,6 +104,27 @@ class RBSolverTrainer:
         self.last_loss = loss_value
         return output, loss_value
 
+    def _fast_outputs(self):
+        """The ``output`` dict of RBSolver.forward (rb_solver.py:73-94) for the step the launch chain just took; the pose
+        it refers to is the one the step STARTED from (the row the chain recorded in history_ops), as in the reference,
+        where forward() runs before optimizer.step()."""
+        f, m = self.fast, self.model
+        rendered = f.mask.clone()
+        ref = self.batch["mask"]
+        out = {"rendered_masks": rendered, "ref_masks": ref, "error_maps": (rendered - ref.float()).abs()}
+        row = (f.step_t.long() - 1).clamp(0, m.history_ops.shape[0] - 1)
+        dof_before = m.history_ops[row][0]
+        gt_dof6 = self.batch.get("gt_dof6")
+        if gt_dof6 is not None:
+            import numpy as np
+            trans_err = ((gt_dof6[:3] - dof_before[:3]) * 100).abs()
+            rot_err = (gt_dof6[3:] - dof_before[3:]).abs().max() / np.pi * 180
+            out["metrics"] = {"err_x": trans_err[0], "err_y": trans_err[1], "err_z": trans_err[2],
+                              "err_trans": trans_err.norm(), "err_rot": rot_err}
+        from .se3 import se3_exp_map
+        out["tsfm"] = se3_exp_map(dof_before[None].detach().cpu()).permute(0, 2, 1)[0]
+        return out
+
     def fit(self, num_steps=None, log=None):
         """Runs ``num_epochs`` steps (base.py:161 ``fit``); returns the list of logged (step, loss) pairs."""
         n = self.cfg.solver.num_epochs if num_steps is None else num_steps
@@ -113,6 +135,10 @@ class RBSolverTrainer:
             _, loss = self.step(with_outputs=False)
             if do_log:
                 lv = float(loss)
+                if lv != lv and self.fast is not None:
+                    # the chain reports an internal overflow as NaN (and leaves dof / Adam state untouched): say why
+                    from . import fused
+                    fused.check_status(self.fast.glctx)
                 history.append((self.global_steps, lv))
                 if log is not None:
                     log(f"step {self.global_steps} mask_loss {lv:.4f} elapsed {time.time() - begin:.2f}s")
@@ -120,14 +146,30 @@ class RBSolverTrainer:
 
     # checkpoint in the reference's layout: ckpt['model']['dof'] / ['history_ops'] (trainer/rbsolver.py:95-114)
     def save(self, path):
+        """``model`` (dof, history_ops, meshes), counters and the optimiser that actually stepped: the launch chain's
+        Adam state in fast mode (exp_avg, exp_avg_sq, step), torch's otherwise -- same layout either way."""
+        opt = self.fast.state_dict() if self.fast is not None else self.optimizer.state_dict()
         d = {"model": self.model.state_dict(), "epoch": self.global_steps, "best_val_loss": float("inf"),
-             "global_steps": self.global_steps, "optimizer": self.optimizer.state_dict()}
+             "global_steps": self.global_steps, "optimizer": opt}
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         torch.save(d, path)
 
     def resume(self, path):
+        """base.py:388-440: restores the model, the optimiser state and the counters.  The next step continues the Adam
+        bias correction where it stopped and appends to ``history_ops`` at the first all-zero row (rb_solver.py:50-51)
+        instead of overwriting it from row 0."""
         d = torch.load(path, map_location="cpu", weights_only=False)
-        self.model.load_state_dict(d["model"])
-        if "optimizer" in d:
-            self.optimizer.load_state_dict(d["optimizer"])
+        self.model.load_state_dict(d["model"])  # also invalidates the model's history cursor
+        if self.fast is not None:
+            self.fast.step_t.fill_(int(self.model.history_cursor()))
+            if "optimizer" in d:
+                self.fast.load_state_dict(d["optimizer"])
+        elif "optimizer" in d and len(d["optimizer"].get("state", {})) > 0:
+            st = d["optimizer"]["state"]
+            st = st[sorted(st.keys())[0]]
+            p = self.model.dof
+            self.optimizer.state[p] = {
+                "step": torch.as_tensor(st["step"], dtype=torch.float32).reshape(()).clone(),
+                "exp_avg": torch.as_tensor(st["exp_avg"], dtype=p.dtype).reshape(p.shape).to(p.device).clone(),
+                "exp_avg_sq": torch.as_tensor(st["exp_avg_sq"], dtype=p.dtype).reshape(p.shape).to(p.device).clone()}
         self.global_steps = d.get("global_steps", 0)

@@ -87,13 +87,16 @@ def test_fast_step_tracks_autograd_step(xarm7):
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 17
 
 
-def test_merged_step_equals_the_separate_kernels(xarm7):
-    """ehr_solver_step (7 launches) against ehr_pose_forward -> ehr_render_mask_loss -> ehr_pose_backward ->
-    ehr_pose_adam called one by one from the same state: identical bits."""
+@pytest.mark.parametrize("B,H,W,scale", [(3, 240, 320, 0.25), (8, 720, 1280, 1.0)])
+def test_merged_step_equals_the_separate_kernels(xarm7, B, H, W, scale):
+    """ehr_solver_step (what bench.py times) against ehr_pose_forward -> ehr_render_mask_loss -> ehr_pose_backward ->
+    ehr_pose_adam called one by one from the same state: identical bits -- also at BASELINE configs[2]'s full size
+    (8 views 1280x720), where ehr_render_mask_loss is the entry point tests/test_gpu_fused.py checks against the
+    oracle, which closes the chain  oracle == ehr_render_mask_loss == timed step."""
     import ctypes
     from easyhec_amd import _lib, fused
     from easyhec_amd.fast import FusedPoseStep
-    cfg, make, batch = problem(xarm7, 3, 240, 320, 0.25)
+    cfg, make, batch = problem(xarm7, B, H, W, scale)
     ma, mb = make(), make()
     fa, fb = FusedPoseStep(ma, batch), FusedPoseStep(mb, batch)
     lib = _lib.lib()
@@ -151,3 +154,28 @@ def test_graph_replay_equals_eager_launches(xarm7):
     fb.step()
     torch.cuda.synchronize()
     assert torch.equal(ma.dof.data, mb.dof.data)
+
+
+def test_outputs_step_shares_the_optimiser_state(xarm7):
+    """RBSolverTrainer(fast=True).step(with_outputs=True) is the SAME launch chain with the mask written (it used to
+    fall through to torch autograd with a second Adam state): a run that asks for outputs every third step is bit
+    identical to one that never does, and the outputs describe the pose the step started from."""
+    from easyhec_amd.trainer import RBSolverTrainer
+    cfg, make, batch = problem(xarm7, 2, 120, 160, 0.125)
+    from easyhec_amd.synthetic import camera_Tc_c2b
+    batch = dict(batch)
+    batch["Tc_c2b"] = torch.tensor(camera_Tc_c2b(), dtype=torch.float32, device="cuda:0")[None].repeat(2, 1, 1)
+    ma, mb = make(), make()
+    ta, tb = RBSolverTrainer(cfg, ma, batch, fast=True), RBSolverTrainer(cfg, mb, batch, fast=True)
+    for it in range(9):
+        ta.step()
+        out, loss = tb.step(with_outputs=(it % 3 == 0))
+        if it % 3 == 0:
+            assert set(out) >= {"rendered_masks", "ref_masks", "error_maps", "metrics", "tsfm"}
+            assert out["rendered_masks"].shape == batch["mask"].shape and float(out["rendered_masks"].max()) <= 1.0
+            sse = ((out["rendered_masks"] - batch["mask"]) ** 2).sum(dim=(1, 2)).mean()
+            assert abs(float(sse) - float(loss)) <= 1e-4 * float(loss)       # the loss of exactly these masks
+            assert torch.equal(mb.history_ops[it], ma.history_ops[it])
+    torch.cuda.synchronize()
+    assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(ta.fast.exp_avg, tb.fast.exp_avg)
+    assert ta.global_steps == tb.global_steps == 9 and int(tb.fast.step_t) == 9

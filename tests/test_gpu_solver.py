@@ -78,6 +78,50 @@ def test_config2_single_view_200_iterations(xarm7, oracle):
     assert tr.global_steps == 200 and float(model.history_ops[199].abs().sum()) > 0  # rb_solver.py:50-51 bookkeeping
 
 
+def test_config2_as_written_three_starts(xarm7):
+    """configs[1] exactly as BASELINE.json states it (ONE 640x480 view, 200 Adam iterations, lr 3e-3, wd 5e-4), from
+    three different initial errors of ~30 mm / ~4 deg, HIP launch chain.  What a single silhouette pins down, measured
+    with tools/config2_study.py (numbers in BASELINE.md): the mean of the last 20 iterates ends 1.1-2.2 mm and
+    1.7-2.0 deg from the truth (the oracle-driven run of the same start: 1.4-3.0 mm / 1.8-2.1 deg, i.e. the same
+    cloud), different starts end up to 3 mm / 3.8 deg apart -- one rotation about the viewing direction is weakly
+    observed, so north_star's 1 mm / 0.1 deg bar is a property of the multi-view problem (next test: 0.3 mm /
+    0.04 deg), not of this config.  Asserted here: every start gets within 4 mm / 3 deg and cuts the loss > 5x."""
+    from easyhec_amd import fused
+    from easyhec_amd.config import XARM7_K_1280x720, Cfg
+    from easyhec_amd.rb_solver import RBSolver
+    from easyhec_amd.se3 import se3_exp_map
+    from easyhec_amd.synthetic import camera_Tc_c2b, make_views, perturb_pose, scaled_K
+    from easyhec_amd.trainer import RBSolverTrainer
+    dev = torch.device("cuda:0")
+    H, W = 480, 640
+    K = scaled_K(XARM7_K_1280x720, 0.5, W, H, True)
+    _, lp = make_views(xarm7, 1, seed=0)
+    Tc = camera_Tc_c2b()
+    Kt, lpt = torch.tensor(K, dtype=torch.float32, device=dev), torch.tensor(lp, device=dev)
+    starts = [((0.02, -0.015, 0.02), (3.0, -2.0, 2.0)), ((-0.015, 0.02, -0.01), (-2.0, 3.0, -1.5)),
+              ((0.01, 0.01, -0.025), (1.5, 2.5, 3.0))]
+    for dt, dr in starts:
+        init = perturb_pose(Tc, dt=dt, drot_deg=dr)
+        cfg = Cfg()
+        cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
+        cfg.model.rbsolver.init_Tc_c2b = init.tolist()
+        model = RBSolver(cfg, meshes=xarm7.meshes).to(dev)
+        with torch.no_grad():
+            gt, _ = fused.render_mask_loss(model._ensure_renderer().glctx, model._ensure_scene(), fused.mvp_matrices(
+                Kt, H, W, torch.tensor(Tc, dtype=torch.float32, device=dev), lpt), torch.zeros((1, H, W), device=dev))
+        tr = RBSolverTrainer(cfg, model, {"mask": (gt > 0.5).float(), "link_poses": lpt, "K": Kt[None]}, fast=True)
+        dofs, first = [], None
+        for it in range(200):
+            loss = float(tr.step()[1])
+            first = loss if first is None else first
+            dofs.append(model.dof.detach().clone())
+        Tm = se3_exp_map(torch.stack(dofs[-20:]).mean(0).cpu()[None]).permute(0, 2, 1)[0].numpy().astype(np.float64)
+        e0, e1 = pose_error(init, Tc), pose_error(Tm, Tc)
+        assert e0[0] > 20 and e1[0] <= 4.0 and e1[1] <= 3.0, (e0, e1)
+        assert loss < 0.2 * first, (first, loss)
+        fused.check_status(model._ensure_renderer().glctx)
+
+
 def test_multi_view_converges_to_ground_truth_and_to_the_oracle_run(xarm7, oracle):
     """4 views: the HIP-driven estimate reaches the ground-truth pose and the oracle-driven estimate within
     1 mm / 0.1 deg (north_star's bar), comparing the mean of the last 20 iterates (Adam's constant-LR jitter)."""
