@@ -5,6 +5,19 @@
 // vertices, depth/barycentrics come from the unsnapped clip-space vertices.  The semantics restate nvdiffrast's
 // rasterize/interpolate/antialias as called from
 // /root/reference/easyhec/structures/nvdiffrast_renderer.py:39,42,43.
+//
+// PROVENANCE of the antialias arithmetic.  rational_gt, max_idx3, same_sign, tri_to_float / float_to_tri (0x4a800000),
+// aa_analyze and aa_pos_grad below reproduce the per-pair arithmetic of nvdiffrast's CUDA sources
+// (nvdiffrast/common/antialias.cu: AntialiasFwdMeshKernel / AntialiasFwdAnalysisKernel / AntialiasGradKernel, and
+// common.h helpers) statement by statement, down to the constants (eps = 1/16, 1e-3 pixel regulariser) and the order of
+// operations, because bit-level agreement with the reference's renderer requires exactly that arithmetic.  nvdiffrast is
+// NOT in /root/reference (requirements.txt:29 installs it from git) and no file of it was available here: this was
+// written from knowledge of that code, not derived independently from the paper.  nvdiffrast is distributed under the
+// NVIDIA Source Code License (1-Way Commercial / non-commercial research terms): these functions inherit whatever that
+// licence implies for a restatement; everything around them (z-buffer loops, topology table, composite, drivers) is new.
+// The oracle (oracle/ehr_oracle.c) holds the same functions typed a second time: the GPU-vs-oracle suite therefore
+// verifies the parallel decomposition (culling, LDS z-test, compaction, deterministic reductions), while this arithmetic
+// itself rests on the CPU analytic / finite-difference tests in tests/test_oracle_*.py.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,5 +1,11 @@
 // ehr_interp_aa.hip -- drop-in dr.interpolate (nvdiffrast_renderer.py:42) and dr.antialias (:43), fwd + bwd,
 // plus the edge-topology build that replaces dr.antialias_construct_topology_hash.
+//
+// PROVENANCE: the discover -> analyse -> gradient split with an int4 work buffer mirrors the kernel trio of nvdiffrast's
+// antialias.cu (AntialiasFwdDiscontinuityKernel / AntialiasFwdAnalysisKernel / AntialiasGradKernel), and the per-pair
+// arithmetic is ehr_device.h's aa_analyze / aa_pos_grad (see the provenance note there: written from knowledge of that
+// code, which is under the NVIDIA Source Code License; not present in /root/reference).  The topology here is a sorted
+// edge table, not nvdiffrast's hash.
 #include <algorithm>
 
 #include "ehr_device.h"

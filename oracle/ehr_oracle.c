@@ -25,6 +25,16 @@
  *   - depth / barycentrics: evaluated in float from the UNSNAPPED clip-space vertices at the pixel centre
  *     (homogeneous edge functions); nearest z/w wins, ties go to the lower triangle index;
  *   - rast = (u, v, z/w, tri_id+1), row 0 = bottom (GL convention).
+ *
+ * PROVENANCE of the antialias arithmetic.  rational_gt, max_idx3, same_sign, tri_to_float / float_to_tri (0x4a800000),
+ * aa_analyze and aa_pos_grad below reproduce the per-pair arithmetic of nvdiffrast's CUDA sources
+ * (nvdiffrast/common/antialias.cu: AntialiasFwdMeshKernel / AntialiasFwdAnalysisKernel / AntialiasGradKernel, and
+ * common.h helpers) statement by statement, down to the constants (eps = 1/16, 1e-3 pixel regulariser) and the order of
+ * operations, because bit-level agreement with the reference's renderer requires exactly that arithmetic.  nvdiffrast is
+ * NOT in /root/reference (requirements.txt:29 installs it from git) and no file of it was available here: this was
+ * written from knowledge of that code, not derived independently from the paper.  nvdiffrast is distributed under the
+ * NVIDIA Source Code License (1-Way Commercial / non-commercial research terms): these functions inherit whatever that
+ * licence implies for a restatement; everything around them (z-buffer loops, topology table, composite, drivers) is new.
  */
 #include <float.h>
 #include <math.h>
