@@ -265,7 +265,8 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         posc[(size_t)b * V + v] = o;
         return;
     }
-    if (c >= cl.NC) return;
+    __shared__ int wbox[4][5];  // per wave: link, box of its cluster
+    const bool cvalid = c < cl.NC;
     int x0 = 0xffff, y0 = 0xffff, x1 = 0, y1 = 0;  // empty (overlaps nothing)
     int4 r0 = make_int4(-1, -1, -1, 0), r1 = make_int4(0, 0, t, 0);
     float4 p0 = make_float4(0.f, 0.f, 0.f, -1.f), p1 = p0, p2 = p0;
@@ -295,9 +296,9 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             }
         }
     }
-    const size_t slot = ((size_t)b * cl.NC + c) * 64 + lane;
-    rc.tbox[slot] = vb_pack_box(x0, y0, x1, y1);
-    if (x0 <= x1) {
+    const size_t slot = ((size_t)b * cl.NC + (cvalid ? c : 0)) * 64 + lane;
+    if (cvalid) rc.tbox[slot] = vb_pack_box(x0, y0, x1, y1);
+    if (cvalid && x0 <= x1) {
         rc.trec[slot] = r0;
         rc.trec[rc.n + slot] = r1;
         rc.tdep[slot] = p0;
@@ -313,15 +314,37 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         cc = max(cc, __shfl_xor(cc, off, 64));
         d = max(d, __shfl_xor(d, off, 64));
     }
+    const int wv = tid >> 6;
     if (lane == 0) {
-        const bool cne = a <= cc;
-        rc.cbox[(size_t)b * cl.NC + c] = cne ? vb_pack_box(a, bq, cc, d) : VB_BOX_EMPTY;
-        if (cne && lv) {  // link box: integer atomics, one 64-byte line per (view, link) so that links do not serialise
-            int* bx = lbox + VB_LBOX_STRIDE * ((size_t)b * L + l);
-            atomicMin(bx + 0, a);
-            atomicMin(bx + 1, bq);
-            atomicMax(bx + 2, cc);
-            atomicMax(bx + 3, d);
+        const bool cne = cvalid && a <= cc;
+        if (cvalid) rc.cbox[(size_t)b * cl.NC + c] = cne ? vb_pack_box(a, bq, cc, d) : VB_BOX_EMPTY;
+        wbox[wv][0] = (cne && lv) ? l : -1;
+        wbox[wv][1] = a;
+        wbox[wv][2] = bq;
+        wbox[wv][3] = cc;
+        wbox[wv][4] = d;
+    }
+    __syncthreads();
+    // link box: integer atomics, merged over the workgroup's four clusters (usually one link) and with one 64-byte line
+    // per (view, link): ~5 k atomics per step spread over B * L lines instead of 20 k on a handful
+    if (tid < 4 && wbox[tid][0] >= 0) {
+        const int ll = wbox[tid][0];
+        bool first_of_link = true;
+        for (int k = 0; k < tid; k++) first_of_link = first_of_link && wbox[k][0] != ll;
+        if (first_of_link) {
+            int ma = wbox[tid][1], mb = wbox[tid][2], mc = wbox[tid][3], md = wbox[tid][4];
+            for (int k = tid + 1; k < 4; k++)
+                if (wbox[k][0] == ll) {
+                    ma = min(ma, wbox[k][1]);
+                    mb = min(mb, wbox[k][2]);
+                    mc = max(mc, wbox[k][3]);
+                    md = max(md, wbox[k][4]);
+                }
+            int* bx = lbox + VB_LBOX_STRIDE * ((size_t)b * L + ll);
+            atomicMin(bx + 0, ma);
+            atomicMin(bx + 1, mb);
+            atomicMax(bx + 2, mc);
+            atomicMax(bx + 3, md);
         }
     }
 }
@@ -656,9 +679,11 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
     }
     total = min(total, jcap);
     // XCD-aware order: workgroup w runs on XCD w % 8 (observed, used for L2 locality only): every XCD takes a contiguous
-    // eighth of the job list, so that a view's vertices, boxes and records stay in one L2.  Inside that eighth the jobs are
-    // dealt round-robin; claiming them dynamically (one returning atomic per job on the XCD's cursor, EHR_VB_DEBUG & 8)
-    // balances better but measured 20 % slower: 500 waves hit each cursor at once (~12 ns per same-address atomic).
+    // eighth of the job list, so that a view's vertices, boxes and records stay in one L2.  Inside that eighth every wave
+    // takes one job statically; the jobs beyond that are claimed (one returning atomic on the XCD's cursor) by whichever
+    // wave finishes first.  Jobs differ by two orders of magnitude in cost: dealt statically (EHR_VB_DEBUG & 8) the kernel
+    // waits for a wave that got a heavy SECOND job; claimed from the start, 500 waves hit each cursor at once (~12 ns per
+    // same-address atomic) and the kernel is 20 % slower.
     const int per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
     const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
     int* const cursor = meta + 32 + xcd;
@@ -666,14 +691,17 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
     long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)ph_last;
     (void)ph_acc;
+    const int nwx = (gridDim.x >> 3) * 4;  // waves working on this XCD's eighth
+    bool first_job = true;
     int sjob = jbeg + (blockIdx.x >> 3) * 4 + wave;
     for (;;) {
         int job = 0;
-        if (!(dbg & 8)) {
+        if (first_job || (dbg & 8)) {
             job = sjob;
-            sjob += (gridDim.x >> 3) * 4;
-        } else {
-            if (lane == 0) job = jbeg + atomicAdd(cursor, 1);
+            sjob += nwx;
+            first_job = false;
+        } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
+            if (lane == 0) job = jbeg + nwx + atomicAdd(cursor, 1);
             job = __builtin_amdgcn_readfirstlane(job);
         }
         if (job >= jend) break;
