@@ -175,7 +175,7 @@ using namespace ehr;
 
 extern "C" {
 
-int ehr_version(void) { return 1; }
+int ehr_version(void) { return 2; }
 
 const char* ehr_last_error(void) { return g_last_error.c_str(); }
 

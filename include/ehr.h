@@ -36,7 +36,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 1 */
+int ehr_version(void);                 /* ABI version, currently 2 (2: ehr_fused_plan takes the scene arrays) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
@@ -92,11 +92,16 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  * Scene = all links concatenated: verts [V,3]; tris [T,3] with GLOBAL vertex indices, sorted by link;
  * tri_link [T] / vert_link [V] int32 link of each triangle / vertex; opp [T,3] from ehr_antialias_topology on the
  * concatenated mesh (links share no vertices, so the per-link topology is preserved).
- * ehr_fused_plan sizes the ctx scratch for (B,L,T,H,W) and must be called (it synchronises) before the first
- * ehr_render_mask_loss of that shape; ehr_render_mask_loss itself never synchronises or allocates, so it can be
- * captured in a hipGraph.  If a bin queue overflows at run time, loss[] is set to NaN (never a silently wrong
- * image) and ehr_fused_status() returns EHR_ERR_OVERFLOW after the stream is synchronised; re-plan with a larger
- * `slack`. */
+ * ehr_fused_plan prepares the context for one scene and shape (it synchronises and reads the scene back once): it
+ * sizes the scratch for (B,L,V,T,H,W) and builds the static acceleration index of the scene's triangles (clusters of 64
+ * spatially close triangles per link, padded index tables), so it takes the scene arrays -- the SAME device arrays that
+ * are later passed to ehr_render_mask_loss / ehr_solver_step (they are checked by address; call it again when the
+ * scene, the shape or the arrays change).  The hot calls never synchronise or allocate, so they can be captured in a
+ * hipGraph; a new plan invalidates a captured graph.  One slot per (view, link, tile) is reserved, so nothing on this
+ * path can overflow except the fixed-point accumulators (|sum| > 2^31) and a 16 MB spill pool for tiles with more than
+ * 64 blended pairs per link: then loss[] is NaN (never a silently wrong image), the optimiser state is left untouched
+ * and ehr_fused_status() returns EHR_ERR_OVERFLOW after synchronising.  `slack` only matters for the round-1 tile chain
+ * (EHR_FUSED_PATH=tile: bin-queue capacity). */
 int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
                    const int32_t* tris, const int32_t* tri_link, const int32_t* opp);
 int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
@@ -104,12 +109,15 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
                          int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream);
 int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVERFLOW */
 
-/* Measurement hook (bench.py's roofline leg): when enabled, every ehr_render_mask_loss call records hipEvents
- * around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED milliseconds
- * per stage since the last read -- ms[0] memset + vertex transform + bin count, ms[1] queue alloc, ms[2] bin fill,
- * ms[3] empty-tile streaming kernel, ms[4] work-list tile kernel (lean instantiation: the dominant kernel), ms[5] its
- * slow-path instantiation, ms[6] reduce -- and the number of calls covered, then resets.  While enabled the kernels
- * run back to back on the launch stream (no side-stream overlap).  Not for use under graph capture. */
+/* Measurement hook (bench.py's roofline leg): when enabled, every ehr_render_mask_loss / ehr_solver_step call records
+ * hipEvents around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED
+ * milliseconds per stage since the last read and the number of calls covered, then resets.  Stages of the default
+ * (visibility-buffer) chain: ms[0] vertex kernel (pose forward, clip-space vertices, per-triangle raster records, cluster
+ * and link boxes), ms[1] job kernel (one wave per (view, link, tile): culling, LDS rasterizer, silhouette analysis -- the
+ * dominant kernel), ms[4] composite kernel (link sum, clamp, loss, mask, backward), ms[6] finish kernel (accumulators ->
+ * loss / grad_mvp [-> pose backward -> Adam]); ms[2], ms[3], ms[5] are unused (~0).  With EHR_FUSED_PATH=tile the seven
+ * slots are the round-1 chain's: count, alloc, fill, empty tiles, tile kernel, its slow instantiation, reduce.
+ * Not for use under graph capture. */
 #define EHR_FUSED_STAGES 7
 int ehr_fused_timing(ehr_ctx* ctx, int enable);
 int ehr_fused_timing_read(ehr_ctx* ctx, float* ms, int* ncalls);
