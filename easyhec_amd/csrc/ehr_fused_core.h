@@ -56,7 +56,17 @@ __global__ void __launch_bounds__(256) fused_finish_kernel(BinGeom g, int B, con
         for (int k = 0; k < nls; k++) s += facc[(size_t)b * acc_stride + 12 * L + k];
         return fix_get(s);
     };
-    if (tid < B) vloss[tid] = view_loss_slow(tid);
+    if (nls == 32) {  // one slot per lane, half a wave per view: a single round trip instead of 32 dependent adds
+        for (int base = 0; base < min(B, 256); base += 8) {
+            const int b = base + (tid >> 5), k = tid & 31;
+            long long s = (b < B) ? facc[(size_t)b * acc_stride + 12 * L + k] : 0;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (k == 0 && b < B && b < 256) vloss[b] = fix_get(s);
+        }
+    } else if (tid < B) {
+        vloss[tid] = view_loss_slow(tid);
+    }
     __syncthreads();
     auto view_loss = [&](int b) { return b < 256 ? vloss[b] : view_loss_slow(b); };
     const bool bad = meta[EHR_META_OVERFLOW] != 0;  // overflow => NaN, never a silently wrong loss
