@@ -691,63 +691,12 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
     long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)ph_last;
     (void)ph_acc;
-    const int nwx = (gridDim.x >> 3) * 4;  // waves working on this XCD's eighth
-    bool first_job = true;
-    int sjob = jbeg + (blockIdx.x >> 3) * 4 + wave;
-    for (;;) {
-        int job = 0;
-        if (first_job || (dbg & 8)) {
-            job = sjob;
-            sjob += nwx;
-            first_job = false;
-        } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
-            if (lane == 0) job = jbeg + nwx + atomicAdd(cursor, 1);
-            job = __builtin_amdgcn_readfirstlane(job);
-        }
-        if (job >= jend) break;
-        VB_PHASE(0);  // claim / previous job's tail
-        int u;
-        {
-            int lo = 0, hi = U - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (upre[mid] <= job)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            u = lo;
-        }
-        const int b = u / L, l = u - b * L;
-        int tx, ty;
-        {
-            const unsigned ut = utile[u];
-            const int nx = (int)(ut >> 22), k = job - upre[u];
-            ty = (int)((ut >> 10) & 4095u) + k / nx;
-            tx = (int)(ut & 1023u) + k - (k / nx) * nx;
-        }
-        const size_t slot = (size_t)job;
-        const int r = lane >> 3, c4 = (lane & 7) * 4;
-        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
-        VbRegion rg;  // tile + 1-pixel halo, inside the image
-        rg.x0 = max(rx0, 0);
-        rg.y0 = max(ry0, 0);
-        rg.x1 = min(rx0 + VB_RW - 1, W - 1);
-        rg.y1 = min(ry0 + VB_RH - 1, H - 1);
-        const int myq = (r + 1) * VB_RW + (c4 + 1);
-        const float4* const pv = posc + (size_t)b * V;
-        int nitems = 0;       // wave-uniform
-        int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
-        bool drawn = false;   // wave-uniform: some triangle's box touches the region
-        // ---- coverage + depth of this link inside the region: cull clusters, then triangles, rasterize into LDS
-        VB_WAVE_SYNC();
-#pragma unroll
-        for (int k = 0; k < VB_WORDS; k++) {
-            const unsigned i = 64u * k + lane;
-            if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
-        }
-        VB_WAVE_SYNC();
-        {
+    // Culls the link's clusters and triangles against the job's region and rasterizes this wave's share of them into
+    // `key_` (the job's LDS depth/id buffer, initialised by the caller).  share / nshare: the wave takes every nshare-th
+    // candidate cluster -- 0 / 1 for a job of its own, wave / 4 when the whole workgroup works on one heavy job.
+    auto raster_share = [&](VbWaveLds& W_, u64* key_, int b, int l, const VbRegion& rg, int rx0, int ry0, int share, int nshare,
+                            int& nsurv) -> bool
+    {
             const int c0 = lcoff[l], c1 = lcoff[l + 1];
             const uint2* const cb = rc.cbox + (size_t)b * cl.NC;
             const unsigned rlo = (unsigned)rg.x0 | ((unsigned)rg.y0 << 16), rhi = (unsigned)rg.x1 | ((unsigned)rg.y1 << 16);
@@ -755,7 +704,8 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
             // the rasterizer is full; the triangle boxes of up to four candidate clusters are fetched per round trip.
             const size_t vbase = (size_t)b * cl.NC * 64;
             int qh = 0, qn = 0;  // wave-uniform ring state
-            drawn = false;
+            int cord = 0;        // running ordinal of the candidate clusters
+            bool drawn = false;
             for (int cbase = c0; cbase < c1; cbase += 64) {
                 const int c = cbase + lane;
                 bool hit = false;
@@ -765,6 +715,16 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
                           (bx.x >> 16) <= (rhi >> 16) && (bx.y >> 16) >= (rlo >> 16);
                 }
                 u64 cm = __ballot(hit);
+                if (nshare > 1) {  // cooperative job: this wave takes every nshare-th candidate cluster
+                    u64 mine = 0;
+                    u64 all = cm;
+                    while (all) {
+                        const u64 low = all & (~all + 1);
+                        if ((cord++ % nshare) == share) mine |= low;
+                        all ^= low;
+                    }
+                    cm = mine;
+                }
                 VB_PHASE(1);  // cluster box culling
                 while (cm) {  // wave-uniform
                     int cc[4];
@@ -786,13 +746,14 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
                                         (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16);
                         const u64 sm = __ballot(sv);
                         if (!sm) continue;
-                        if (sv) S.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(cc[k] * 64 + lane);
+                        if (sv) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(cc[k] * 64 + lane);
                         qn += __popcll(sm);
                         drawn = true;
+                        nsurv += __popcll(sm);
                         VB_PHASE(7);  // triangle box culling
                         if (qn >= 64) {
                             VB_WAVE_SYNC();
-                            vb_raster_round(true, vbase + S.sq[(qh + lane) & 127], rc, rg, rx0, ry0, W, H, S.u.R, S.key, ph_acc, ph_last);
+                            vb_raster_round(true, vbase + W_.sq[(qh + lane) & 127], rc, rg, rx0, ry0, W, H, W_.u.R, key_, ph_acc, ph_last);
                             qh = (qh + 64) & 127;
                             qn -= 64;
                         }
@@ -802,13 +763,18 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
             if (qn) {
                 VB_WAVE_SYNC();
                 const bool sv = lane < qn;
-                vb_raster_round(sv, vbase + (sv ? S.sq[(qh + lane) & 127] : 0u), rc, rg, rx0, ry0, W, H, S.u.R, S.key, ph_acc, ph_last);
+                vb_raster_round(sv, vbase + (sv ? W_.sq[(qh + lane) & 127] : 0u), rc, rg, rx0, ry0, W, H, W_.u.R, key_, ph_acc, ph_last);
             }
-        }
-        if (!drawn) {  // the link's box touches this tile, its triangles do not
-            if (lane == 0) jn[slot] = -1;
-            continue;
-        }
+            return drawn;
+        };
+    // Everything after the coverage of a job is complete in S.key: pair discovery, silhouette analysis, gather, publish.
+    auto resolve = [&](VbWaveLds& S, int b, int l, int tx, int ty, size_t slot, const VbRegion& rg, int rx0, int ry0) {
+        (void)l; (void)tx; (void)ty;
+        const int r = lane >> 3, c4 = (lane & 7) * 4;
+        const int myq = (r + 1) * VB_RW + (c4 + 1);
+        const float4* const pv = posc + (size_t)b * V;
+        int nitems = 0;       // wave-uniform
+        int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
         VB_WAVE_SYNC();
         VB_PHASE(1);
         for (int i = lane; i < 2 * VB_RN; i += 64) S.u.Z.pairA[i] = 0.f;  // aliases the raster scratch
@@ -983,6 +949,63 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
         }
         VB_WAVE_SYNC();
         VB_PHASE(6);  // publish
+    };
+    const int nwx = (gridDim.x >> 3) * 4;  // waves working on this XCD's eighth
+    bool first_job = true;
+    int sjob = jbeg + (blockIdx.x >> 3) * 4 + wave;
+    for (;;) {
+        int job = 0;
+        if (first_job || (dbg & 8)) {
+            job = sjob;
+            sjob += nwx;
+            first_job = false;
+        } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
+            if (lane == 0) job = jbeg + nwx + atomicAdd(cursor, 1);
+            job = __builtin_amdgcn_readfirstlane(job);
+        }
+        if (job >= jend) break;
+        VB_PHASE(0);  // claim / previous job's tail
+        int u;
+        {
+            int lo = 0, hi = U - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (upre[mid] <= job)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            u = lo;
+        }
+        const int b = u / L, l = u - b * L;
+        int tx, ty;
+        {
+            const unsigned ut = utile[u];
+            const int nx = (int)(ut >> 22), k = job - upre[u];
+            ty = (int)((ut >> 10) & 4095u) + k / nx;
+            tx = (int)(ut & 1023u) + k - (k / nx) * nx;
+        }
+        const size_t slot = (size_t)job;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        VbRegion rg;  // tile + 1-pixel halo, inside the image
+        rg.x0 = max(rx0, 0);
+        rg.y0 = max(ry0, 0);
+        rg.x1 = min(rx0 + VB_RW - 1, W - 1);
+        rg.y1 = min(ry0 + VB_RH - 1, H - 1);
+        VB_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
+        }
+        VB_WAVE_SYNC();
+        int nsurv = 0;
+        const bool drawn = raster_share(S, S.key, b, l, rg, rx0, ry0, 0, 1, nsurv);
+        if (!drawn) {  // the link's box touches this tile, its triangles do not
+            if (lane == 0) jn[slot] = -1;
+            continue;
+        }
+        resolve(S, b, l, tx, ty, slot, rg, rx0, ry0);
     }
 #ifdef VB_PHASE_TIMING
     if (lane == 0)
