@@ -71,6 +71,7 @@ struct ehr_ctx {
     // visibility-buffer chain of the fused op (ehr_vbuf.hip); its own scratch, never shared with the drop-in ops
     bool path_vbuf = true;   // EHR_FUSED_PATH=tile selects the round-1 LDS-tile chain (A/B measurements)
     ehr::Scratch vb_clus;    // i32 cluster index: ctri [NC][64] | clink [NC] | coff [L + 1] (static, built by the plan)
+    ehr::Scratch vb_heavy;   // heavy-job scheduling hint carried from step to step (generation, lists, stamps)
     ehr::Scratch vb_idx;     // int4 [T] padded triangle indices | int4 [T] padded edge topology (static)
     const void* vb_plan_tris = nullptr;  // the scene the static index was built for
     const void* vb_plan_opp = nullptr;

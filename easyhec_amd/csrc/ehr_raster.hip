@@ -235,6 +235,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->sc_posc.release();
     c->vb_clus.release();
     c->vb_idx.release();
+    c->vb_heavy.release();
     c->vb_jobs.release();
     c->vb_boxes.release();
     c->vb_acc.release();

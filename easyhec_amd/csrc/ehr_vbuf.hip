@@ -37,6 +37,8 @@ constexpr int VB_RH = EHR_TILE_H + 2;
 constexpr int VB_RN = VB_RW * VB_RH;   // 340
 constexpr int VB_WORDS = (VB_RN + 63) / 64;  // 6 coverage words
 constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min y, max x, max y, padding to a 64-byte line
+constexpr int VB_HEAVY_T = 320;       // survivors from which a job counts as heavy (next step: a whole workgroup takes it)
+constexpr int VB_HEAVY_CAP = 1024;    // heavy jobs remembered per step
 constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
 constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
 constexpr u64 VB_EMPTY = ~0ull;
@@ -100,6 +102,15 @@ __device__ __forceinline__ int vb_mbcnt(u64 m) {  // set bits of m below this la
 }
 
 // ---- stage 1: vertices, screen boxes of triangles / clusters / links ---------------------------------------------
+
+// Jobs that turned out heavy in the PREVIOUS step (poses move little between optimisation steps): remembered by their
+// dense (view, link, tile) id, stamped into a table at the start of the step so that the single-wave enumeration skips
+// them, and processed first, each by a whole workgroup.  Purely a scheduling hint: results do not depend on it.
+struct VbHeavy {
+    int* gen;     // [0] generation (one per call), [1..2] entries in list 0 / 1
+    int* list;    // [2][VB_HEAVY_CAP] dense ids; list (gen & 1) is being written, the other one is being consumed
+    int* stamp;   // [B * L * nt]  == generation: handled by a heavy workgroup this step
+};
 
 struct VbClusters {          // static acceleration index built by ehr_fused_plan (host): triangles grouped into
     const int32_t* ctri;     // [NC * 64] clusters of <= 64 spatially close triangles of one link (-1 = padding)
@@ -171,7 +182,7 @@ __global__ void __launch_bounds__(256)
 vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vert_link,
                  const int32_t* __restrict__ tris, VbClusters cl, StepHead head, float* __restrict__ mvp, int V, int nvb,
                  BinGeom g, float4* __restrict__ posc, VbRecs rc, int* __restrict__ lbox, int* __restrict__ zacc,
-                 int nzacc, int* __restrict__ meta, int B, int gx, int xcd_views) {
+                 int nzacc, int* __restrict__ meta, int B, int gx, int xcd_views, VbHeavy hv) {
     __shared__ float Tc[16];
     __shared__ float M[32][16];
     // 1-D grid of B * gx workgroups.  xcd_views > 0 (B a multiple of 8): workgroup w runs on XCD w % 8 (observed, used
@@ -239,6 +250,19 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         }
     }
     if (first) {
+        // new generation of the heavy-job hint: stamp last step's heavy jobs, start this step's list empty
+        __shared__ int s_gen;
+        if (tid == 0) {
+            s_gen = hv.gen[0] + 1;
+            hv.gen[0] = s_gen;
+            hv.gen[1 + (s_gen & 1)] = 0;
+        }
+        __syncthreads();
+        {
+            const int gen = s_gen, cur = (gen - 1) & 1;
+            const int n = min(hv.gen[1 + cur], VB_HEAVY_CAP);
+            for (int i = tid; i < n; i += 256) hv.stamp[hv.list[cur * VB_HEAVY_CAP + i]] = gen;
+        }
         for (int i = tid; i < nzacc; i += 256) zacc[i] = 0;  // fixed-point accumulators (a few KB)
         if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
         if (tid < 8) meta[32 + tid] = 0;                     // job cursors of the 8 XCDs
@@ -634,7 +658,7 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
               const int4* __restrict__ opp4, VbClusters cl, VbRecs rc, const int* __restrict__ lbox,
               int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems, int* __restrict__ jspill,
               int* __restrict__ jbase, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
-              int* __restrict__ meta, int dbg) {
+              int* __restrict__ meta, int dbg, VbHeavy hv) {
     __shared__ VbWaveLds lds_all[4];
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
     __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
@@ -950,17 +974,81 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
         VB_WAVE_SYNC();
         VB_PHASE(6);  // publish
     };
-    const int nwx = (gridDim.x >> 3) * 4;  // waves working on this XCD's eighth
-    bool first_job = true;
-    int sjob = jbeg + (blockIdx.x >> 3) * 4 + wave;
+    // ---- heavy jobs first, one workgroup each: the four waves share the job's depth/id buffer (wave 0's) and split the
+    //      candidate clusters; wave 0 resolves.  A job alone costs up to ~80 us on one wave (a thousand candidate
+    //      triangles in one tile), which used to be the duration of this kernel at small batch sizes.
+    __shared__ int s_heavy[2];  // drawn flag, survivors
+    const int gen = hv.gen[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
+    // Only when the machine is short of jobs (at most ~2 per wave): with many views per GPU the kernel is bound by the
+    // sum of the jobs, not by the longest, and four waves on one job are less efficient than four jobs (measured: 64
+    // views 8 % slower with the heavy phase, 8 views 10 % faster, 1 view 40 % faster).
+    // Likewise when heavy jobs are the rule rather than the exception (more than one per two workgroups: the Franka
+    // meshes at 1080p have ~3000 of them in 8100 jobs and run 17 % slower with the heavy phase; the 8-view xArm7
+    // workload has ~220 in 5000).
+    const int nheavy_prev = hv.gen[1 + hcur];
+    const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > (int)gridDim.x / 2) ? 0 : nheavy_prev;
+    auto remember_heavy = [&](int id) {
+        const int at = atomicAdd(&hv.gen[1 + hnxt], 1);
+        if (at < VB_HEAVY_CAP) hv.list[hnxt * VB_HEAVY_CAP + at] = id;
+    };
+    if (tid < 2) s_heavy[tid] = 0;
+    __syncthreads();
+    for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform
+        const int id = hv.list[hcur * VB_HEAVY_CAP + hj];
+        const int u = id / g.nt, tile = id - u * g.nt;
+        const int tx = tile % g.ntx, ty = tile / g.ntx;
+        const unsigned ut = utile[u];
+        const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
+        const int job = upre[u] + (ty - ty0) * nx + (tx - tx0);
+        if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
+        const int b = u / L, l = u - b * L;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        VbRegion rg;
+        rg.x0 = max(rx0, 0);
+        rg.y0 = max(ry0, 0);
+        rg.x1 = min(rx0 + VB_RW - 1, W - 1);
+        rg.y1 = min(ry0 + VB_RH - 1, H - 1);
+        VbWaveLds& S0 = lds_all[0];
+        for (int i = tid; i < VB_RN; i += 256) S0.key[i] = VB_EMPTY;
+        __syncthreads();
+        int nsurv = 0;
+        const bool drawn = raster_share(S, S0.key, b, l, rg, rx0, ry0, wave, 4, nsurv);
+        if (lane == 0) {
+            if (drawn) atomicOr(&s_heavy[0], 1);
+            atomicAdd(&s_heavy[1], nsurv);
+        }
+        __syncthreads();
+        const int any_drawn = s_heavy[0], tot_surv = s_heavy[1];
+        __syncthreads();
+        if (wave == 0) {
+            if (lane == 0) {
+                s_heavy[0] = 0;
+                s_heavy[1] = 0;
+                if (tot_surv >= VB_HEAVY_T) remember_heavy(id);
+            }
+            if (any_drawn)
+                resolve(S0, b, l, tx, ty, (size_t)job, rg, rx0, ry0);
+            else if (lane == 0)
+                jn[job] = -1;
+        }
+        __syncthreads();
+    }
+
+    // workgroups that just spent their time on a heavy job take no static job: the first hk of this XCD's workgroups
+    const int nhw = min(nheavy, (int)gridDim.x);
+    const int hk = (nhw > xcd) ? (nhw - xcd + 7) >> 3 : 0;
+    const int kx = blockIdx.x >> 3;                      // this workgroup's index inside its XCD
+    const int nsw = ((gridDim.x >> 3) - hk) * 4;         // waves of this XCD that take a static first job
+    bool first_job = kx >= hk;
+    int sjob = jbeg + (kx - hk) * 4 + wave;
     for (;;) {
         int job = 0;
         if (first_job || (dbg & 8)) {
             job = sjob;
-            sjob += nwx;
+            sjob += nsw;
             first_job = false;
         } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
-            if (lane == 0) job = jbeg + nwx + atomicAdd(cursor, 1);
+            if (lane == 0) job = jbeg + nsw + atomicAdd(cursor, 1);
             job = __builtin_amdgcn_readfirstlane(job);
         }
         if (job >= jend) break;
@@ -986,6 +1074,8 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
             tx = (int)(ut & 1023u) + k - (k / nx) * nx;
         }
         const size_t slot = (size_t)job;
+        const int dense_id = u * g.nt + ty * g.ntx + tx;
+        if (nheavy > 0 && hv.stamp[dense_id] == gen) continue;  // a workgroup took this one in the heavy phase
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
         VbRegion rg;  // tile + 1-pixel halo, inside the image
         rg.x0 = max(rx0, 0);
@@ -1001,6 +1091,7 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
         VB_WAVE_SYNC();
         int nsurv = 0;
         const bool drawn = raster_share(S, S.key, b, l, rg, rx0, ry0, 0, 1, nsurv);
+        if (nsurv >= VB_HEAVY_T && lane == 0) remember_heavy(dense_id);
         if (!drawn) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) jn[slot] = -1;
             continue;
@@ -1300,6 +1391,12 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + 2 * sizeof(int)) +
                                        (size_t)B * L * sizeof(int)))) return rc;
     }
+    {  // heavy-job hint: generation + two counts | two lists | stamp table
+        BinGeom g = make_geom(H, W, L);
+        const size_t ints = 4 + 2 * (size_t)VB_HEAVY_CAP + (size_t)B * L * g.nt;
+        if ((rc = ctx->vb_heavy.reserve(ints * sizeof(int)))) return rc;
+        EHR_HIP(hipMemset(ctx->vb_heavy.ptr, 0, ints * sizeof(int)));
+    }
     if ((rc = ctx->vb_idx.reserve((size_t)2 * std::max(T, 1) * sizeof(int4)))) return rc;
     if (T > 0) {
         vb_pad_kernel<<<(T + 255) / 256, 256>>>(tris, T, (int4*)ctx->vb_idx.ptr);
@@ -1323,6 +1420,9 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
         int m8[8];
         EHR_HIP(hipMemcpy(m8, (char*)ctx->vb_acc.ptr + off, sizeof(m8), hipMemcpyDeviceToHost));
         fprintf(stderr, "[ehr vbuf] overflow %d spill %d jobs %d\n", m8[EHR_META_OVERFLOW], m8[EHR_META_SPILL], m8[5]);
+        int hg[3];
+        EHR_HIP(hipMemcpy(hg, ctx->vb_heavy.ptr, sizeof(hg), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ehr vbuf] heavy jobs: generation %d, lists %d / %d\n", hg[0], hg[1], hg[2]);
         int cur[8];
         EHR_HIP(hipMemcpy(cur, (char*)ctx->vb_acc.ptr + off + 32 * sizeof(int), sizeof(cur), hipMemcpyDeviceToHost));
         fprintf(stderr, "[ehr vbuf] job cursors %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
@@ -1363,6 +1463,10 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     cl.coff = cl.clink + NC1;
     cl.laabb = (const float*)(cl.coff + L + 1);
     cl.NC = NC;
+    VbHeavy hv;
+    hv.gen = (int*)ctx->vb_heavy.ptr;
+    hv.list = hv.gen + 4;
+    hv.stamp = hv.list + 2 * VB_HEAVY_CAP;
     VbRecs recs;
     recs.n = (size_t)B * NC1 * 64;
     recs.tdep = (float4*)ctx->vb_boxes.ptr;
@@ -1391,11 +1495,11 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     const dim3 vgrid(gx * B);
     if (head) {
         vb_vertex_kernel<true><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, *head, mvp, V, nvb, g, posc, recs,
-                                                         lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views);
+                                                         lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views, hv);
     } else {
         StepHead none = {};
         vb_vertex_kernel<false><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, none, mvp, V, nvb, g, posc, recs,
-                                                          lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views);
+                                                          lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views, hv);
     }
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[1], stream));
@@ -1410,7 +1514,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     int* jbase = jspill + nslot;
     vb_job_kernel<<<((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7, 256, 0, stream>>>(
         g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T, cl, recs, lbox, jn, jval, jitems, jspill, jbase, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
-        VB_SPILL_ITEMS, meta, dbg);
+        VB_SPILL_ITEMS, meta, dbg, hv);
     EHR_LAUNCH_CHECK();
     if (ev) {
         for (int k = 2; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
