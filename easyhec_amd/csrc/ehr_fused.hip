@@ -633,10 +633,10 @@ static int fused_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, co
     if (ev) EHR_HIP(hipEventRecord(ev[6], stream));
     // stage 4: accumulators -> loss / grad_mvp (+ pose backward and Adam in the solver-step form), one workgroup
     if (tail) {
-        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail, 1, nullptr);
+        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail, 1, nullptr, 1);
     } else {
         StepTail none = {};
-        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none, 1, nullptr);
+        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none, 1, nullptr, 1);
     }
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[7], stream));

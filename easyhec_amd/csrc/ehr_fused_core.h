@@ -43,23 +43,24 @@ template <bool TAIL>
 __global__ void __launch_bounds__(256) fused_finish_kernel(BinGeom g, int B, const long long* __restrict__ facc,
                                                            float* __restrict__ loss, float* __restrict__ grad_mvp,
                                                            const int* __restrict__ meta, StepTail tail, int nls,
-                                                           int* __restrict__ lbox) {
+                                                           int* __restrict__ lbox, int lstride) {
     // per view: 12 numbers per link, then `nls` partial sums of the frame loss (several slots so that thousands of
     // tiles do not serialise on one address; integer sums, so the split does not change the result)
     const int tid = threadIdx.x, L = g.L;
-    const int acc_stride = 12 * L + nls;
+    // (`lstride` i64 apart: the visibility-buffer chain gives every slot a 128-byte line of its own)
+    const int acc_stride = 12 * L + nls * lstride;
     __shared__ float vloss[256];  // frame loss of up to 256 views per pass (summed once, read many times below)
     if (lbox)  // visibility-buffer chain: the links' screen boxes start "empty" in the next step
         for (int i = tid; i < 16 * B * L; i += 256) lbox[i] = (i & 2) ? INT_MIN : INT_MAX;  // 16 ints (one line) per box
     auto view_loss_slow = [&](int b) {
         long long s = 0;
-        for (int k = 0; k < nls; k++) s += facc[(size_t)b * acc_stride + 12 * L + k];
+        for (int k = 0; k < nls; k++) s += facc[(size_t)b * acc_stride + 12 * L + k * lstride];
         return fix_get(s);
     };
     if (nls == 32) {  // one slot per lane, half a wave per view: a single round trip instead of 32 dependent adds
         for (int base = 0; base < min(B, 256); base += 8) {
             const int b = base + (tid >> 5), k = tid & 31;
-            long long s = (b < B) ? facc[(size_t)b * acc_stride + 12 * L + k] : 0;
+            long long s = (b < B) ? facc[(size_t)b * acc_stride + 12 * L + k * lstride] : 0;
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
             if (k == 0 && b < B && b < 256) vloss[b] = fix_get(s);

@@ -42,6 +42,7 @@ struct Scratch {
 struct StepHead;
 struct StepTail;
 #define VB_LOSS_SLOTS 32          // partial frame-loss sums per view (spreads same-address atomics)
+#define VB_LOSS_STRIDE 16         // i64 between two of them: one 128-byte line each (atomics on one line serialise)
 #define VB_MAX_UNITS 512          // views x links one context plans for
 #define VB_SPILL_ITEMS (1 << 20)  // pool of blended-pair items for tiles that overflow their LDS list (16 MB)
 int vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
@@ -79,7 +80,7 @@ struct ehr_ctx {
     int vb_jcap = 0;         // job slots
     ehr::Scratch vb_boxes;   // uint2 pixel boxes of the current step: tbox [B][NC][64] | cbox [B][NC]
     ehr::Scratch vb_units;   // i32 [B][L][4] pixel boxes of the links (re-armed by the finish kernel)
-    ehr::Scratch vb_acc;     // i64 [B][12 L + VB_LOSS_SLOTS] fixed-point sums, then the meta words
+    ehr::Scratch vb_acc;     // i64 [B][12 L + VB_LOSS_SLOTS * VB_LOSS_STRIDE] fixed-point sums, then the meta words
     ehr::Scratch vb_posc;    // float4 [B][V] clip-space vertices
     ehr::Scratch vb_jobs;    // per (view, link, tile) job slot: value tile | blended pairs | count | spill base
     ehr::Scratch vb_spill;   // blended pairs of jobs that exceed their slot

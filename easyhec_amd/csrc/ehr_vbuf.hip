@@ -1,27 +1,34 @@
-// ehr_vbuf.hip -- the fused hot path, visibility-buffer form (round 2).  Same arithmetic and outputs as the LDS-tile
-// chain in ehr_fused.hip, restating
+// ehr_vbuf.hip -- the fused hot path, visibility-buffer form (round 2; the default).  Same arithmetic and outputs as the
+// LDS-tile chain in ehr_fused.hip (kept behind EHR_FUSED_PATH=tile), restating
 //   /root/reference/easyhec/modeling/models/rb_solve/rb_solver.py:60-72   (per-link render, sum, clamp, SSE)
 //   /root/reference/easyhec/structures/nvdiffrast_renderer.py:33-47        (rasterize -> interpolate -> antialias -> flip)
 //   /root/reference/easyhec/utils/nvdiffrast_utils.py:14-18                (transform_pos)
-// but without triangle binning and without a per-tile rasterizer.  The xArm7 / Franka meshes project to micro-triangles
-// (median bounding box 8 px, a quarter of them cover no pixel centre at all), for which building and draining per-tile
-// queues costs more than the coverage tests themselves.  Here:
+// but without per-step triangle binning: no (tile, link) queues are built, counted, allocated or filled.  The meshes
+// project to micro-triangles (median bounding box 8 px, a quarter of them cover no pixel centre at all), for which
+// building and draining per-tile queues cost more than the coverage tests themselves.  Instead ehr_fused_plan groups
+// every link's triangles ONCE into clusters of 64 spatially close ones (Morton order of the centroids in object space,
+// valid for every pose), and a step is four launches:
 //
-//   vb_vertex_kernel   [pose forward] + clip-space vertices + housekeeping: the depth keys written by the PREVIOUS
-//                      step are reset (only the tiles that step marked), accumulators zeroed.
-//   vb_raster_kernel   one thread per (view, triangle): snap, exact integer coverage over its pixel box, and for every
-//                      covered pixel centre one 64-bit atomic-min of  ordered(z/w) << 32 | triangle  into the
-//                      (view, link) key image in HBM/L2.  The minimum is order independent, so the result is the
-//                      oracle's nearest-wins / lowest-index-wins z-buffer bit for bit.  Boxes above VB_SMALL_BOX
-//                      pixels are walked by the whole wave (64 pixels per step) instead of one lane.  Every triangle
-//                      also marks the 32x8 tiles its box (+1 pixel) touches in a per-tile link bitmask.
-//   vb_resolve_kernel  one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers).
-//                      Unmarked tiles stream (mask = 0, loss += ref^2).  For each marked link the wave loads the
-//                      tile + halo keys, finds covered/uncovered pixel pairs with wave-uniform bit arithmetic on the
-//                      coverage bitmap, runs the silhouette analysis on the compacted hits, gathers the antialias
-//                      blend per pixel in the oracle's order, composites, and back-propagates the blended pairs to
-//                      12 numbers per link which go to the view's fixed-point accumulators.
-//   fused_finish_kernel (shared with the tile chain)  accumulators -> loss / grad_mvp [-> pose backward -> Adam].
+//   vb_vertex_kernel    [pose forward] + clip-space vertices (posc) + one wave per cluster: transforms the cluster's
+//                       triangles, snaps them, and publishes per triangle its pixel box (tbox), its raster record
+//                       (integer edge functions with the tie rule folded in, trec) and its clip-space vertices (tdep);
+//                       per cluster and per link the union of the boxes (cbox; lbox through integer atomics).
+//   vb_job_kernel       one WAVE per job = (view, link, 32x8 tile the link's box touches), persistent waves over a job
+//                       list that is never materialised.  A job culls cluster boxes, then triangle boxes, rasterizes the
+//                       survivors with a wave-wide balanced walker into its LDS depth/id buffer (ds_min_u64 on
+//                       ordered(z/w) << 32 | triangle: order independent, hence the oracle's z-buffer bit for bit), finds
+//                       the covered/uncovered pixel pairs with bit arithmetic on the coverage bitmap, runs the silhouette
+//                       analysis and leaves the link's 256 antialiased values + the blended pairs in the job's slot.
+//                       Jobs that were heavy in the previous step go first, one workgroup each.
+//   vb_composite_kernel one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses): sums the links' values in link
+//                       order, clamps, frame loss, mask write, and back-propagates the tile's blended pairs to 12 numbers
+//                       per link which go to the view's fixed-point accumulators.  Tiles no link touches just stream.
+//   fused_finish_kernel (shared with the tile chain)  accumulators -> loss / grad_mvp [-> pose backward -> Adam];
+//                       re-arms the link boxes.
+//
+// An earlier form of this file kept the depth/id image in HBM and resolved visibility with one 64-bit global atomic-min
+// per covered pixel; global atomics execute memory-side on this part (4.6 G/s with raster locality: 272 us for the
+// 1.26 M fragments of the 8-view workload), see DESIGN.md section 6.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -44,6 +51,13 @@ constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per ov
 constexpr u64 VB_EMPTY = ~0ull;
 #define VB_SMALL_BOX 16                // pixel boxes up to this size are walked by the triangle's own lane
 #define VB_FAST_EXTENT 8192            // snapped extent (1/16 px) up to which 32-bit edge functions are exact
+
+// Counters that many waves hit with atomics each get a 128-byte line of their own behind the meta block (atomics on
+// one line serialise memory-side at ~12 ns each): line xcd = job cursor of that XCD, line 8 + xcd = its drawn jobs.
+#define VB_LINES 16
+__host__ __device__ __forceinline__ int* vb_line(int* meta, int k) {
+    return (int*)((((uintptr_t)(meta + EHR_META_INTS)) + 127) & ~(uintptr_t)127) + 32 * k;
+}
 
 #define VB_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #ifdef VB_PHASE_TIMING  // profiling build only (-DVB_PHASE_TIMING): cycles per phase, kept per wave, summed at its end
@@ -197,7 +211,6 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         b = blockIdx.x / gx;
         bx = blockIdx.x - b * gx;
     }
-    (void)B;
     const int tid = threadIdx.x, L = g.L, H = g.H, W = g.W;
     const bool first = bx == 0 && b == 0;
     const bool vpath = bx < nvb;
@@ -263,9 +276,12 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             const int n = min(hv.gen[1 + cur], VB_HEAVY_CAP);
             for (int i = tid; i < n; i += 256) hv.stamp[hv.list[cur * VB_HEAVY_CAP + i]] = gen;
         }
-        for (int i = tid; i < nzacc; i += 256) zacc[i] = 0;  // fixed-point accumulators (a few KB)
         if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
-        if (tid < 8) meta[32 + tid] = 0;                     // job cursors of the 8 XCDs
+        if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors and drawn-job counts of the 8 XCDs
+    }
+    if (bx == 0) {  // fixed-point accumulators of this view (a few KB)
+        const int nzv = nzacc / B;
+        for (int i = tid; i < nzv; i += 256) zacc[(size_t)b * nzv + i] = 0;
     }
     __syncthreads();
     if (HEAD) {
@@ -618,16 +634,14 @@ __device__ __forceinline__ void vb_raster_round(bool sv, size_t slot, const VbRe
     }
 }
 
-struct VbResolveLds {
+struct alignas(16) VbResolveLds {  // per wave of the resolve kernel
+    unsigned ids[VB_RN];         // triangle id of each region pixel (all-ones = uncovered), copied from the job's slot
     float pairA[2 * VB_RN];      // blend weight of pair (q, d) at [d * RN + q]
     unsigned short hits[2 * VB_RN];
 };
-struct alignas(16) VbWaveLds {
+struct alignas(16) VbWaveLds {   // per wave of the job kernel
     u64 key[VB_RN];              // depth/id of each region pixel: ordered(z/w) << 32 | triangle, all-ones = uncovered
-    union {
-        VbRaster R;              // while the link is being rasterized
-        VbResolveLds Z;          // afterwards
-    } u;
+    VbRaster R;                  // staging area of the rasterizer rounds
     unsigned sq[128];            // survivors of the box culling waiting for a full round: record slots (ring)
 };
 
@@ -654,10 +668,8 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 #define VB_JOB_WAVES 4
 #endif
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
-vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const int4* __restrict__ tri4,
-              const int4* __restrict__ opp4, VbClusters cl, VbRecs rc, const int* __restrict__ lbox,
-              int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems, int* __restrict__ jspill,
-              int* __restrict__ jbase, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
+vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
+              unsigned* __restrict__ jid, int2* __restrict__ dlist, int* __restrict__ jbase, int jcap,
               int* __restrict__ meta, int dbg, VbHeavy hv) {
     __shared__ VbWaveLds lds_all[4];
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
@@ -665,7 +677,6 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
     __shared__ int lcoff[33];                 // first cluster of every link
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbWaveLds& S = lds_all[wave];
-#define KT(i) (reinterpret_cast<const unsigned*>(S.key)[2 * (i)])  // triangle id of region pixel i (all-ones = uncovered)
     const int W = g.W, H = g.H, L = g.L, U = B * L;
     // ---- prologue (every workgroup, redundantly): tile range and job count of every (view, link), prefix sum
     if (tid <= L) lcoff[tid] = cl.coff[tid];
@@ -710,7 +721,7 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
     // same-address atomic) and the kernel is 20 % slower.
     const int per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
     const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
-    int* const cursor = meta + 32 + xcd;
+    int* const cursor = vb_line(meta, xcd);
     long long ph_last = __builtin_readcyclecounter();
     long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     (void)ph_last;
@@ -777,7 +788,7 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
                         VB_PHASE(7);  // triangle box culling
                         if (qn >= 64) {
                             VB_WAVE_SYNC();
-                            vb_raster_round(true, vbase + W_.sq[(qh + lane) & 127], rc, rg, rx0, ry0, W, H, W_.u.R, key_, ph_acc, ph_last);
+                            vb_raster_round(true, vbase + W_.sq[(qh + lane) & 127], rc, rg, rx0, ry0, W, H, W_.R, key_, ph_acc, ph_last);
                             qh = (qh + 64) & 127;
                             qn -= 64;
                         }
@@ -787,191 +798,25 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
             if (qn) {
                 VB_WAVE_SYNC();
                 const bool sv = lane < qn;
-                vb_raster_round(sv, vbase + (sv ? W_.sq[(qh + lane) & 127] : 0u), rc, rg, rx0, ry0, W, H, W_.u.R, key_, ph_acc, ph_last);
+                vb_raster_round(sv, vbase + (sv ? W_.sq[(qh + lane) & 127] : 0u), rc, rg, rx0, ry0, W, H, W_.R, key_, ph_acc, ph_last);
             }
             return drawn;
         };
-    // Everything after the coverage of a job is complete in S.key: pair discovery, silhouette analysis, gather, publish.
-    auto resolve = [&](VbWaveLds& S, int b, int l, int tx, int ty, size_t slot, const VbRegion& rg, int rx0, int ry0) {
-        (void)l; (void)tx; (void)ty;
-        const int r = lane >> 3, c4 = (lane & 7) * 4;
-        const int myq = (r + 1) * VB_RW + (c4 + 1);
-        const float4* const pv = posc + (size_t)b * V;
-        int nitems = 0;       // wave-uniform
-        int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
+    // A drawn job leaves the triangle id of every region pixel in its slot and its descriptor in the list of the XCD that
+    // owns the job; the resolve kernel takes it from there.
+    auto publish = [&](const u64* key_, int job, int u, int tx, int ty) {
         VB_WAVE_SYNC();
-        VB_PHASE(1);
-        for (int i = lane; i < 2 * VB_RN; i += 64) S.u.Z.pairA[i] = 0.f;  // aliases the raster scratch
-        // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
-        u64 Iw[VB_WORDS];
+        unsigned* const dst = jid + (size_t)job * VB_RN;
 #pragma unroll
         for (int k = 0; k < VB_WORDS; k++) {
             const unsigned i = 64u * k + lane;
-            const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
-            const int x = rx0 + qx, y = ry0 + qy;
-            Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
+            if (i < (unsigned)VB_RN) dst[i] = (unsigned)key_[i];  // low word = triangle id; all-ones stays all-ones
         }
-        u64 Vh[VB_WORDS], Vv[VB_WORDS];
-        {
-            // compile-time bitmaps (forced: a constexpr call with a loop index is otherwise evaluated at run time)
-            constexpr u64 KH[VB_WORDS] = {vb_word_h(0), vb_word_h(1), vb_word_h(2), vb_word_h(3), vb_word_h(4), vb_word_h(5)};
-            constexpr u64 KV[VB_WORDS] = {vb_word_v(0), vb_word_v(1), vb_word_v(2), vb_word_v(3), vb_word_v(4), vb_word_v(5)};
-            static_assert(VB_WORDS == 6, "tables above");
-            u64 s1[VB_WORDS], s34[VB_WORDS];
-            vb_shr<1>(Iw, s1);
-            vb_shr<VB_RW>(Iw, s34);
-#pragma unroll
-            for (int k = 0; k < VB_WORDS; k++) {
-                Vh[k] = Iw[k] & s1[k] & KH[k];
-                Vv[k] = Iw[k] & s34[k] & KV[k];
-            }
-        }
-        u64 C[VB_WORDS];
-#pragma unroll
-        for (int k = 0; k < VB_WORDS; k++) {
-            const unsigned i = 64u * k + lane;
-            C[k] = __ballot(i < (unsigned)VB_RN && S.key[i] != VB_EMPTY);
-        }
-        // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
-        //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
-        u64 Hw[2 * VB_WORDS];
-        int nh = 0;
-        {
-            u64 s1[VB_WORDS], s34[VB_WORDS];
-            vb_shr<1>(C, s1);
-            vb_shr<VB_RW>(C, s34);
-#pragma unroll
-            for (int k = 0; k < VB_WORDS; k++) {
-                Hw[k] = (C[k] ^ s1[k]) & Vh[k];
-                Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
-                nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
-            }
-        }
-        VB_WAVE_SYNC();
-        float val[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) val[j] = (KT(myq + j) != 0xffffffffu) ? 1.f : 0.f;
-        if (dbg & 2) nh = 0;
-        if (nh != 0) {
-            // ---- dense hit list, ordered by (direction, region index)
-            {
-                int base = 0;
-#pragma unroll
-                for (int s = 0; s < 2 * VB_WORDS; s++) {
-                    const u64 w = Hw[s];
-                    if (w) {
-                        if ((w >> lane) & 1)
-                            S.u.Z.hits[base + vb_mbcnt(w)] = (unsigned short)(((s % VB_WORDS) * 64 + lane) | ((s / VB_WORDS) << 15));
-                        base += __popcll(w);
-                    }
-                }
-            }
-            VB_WAVE_SYNC();
-            // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
-            for (int hbase = 0; hbase < nh; hbase += 64) {
-                const int h = hbase + lane;
-                VbItem it;
-                it.packed = 0;
-                it.v1 = 0;
-                it.v2 = 0;
-                it.alpha = 0.f;
-                bool keep = false;
-                if (h < nh) {
-                    const int hq = S.u.Z.hits[h];
-                    const int d = hq >> 15, q = hq & 0x7fff;
-                    const int qy = q / VB_RW, qx = q - qy * VB_RW;
-                    const int nq = q + (d ? VB_RW : 1);
-                    const unsigned k0 = KT(q), k1 = KT(nq);
-                    const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
-                    const int t = (int)(chose0 ? k0 : k1);
-                    int px = rx0 + qx, py = ry0 + qy;
-                    if (!chose0) {
-                        px += 1 - d;
-                        py += d;
-                    }
-                    float4 p[3], o[3];
-                    const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
-                    const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
-#pragma unroll
-                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
-#pragma unroll
-                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
-                    const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
-                    if (a.found) {
-                        S.u.Z.pairA[d * VB_RN + q] = a.alpha;
-                        // keep for the backward pass if the destination pixel is interior to this tile
-                        const int oq = (a.alpha > 0.f) ? q : nq;
-                        const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
-                        const bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
-                        if (oi && a.alpha != 0.f) {
-                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
-                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
-                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
-                            it.alpha = a.alpha;
-                            keep = want_grad != 0;
-                        }
-                    }
-                }
-                const u64 km = __ballot(keep);
-                if (km) {
-                    const int at = nitems + vb_mbcnt(km);
-                    const int nnew = nitems + __popcll(km);
-                    if (nnew > VB_JOB_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this job
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
-                        spill_base = __builtin_amdgcn_readfirstlane(base);
-                    }
-                    if (keep) {
-                        if (at < VB_JOB_ITEMS) {
-                            jitems[slot * VB_JOB_ITEMS + at] = it;
-                        } else {
-                            const int gi = at - VB_JOB_ITEMS;
-                            if (gi < VB_SPILL_BLOCK && spill_base + gi < spill_cap)
-                                spill[spill_base + gi] = it;
-                            else
-                                meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
-                        }
-                    }
-                    nitems = min(nnew, VB_JOB_ITEMS + VB_SPILL_BLOCK);
-                }
-            }
-            VB_WAVE_SYNC();
-            // ---- gather the antialiased value of this link at my pixels (fixed order: down, left, right, up pair)
-            {
-                float cn[6], cd[4], cu[4];
-#pragma unroll
-                for (int j = 0; j < 6; j++) cn[j] = (KT(myq - 1 + j) != 0xffffffffu) ? 1.f : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    cd[j] = (KT(myq - VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
-                    cu[j] = (KT(myq + VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float c = cn[j + 1];
-                    float v = c;
-                    float a;
-                    a = S.u.Z.pairA[VB_RN + myq + j - VB_RW];
-                    if (a < 0.f) v += a * (c - cd[j]);
-                    a = S.u.Z.pairA[myq + j - 1];
-                    if (a < 0.f) v += a * (c - cn[j]);
-                    a = S.u.Z.pairA[myq + j];
-                    if (a > 0.f) v += a * (cn[j + 2] - c);
-                    a = S.u.Z.pairA[VB_RN + myq + j];
-                    if (a > 0.f) v += a * (cu[j] - c);
-                    val[j] = v;
-                }
-            }
-        }
-        VB_PHASE(5);  // pairs, analysis, gather
-        // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
-        const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
-        if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
         if (lane == 0) {
-            jn[slot] = nz ? nitems : -1;
-            if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
+            const int owner = min(job / max(per_xcd, 1), 7);
+            const int at = atomicAdd(vb_line(meta, 8 + owner), 1);
+            dlist[owner * per_xcd + at] = make_int2(job, u | (tx << 9) | (ty << 19));
         }
-        VB_WAVE_SYNC();
         VB_PHASE(6);  // publish
     };
     // ---- heavy jobs first, one workgroup each: the four waves share the job's depth/id buffer (wave 0's) and split the
@@ -1027,7 +872,7 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
                 if (tot_surv >= VB_HEAVY_T) remember_heavy(id);
             }
             if (any_drawn)
-                resolve(S0, b, l, tx, ty, (size_t)job, rg, rx0, ry0);
+                publish(S0.key, job, u, tx, ty);
             else if (lane == 0)
                 jn[job] = -1;
         }
@@ -1096,13 +941,232 @@ vb_job_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const in
             if (lane == 0) jn[slot] = -1;
             continue;
         }
-        resolve(S, b, l, tx, ty, slot, rg, rx0, ry0);
+        publish(S.key, job, u, tx, ty);
     }
 #ifdef VB_PHASE_TIMING
     if (lane == 0)
         for (int i = 0; i < 8; i++)
             if (ph_acc[i]) atomicAdd((unsigned long long*)(meta + 8) + i, (unsigned long long)ph_acc[i]);
 #endif
+}
+
+// Stage 2b: one WAVE per DRAWN job, persistent waves over the per-XCD lists the job kernel appended to.  From the
+// triangle ids of the job's region (tile + 1-pixel halo): covered/uncovered pixel pairs by wave-uniform bit arithmetic on
+// the coverage bitmap, silhouette analysis of the compacted hits (restates nvdiffrast's antialias mesh kernel), gather of
+// the link's antialiased value per pixel in the oracle's order.  Leaves in the job's slot the 256 values (jval), the
+// blended pairs the backward pass needs (jitems) and their number (jn; -1 = the link contributes nothing here).
+// A kernel of its own because its registers (36 wave-uniform 64-bit bitmaps, 24 floats of vertex positions per hit)
+// and the rasterizer's do not fit 128 VGPRs together: fused, the job kernel kept 350 bytes per lane in scratch and its
+// 4096 waves' 91 MB of scratch evicted each other from the 4 MB L2s.
+__global__ void __launch_bounds__(256)
+vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const int4* __restrict__ tri4,
+                  const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const int2* __restrict__ dlist,
+                  int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems,
+                  int* __restrict__ jspill, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
+                  int* __restrict__ meta, int dbg) {
+    __shared__ VbResolveLds lds_all[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    VbResolveLds& S = lds_all[wave];
+#define KT(i) (S.ids[i])
+    const int W = g.W, H = g.H, L = g.L;
+    (void)B;
+    const int total = min(meta[5], jcap), per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
+    const int n = *vb_line(meta, 8 + xcd);
+    const int2* const mine = dlist + (size_t)xcd * per_xcd;
+    const int step = (int)(gridDim.x >> 3) * 4;
+    for (int e = (int)(blockIdx.x >> 3) * 4 + wave; e < n; e += step) {
+        const int2 de = mine[e];
+        const size_t slot = (size_t)de.x;
+        const int u = de.y & 511, tx = (de.y >> 9) & 1023, ty = (de.y >> 19) & 4095;
+        const int b = u / L;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        VB_WAVE_SYNC();  // the previous job's reads of S are complete
+        {
+            const unsigned* const src = jid + slot * VB_RN;
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                const unsigned i = 64u * k + lane;
+                if (i < (unsigned)VB_RN) S.ids[i] = src[i];
+            }
+        }
+        const int r = lane >> 3, c4 = (lane & 7) * 4;
+        const int myq = (r + 1) * VB_RW + (c4 + 1);
+        const float4* const pv = posc + (size_t)b * V;
+        int nitems = 0;       // wave-uniform
+        int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
+        VB_WAVE_SYNC();
+        for (int i = lane; i < 2 * VB_RN; i += 64) S.pairA[i] = 0.f;
+        // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
+        u64 Iw[VB_WORDS];
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
+            const int x = rx0 + qx, y = ry0 + qy;
+            Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
+        }
+        u64 Vh[VB_WORDS], Vv[VB_WORDS];
+        {
+            // compile-time bitmaps (forced: a constexpr call with a loop index is otherwise evaluated at run time)
+            constexpr u64 KH[VB_WORDS] = {vb_word_h(0), vb_word_h(1), vb_word_h(2), vb_word_h(3), vb_word_h(4), vb_word_h(5)};
+            constexpr u64 KV[VB_WORDS] = {vb_word_v(0), vb_word_v(1), vb_word_v(2), vb_word_v(3), vb_word_v(4), vb_word_v(5)};
+            static_assert(VB_WORDS == 6, "tables above");
+            u64 s1[VB_WORDS], s34[VB_WORDS];
+            vb_shr<1>(Iw, s1);
+            vb_shr<VB_RW>(Iw, s34);
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                Vh[k] = Iw[k] & s1[k] & KH[k];
+                Vv[k] = Iw[k] & s34[k] & KV[k];
+            }
+        }
+        u64 C[VB_WORDS];
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            C[k] = __ballot(i < (unsigned)VB_RN && S.ids[i] != 0xffffffffu);
+        }
+        // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
+        //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
+        u64 Hw[2 * VB_WORDS];
+        int nh = 0;
+        {
+            u64 s1[VB_WORDS], s34[VB_WORDS];
+            vb_shr<1>(C, s1);
+            vb_shr<VB_RW>(C, s34);
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                Hw[k] = (C[k] ^ s1[k]) & Vh[k];
+                Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
+                nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
+            }
+        }
+        VB_WAVE_SYNC();
+        float val[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) val[j] = (KT(myq + j) != 0xffffffffu) ? 1.f : 0.f;
+        if (dbg & 2) nh = 0;
+        if (nh != 0) {
+            // ---- dense hit list, ordered by (direction, region index)
+            {
+                int base = 0;
+#pragma unroll
+                for (int s = 0; s < 2 * VB_WORDS; s++) {
+                    const u64 w = Hw[s];
+                    if (w) {
+                        if ((w >> lane) & 1)
+                            S.hits[base + vb_mbcnt(w)] = (unsigned short)(((s % VB_WORDS) * 64 + lane) | ((s / VB_WORDS) << 15));
+                        base += __popcll(w);
+                    }
+                }
+            }
+            VB_WAVE_SYNC();
+            // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
+            for (int hbase = 0; hbase < nh; hbase += 64) {
+                const int h = hbase + lane;
+                VbItem it;
+                it.packed = 0;
+                it.v1 = 0;
+                it.v2 = 0;
+                it.alpha = 0.f;
+                bool keep = false;
+                if (h < nh) {
+                    const int hq = S.hits[h];
+                    const int d = hq >> 15, q = hq & 0x7fff;
+                    const int qy = q / VB_RW, qx = q - qy * VB_RW;
+                    const int nq = q + (d ? VB_RW : 1);
+                    const unsigned k0 = KT(q), k1 = KT(nq);
+                    const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
+                    const int t = (int)(chose0 ? k0 : k1);
+                    int px = rx0 + qx, py = ry0 + qy;
+                    if (!chose0) {
+                        px += 1 - d;
+                        py += d;
+                    }
+                    float4 p[3], o[3];
+                    const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
+                    const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
+                    const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
+                    if (a.found) {
+                        S.pairA[d * VB_RN + q] = a.alpha;
+                        // keep for the backward pass if the destination pixel is interior to this tile
+                        const int oq = (a.alpha > 0.f) ? q : nq;
+                        const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+                        const bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
+                        if (oi && a.alpha != 0.f) {
+                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
+                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
+                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
+                            it.alpha = a.alpha;
+                            keep = want_grad != 0;
+                        }
+                    }
+                }
+                const u64 km = __ballot(keep);
+                if (km) {
+                    const int at = nitems + vb_mbcnt(km);
+                    const int nnew = nitems + __popcll(km);
+                    if (nnew > VB_JOB_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this job
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
+                        spill_base = __builtin_amdgcn_readfirstlane(base);
+                    }
+                    if (keep) {
+                        if (at < VB_JOB_ITEMS) {
+                            jitems[slot * VB_JOB_ITEMS + at] = it;
+                        } else {
+                            const int gi = at - VB_JOB_ITEMS;
+                            if (gi < VB_SPILL_BLOCK && spill_base + gi < spill_cap)
+                                spill[spill_base + gi] = it;
+                            else
+                                meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
+                        }
+                    }
+                    nitems = min(nnew, VB_JOB_ITEMS + VB_SPILL_BLOCK);
+                }
+            }
+            VB_WAVE_SYNC();
+            // ---- gather the antialiased value of this link at my pixels (fixed order: down, left, right, up pair)
+            {
+                float cn[6], cd[4], cu[4];
+#pragma unroll
+                for (int j = 0; j < 6; j++) cn[j] = (KT(myq - 1 + j) != 0xffffffffu) ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    cd[j] = (KT(myq - VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                    cu[j] = (KT(myq + VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float c = cn[j + 1];
+                    float v = c;
+                    float a;
+                    a = S.pairA[VB_RN + myq + j - VB_RW];
+                    if (a < 0.f) v += a * (c - cd[j]);
+                    a = S.pairA[myq + j - 1];
+                    if (a < 0.f) v += a * (c - cn[j]);
+                    a = S.pairA[myq + j];
+                    if (a > 0.f) v += a * (cn[j + 2] - c);
+                    a = S.pairA[VB_RN + myq + j];
+                    if (a > 0.f) v += a * (cu[j] - c);
+                    val[j] = v;
+                }
+            }
+        }
+            // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
+        const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
+        if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
+        if (lane == 0) {
+            jn[slot] = nz ? nitems : -1;
+            if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
+        }
+        VB_WAVE_SYNC();
+        VB_PHASE(6);  // publish
+    }
 #undef KT
 }
 
@@ -1128,9 +1192,9 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     if (wg >= nwg || gw >= B * g.nt) return;
     const int b = gw / g.nt, tile = gw - b * g.nt;
     const int tx = tile % g.ntx, ty = tile / g.ntx;
-    const int acc_stride = 12 * L + nls;
+    const int acc_stride = 12 * L + nls * VB_LOSS_STRIDE;
     long long* const vacc = facc + (size_t)b * acc_stride;
-    long long* const lacc = vacc + 12 * L + (tile % nls);
+    long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
 
     const int r = lane >> 3, c4 = (lane & 7) * 4;
     const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
@@ -1373,13 +1437,14 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     int rc;
     if ((rc = vb_build_clusters(ctx, L, V, T, verts, tris, tri_link))) return rc;
     const int NC = std::max(ctx->vb_nc, 1);
-    if ((rc = ctx->vb_acc.reserve(((size_t)B * (12 * (size_t)L + VB_LOSS_SLOTS)) * sizeof(long long) + EHR_META_INTS * sizeof(int)))) return rc;
+    if ((rc = ctx->vb_acc.reserve(((size_t)B * (12 * (size_t)L + VB_LOSS_SLOTS * VB_LOSS_STRIDE)) * sizeof(long long) + EHR_META_INTS * sizeof(int) + (VB_LINES + 1) * 128))) return rc;
     if ((rc = ctx->vb_posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
     // per step and (view, cluster slot): tdep 48 B | trec 32 B | tbox 8 B, then cbox 8 B per (view, cluster)
     if ((rc = ctx->vb_boxes.reserve((size_t)B * NC * (64 * 88 + 8)))) return rc;
     if ((rc = ctx->vb_spill.reserve((size_t)VB_SPILL_ITEMS * sizeof(VbItem)))) return rc;
     if ((rc = ctx->vb_units.reserve((size_t)VB_LBOX_STRIDE * B * L * sizeof(int)))) return rc;
-    {  // job slots, compact (numbered like the jobs): value tile 1 KB | items 1 KB | count | spill base; then the links' first jobs
+    {  // job slots, compact (numbered like the jobs): value tile 1 KB | items 1 KB | count | spill base | region ids 1.36 KB;
+       // then the drawn-job lists and the links' first jobs
         BinGeom g = make_geom(H, W, L);
         // a job = a (link, tile) pair whose boxes touch: `slack` tiles-worth of links per view (default 4 = every pixel
         // under four link boxes), never more than all of them
@@ -1388,8 +1453,9 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         if (want > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles exceeds 2e9");
         ctx->vb_jcap = (int)want;
         const size_t nslot = (size_t)ctx->vb_jcap;
-        if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + 2 * sizeof(int)) +
-                                       (size_t)B * L * sizeof(int)))) return rc;
+        if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + 2 * sizeof(int) +
+                                                VB_RN * sizeof(unsigned) + sizeof(int2)) +
+                                       8 * sizeof(int2) + (size_t)B * L * sizeof(int)))) return rc;
     }
     {  // heavy-job hint: generation + two counts | two lists | stamp table
         BinGeom g = make_geom(H, W, L);
@@ -1414,7 +1480,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
 }
 
 int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
-    const size_t off = (size_t)ctx->pB * (12 * (size_t)ctx->pL + VB_LOSS_SLOTS) * sizeof(long long);
+    const size_t off = (size_t)ctx->pB * (12 * (size_t)ctx->pL + VB_LOSS_SLOTS * VB_LOSS_STRIDE) * sizeof(long long);
     EHR_HIP(hipMemcpy(meta4, (char*)ctx->vb_acc.ptr + off, 4 * sizeof(int), hipMemcpyDeviceToHost));
     if (getenv("EHR_VB_PRINT")) {  // diagnostics
         int m8[8];
@@ -1424,8 +1490,9 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
         EHR_HIP(hipMemcpy(hg, ctx->vb_heavy.ptr, sizeof(hg), hipMemcpyDeviceToHost));
         fprintf(stderr, "[ehr vbuf] heavy jobs: generation %d, lists %d / %d\n", hg[0], hg[1], hg[2]);
         int cur[8];
-        EHR_HIP(hipMemcpy(cur, (char*)ctx->vb_acc.ptr + off + 32 * sizeof(int), sizeof(cur), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ehr vbuf] job cursors %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
+        for (int k = 0; k < 8; k++)
+            EHR_HIP(hipMemcpy(&cur[k], vb_line((int*)((char*)ctx->vb_acc.ptr + off), 8 + k), sizeof(int), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ehr vbuf] drawn jobs per XCD %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
 #ifdef VB_PHASE_TIMING
         unsigned long long ph[9];
         EHR_HIP(hipMemcpy(ph, (char*)ctx->vb_acc.ptr + off + 8 * sizeof(int), sizeof(ph), hipMemcpyDeviceToHost));
@@ -1451,7 +1518,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     BinGeom g = make_geom(H, W, L);
     const int ntiles = B * g.nt;
     long long* facc = (long long*)ctx->vb_acc.ptr;
-    const int acc_stride = 12 * L + VB_LOSS_SLOTS, nacc_ints = 2 * B * acc_stride;
+    const int acc_stride = 12 * L + VB_LOSS_SLOTS * VB_LOSS_STRIDE, nacc_ints = 2 * B * acc_stride;
     int* meta = (int*)(facc + (size_t)B * acc_stride);
     float4* posc = (float4*)ctx->vb_posc.ptr;
     int* lbox = (int*)ctx->vb_units.ptr;
@@ -1511,13 +1578,22 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     VbItem* jitems = (VbItem*)(jval + nslot * 256);
     int* jn = (int*)(jitems + nslot * VB_JOB_ITEMS);
     int* jspill = jn + nslot;
-    int* jbase = jspill + nslot;
-    vb_job_kernel<<<((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7, 256, 0, stream>>>(
-        g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T, cl, recs, lbox, jn, jval, jitems, jspill, jbase, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
-        VB_SPILL_ITEMS, meta, dbg, hv);
+    unsigned* jid = (unsigned*)(jspill + nslot);
+    int2* dlist = (int2*)(jid + nslot * VB_RN);
+    int* jbase = (int*)(dlist + nslot + 8);
+    const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
+    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jn, jid, dlist, jbase, ctx->vb_jcap, meta, dbg, hv);
+    EHR_LAUNCH_CHECK();
+    if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
+    // stage 1b: drawn jobs -> per-link values and blended pairs
+    static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 4;  // tuning knob
+    const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
+    vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
+                                                   jid, dlist, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
+                                                   VB_SPILL_ITEMS, meta, dbg);
     EHR_LAUNCH_CHECK();
     if (ev) {
-        for (int k = 2; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
+        for (int k = 3; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
     }
     // stage 2: composite, loss, mask, backward
     int nwg = (ntiles + 3) / 4;
@@ -1533,10 +1609,10 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     // stage 2: accumulators -> loss / grad_mvp (+ pose backward and Adam in the solver-step form), one workgroup;
     // it also re-arms the link boxes for the next step
     if (tail) {
-        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail, VB_LOSS_SLOTS, lbox);
+        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail, VB_LOSS_SLOTS, lbox, VB_LOSS_STRIDE);
     } else {
         StepTail none = {};
-        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none, VB_LOSS_SLOTS, lbox);
+        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none, VB_LOSS_SLOTS, lbox, VB_LOSS_STRIDE);
     }
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[7], stream));

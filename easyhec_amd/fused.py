@@ -138,7 +138,7 @@ if (_os.environ.get("EHR_FUSED_PATH") or "v")[0] == "t":
     STAGES = ("bin_count", "bin_alloc", "bin_fill", "tile_empty", "tile", "tile_slow", "reduce")
     DOMINANT_STAGE, DOMINANT_KERNEL = "tile", "fused_tile_kernel<false>"
 else:
-    STAGES = ("vertex", "job", "unused2", "unused3", "composite", "unused5", "finish")
+    STAGES = ("vertex", "job", "resolve", "unused3", "composite", "unused5", "finish")
     DOMINANT_STAGE, DOMINANT_KERNEL = "job", "vb_job_kernel"
 
 
