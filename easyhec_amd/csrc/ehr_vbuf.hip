@@ -53,7 +53,7 @@ constexpr u64 VB_EMPTY = ~0ull;
 #define VB_FAST_EXTENT 8192            // snapped extent (1/16 px) up to which 32-bit edge functions are exact
 
 // Counters that many waves hit with atomics each get a 128-byte line of their own behind the meta block (atomics on
-// one line serialise memory-side at ~12 ns each): line xcd = job cursor of that XCD, line 8 + xcd = its drawn jobs.
+// one line serialise memory-side at ~12 ns each): line xcd = job cursor of that XCD.
 #define VB_LINES 16
 __host__ __device__ __forceinline__ int* vb_line(int* meta, int k) {
     return (int*)((((uintptr_t)(meta + EHR_META_INTS)) + 127) & ~(uintptr_t)127) + 32 * k;
@@ -277,7 +277,7 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             for (int i = tid; i < n; i += 256) hv.stamp[hv.list[cur * VB_HEAVY_CAP + i]] = gen;
         }
         if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
-        if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors and drawn-job counts of the 8 XCDs
+        if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors of the 8 XCDs
     }
     if (bx == 0) {  // fixed-point accumulators of this view (a few KB)
         const int nzv = nzacc / B;
@@ -669,9 +669,10 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 #endif
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
 vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
-              unsigned* __restrict__ jid, int2* __restrict__ dlist, int* __restrict__ jbase, int jcap,
-              int* __restrict__ meta, int dbg, VbHeavy hv) {
+              unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, int jcap,
+              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline) {
     __shared__ VbWaveLds lds_all[4];
+    const long long tl_start = (dbg & 128) ? wall_clock64() : 0;  // EHR_VB_DEBUG & 128: a record per wave, see vbuf_meta_read
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
     __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
     __shared__ int lcoff[33];                 // first cluster of every link
@@ -802,8 +803,9 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             }
             return drawn;
         };
-    // A drawn job leaves the triangle id of every region pixel in its slot and its descriptor in the list of the XCD that
-    // owns the job; the resolve kernel takes it from there.
+    // A drawn job leaves the triangle id of every region pixel and its descriptor in its slot; the resolve kernel takes it
+    // from there (an undrawn one the descriptor -1).  No list of drawn jobs: appending to one costs every job a returning
+    // atomic (~3 us under load), and three quarters of the jobs are drawn anyway.
     auto publish = [&](const u64* key_, int job, int u, int tx, int ty) {
         VB_WAVE_SYNC();
         unsigned* const dst = jid + (size_t)job * VB_RN;
@@ -812,11 +814,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             const unsigned i = 64u * k + lane;
             if (i < (unsigned)VB_RN) dst[i] = (unsigned)key_[i];  // low word = triangle id; all-ones stays all-ones
         }
-        if (lane == 0) {
-            const int owner = min(job / max(per_xcd, 1), 7);
-            const int at = atomicAdd(vb_line(meta, 8 + owner), 1);
-            dlist[owner * per_xcd + at] = make_int2(job, u | (tx << 9) | (ty << 19));
-        }
+        if (lane == 0) jdesc[job] = u | (tx << 9) | (ty << 19);
         VB_PHASE(6);  // publish
     };
     // ---- heavy jobs first, one workgroup each: the four waves share the job's depth/id buffer (wave 0's) and split the
@@ -873,8 +871,10 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             }
             if (any_drawn)
                 publish(S0.key, job, u, tx, ty);
-            else if (lane == 0)
+            else if (lane == 0) {
                 jn[job] = -1;
+                jdesc[job] = -1;
+            }
         }
         __syncthreads();
     }
@@ -884,6 +884,8 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     const int hk = (nhw > xcd) ? (nhw - xcd + 7) >> 3 : 0;
     const int kx = blockIdx.x >> 3;                      // this workgroup's index inside its XCD
     const int nsw = ((gridDim.x >> 3) - hk) * 4;         // waves of this XCD that take a static first job
+    const long long tl_heavy = (dbg & 128) ? wall_clock64() : 0;
+    int tl_jobs = 0, tl_maxsurv = 0, tl_sumsurv = 0;
     bool first_job = kx >= hk;
     int sjob = jbeg + (kx - hk) * 4 + wave;
     for (;;) {
@@ -936,12 +938,30 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         VB_WAVE_SYNC();
         int nsurv = 0;
         const bool drawn = raster_share(S, S.key, b, l, rg, rx0, ry0, 0, 1, nsurv);
+        if (dbg & 128) {
+            tl_jobs++;
+            tl_maxsurv = max(tl_maxsurv, nsurv);
+            tl_sumsurv += nsurv;
+        }
         if (nsurv >= VB_HEAVY_T && lane == 0) remember_heavy(dense_id);
         if (!drawn) {  // the link's box touches this tile, its triangles do not
-            if (lane == 0) jn[slot] = -1;
+            if (lane == 0) {
+                jn[slot] = -1;
+                jdesc[slot] = -1;
+            }
             continue;
         }
         publish(S.key, job, u, tx, ty);
+    }
+    if ((dbg & 128) && lane == 0) {
+        const size_t gw = (size_t)blockIdx.x * 4 + wave;
+        const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave slot, SIMD, CU, SH, SE
+        const unsigned xccid = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
+        timeline[4 * gw] = tl_start;
+        timeline[4 * gw + 1] = wall_clock64();
+        timeline[4 * gw + 2] = tl_heavy;
+        timeline[4 * gw + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
+                               ((long long)(hwid & 0xffff) << 32) | ((long long)(xccid & 0xf) << 48);
     }
 #ifdef VB_PHASE_TIMING
     if (lane == 0)
@@ -960,7 +980,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 // 4096 waves' 91 MB of scratch evicted each other from the 4 MB L2s.
 __global__ void __launch_bounds__(256)
 vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const int4* __restrict__ tri4,
-                  const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const int2* __restrict__ dlist,
+                  const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const int* __restrict__ jdesc,
                   int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems,
                   int* __restrict__ jspill, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
                   int* __restrict__ meta, int dbg) {
@@ -970,14 +990,16 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
 #define KT(i) (S.ids[i])
     const int W = g.W, H = g.H, L = g.L;
     (void)B;
+    // XCD-aware like the job kernel (workgroup w runs on XCD w % 8; the slots of an eighth of the job list were written
+    // through that XCD's L2), one job per wave and turn
     const int total = min(meta[5], jcap), per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
-    const int n = *vb_line(meta, 8 + xcd);
-    const int2* const mine = dlist + (size_t)xcd * per_xcd;
+    const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
     const int step = (int)(gridDim.x >> 3) * 4;
-    for (int e = (int)(blockIdx.x >> 3) * 4 + wave; e < n; e += step) {
-        const int2 de = mine[e];
-        const size_t slot = (size_t)de.x;
-        const int u = de.y & 511, tx = (de.y >> 9) & 1023, ty = (de.y >> 19) & 4095;
+    for (int job = jbeg + (int)(blockIdx.x >> 3) * 4 + wave; job < jend; job += step) {
+        const int de = jdesc[job];
+        if (de < 0) continue;  // nothing drawn: the job kernel has already marked the slot
+        const size_t slot = (size_t)job;
+        const int u = de & 511, tx = (de >> 9) & 1023, ty = (de >> 19) & 4095;
         const int b = u / L;
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
         VB_WAVE_SYNC();  // the previous job's reads of S are complete
@@ -1157,15 +1179,13 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
                 }
             }
         }
-            // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
+        // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
         const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
         if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
         if (lane == 0) {
             jn[slot] = nz ? nitems : -1;
             if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
         }
-        VB_WAVE_SYNC();
-        VB_PHASE(6);  // publish
     }
 #undef KT
 }
@@ -1444,7 +1464,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     if ((rc = ctx->vb_spill.reserve((size_t)VB_SPILL_ITEMS * sizeof(VbItem)))) return rc;
     if ((rc = ctx->vb_units.reserve((size_t)VB_LBOX_STRIDE * B * L * sizeof(int)))) return rc;
     {  // job slots, compact (numbered like the jobs): value tile 1 KB | items 1 KB | count | spill base | region ids 1.36 KB;
-       // then the drawn-job lists and the links' first jobs
+       // descriptor; then the links' first jobs
         BinGeom g = make_geom(H, W, L);
         // a job = a (link, tile) pair whose boxes touch: `slack` tiles-worth of links per view (default 4 = every pixel
         // under four link boxes), never more than all of them
@@ -1454,8 +1474,8 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         ctx->vb_jcap = (int)want;
         const size_t nslot = (size_t)ctx->vb_jcap;
         if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + 2 * sizeof(int) +
-                                                VB_RN * sizeof(unsigned) + sizeof(int2)) +
-                                       8 * sizeof(int2) + (size_t)B * L * sizeof(int)))) return rc;
+                                                VB_RN * sizeof(unsigned) + sizeof(int)) +
+                                       (size_t)B * L * sizeof(int)))) return rc;
     }
     {  // heavy-job hint: generation + two counts | two lists | stamp table
         BinGeom g = make_geom(H, W, L);
@@ -1491,8 +1511,60 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
         fprintf(stderr, "[ehr vbuf] heavy jobs: generation %d, lists %d / %d\n", hg[0], hg[1], hg[2]);
         int cur[8];
         for (int k = 0; k < 8; k++)
-            EHR_HIP(hipMemcpy(&cur[k], vb_line((int*)((char*)ctx->vb_acc.ptr + off), 8 + k), sizeof(int), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ehr vbuf] drawn jobs per XCD %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
+            EHR_HIP(hipMemcpy(&cur[k], vb_line((int*)((char*)ctx->vb_acc.ptr + off), k), sizeof(int), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ehr vbuf] job cursors %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
+        static const int dbg = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;
+        if (dbg & 128) {
+            // Timeline of the job kernel's waves (100 MHz clock), written into the (otherwise idle) spill pool: when
+            // they started, left the heavy phase and ended; what their single-wave jobs amounted to; where they ran.
+            const int nw = 4 * (((ctx->num_cus * 4) + 7) & ~7);
+            std::vector<long long> tl((size_t)4 * nw);
+            EHR_HIP(hipMemcpy(tl.data(), ctx->vb_spill.ptr, tl.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            long long t0 = tl[0], t1 = tl[1];
+            for (int i = 0; i < nw; i++) {
+                t0 = std::min(t0, tl[4 * i]);
+                t1 = std::max(t1, tl[4 * i + 1]);
+            }
+            int hs[16] = {0}, he[16] = {0}, hh[16] = {0};
+            double busy = 0;
+            std::vector<std::pair<long long, int>> order;
+            std::vector<long long> per(8 * 8 * 2 * 16 * 4, 0);  // survivors per SIMD
+            for (int i = 0; i < nw; i++) {
+                hs[std::min<long long>((tl[4 * i] - t0) / 500, 15)]++;
+                he[std::min<long long>((tl[4 * i + 1] - t0) / 500, 15)]++;
+                hh[std::min<long long>((tl[4 * i + 2] - t0) / 500, 15)]++;
+                busy += (double)(tl[4 * i + 1] - tl[4 * i]);
+                order.push_back(std::make_pair(-tl[4 * i + 1], i));
+                const long long x = tl[4 * i + 3];
+                const unsigned hw = (unsigned)(x >> 32) & 0xffff;
+                per[((((size_t)((x >> 48) & 7) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 15)) * 4 + ((hw >> 4) & 3)] += (x >> 20) & 0xfff;
+            }
+            std::sort(order.begin(), order.end());
+            fprintf(stderr, "[ehr timeline] job kernel: %d waves, span %.1f us, mean wave life %.1f us\n", nw, (t1 - t0) * 0.01, busy / nw * 0.01);
+            fprintf(stderr, "[ehr timeline] starts per 5 us:");
+            for (int i = 0; i < 16; i++) fprintf(stderr, " %d", hs[i]);
+            fprintf(stderr, "\n[ehr timeline] heavy phase left per 5 us:");
+            for (int i = 0; i < 16; i++) fprintf(stderr, " %d", hh[i]);
+            fprintf(stderr, "\n[ehr timeline] ends per 5 us:");
+            for (int i = 0; i < 16; i++) fprintf(stderr, " %d", he[i]);
+            fprintf(stderr, "\n[ehr timeline] last waves: wave (workgroup): start, heavy phase left, end [us]; single-wave jobs, max / sum survivors; place\n");
+            for (int k = 0; k < 12 && k < nw; k++) {
+                const int i = order[k].second;
+                const long long x = tl[4 * i + 3];
+                const unsigned hw = (unsigned)(x >> 32) & 0xffff;
+                fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; xcc %lld se %u cu %u simd %u slot %u\n", i, i / 4,
+                        (tl[4 * i] - t0) * 0.01, (tl[4 * i + 2] - t0) * 0.01, (tl[4 * i + 1] - t0) * 0.01, x & 0xff, (x >> 8) & 0xfff,
+                        (x >> 20) & 0xfff, (x >> 48) & 0xf, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15);
+            }
+            long long mx = 0, sum = 0;
+            int used = 0;
+            for (size_t k = 0; k < per.size(); k++) {
+                mx = std::max(mx, per[k]);
+                sum += per[k];
+                used += per[k] > 0;
+            }
+            fprintf(stderr, "[ehr timeline] single-wave survivors per SIMD: %d SIMDs with work, mean %.0f, max %lld\n", used, used ? (double)sum / used : 0.0, mx);
+        }
 #ifdef VB_PHASE_TIMING
         unsigned long long ph[9];
         EHR_HIP(hipMemcpy(ph, (char*)ctx->vb_acc.ptr + off + 8 * sizeof(int), sizeof(ph), hipMemcpyDeviceToHost));
@@ -1579,17 +1651,18 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     int* jn = (int*)(jitems + nslot * VB_JOB_ITEMS);
     int* jspill = jn + nslot;
     unsigned* jid = (unsigned*)(jspill + nslot);
-    int2* dlist = (int2*)(jid + nslot * VB_RN);
-    int* jbase = (int*)(dlist + nslot + 8);
+    int* jdesc = (int*)(jid + nslot * VB_RN);
+    int* jbase = jdesc + nslot;
     const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
-    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jn, jid, dlist, jbase, ctx->vb_jcap, meta, dbg, hv);
+    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jn, jid, jdesc, jbase, ctx->vb_jcap, meta, dbg, hv,
+                                                (long long*)ctx->vb_spill.ptr);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
     // stage 1b: drawn jobs -> per-link values and blended pairs
     static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 4;  // tuning knob
     const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
     vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
-                                                   jid, dlist, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
+                                                   jid, jdesc, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
                                                    VB_SPILL_ITEMS, meta, dbg);
     EHR_LAUNCH_CHECK();
     if (ev) {
