@@ -775,14 +775,19 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
                             tb[k] = rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
                         }
                     }
+                    u64 smk[4];
 #pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        smk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
+                                          (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
+                    // not unrolled: one copy of the rasterizer round per call site (the kernel was 69 KB of code, more
+                    // than the instruction cache two CUs share)
+#pragma nounroll
                     for (int k = 0; k < 4; k++) {
-                        if (cc[k] < 0) continue;  // wave-uniform
-                        const bool sv = (tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
-                                        (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16);
-                        const u64 sm = __ballot(sv);
-                        if (!sm) continue;
-                        if (sv) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(cc[k] * 64 + lane);
+                        const u64 sm = (k == 0) ? smk[0] : (k == 1) ? smk[1] : (k == 2) ? smk[2] : smk[3];
+                        const int ck = (k == 0) ? cc[0] : (k == 1) ? cc[1] : (k == 2) ? cc[2] : cc[3];
+                        if (!sm) continue;  // wave-uniform (an unused batch entry holds the empty box)
+                        if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
                         qn += __popcll(sm);
                         drawn = true;
                         nsurv += __popcll(sm);
