@@ -76,6 +76,7 @@ struct ehr_ctx {
     ehr::Scratch vb_idx;     // int4 [T] padded triangle indices | int4 [T] padded edge topology (static)
     const void* vb_plan_tris = nullptr;  // the scene the static index was built for
     const void* vb_plan_opp = nullptr;
+    const void* vb_plan_verts = nullptr;
     int vb_nc = 0;           // number of clusters
     int vb_jcap = 0;         // job slots
     ehr::Scratch vb_boxes;   // uint2 pixel boxes of the current step: tbox [B][NC][64] | cbox [B][NC]

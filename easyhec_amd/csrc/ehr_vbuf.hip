@@ -131,6 +131,8 @@ struct VbClusters {          // static acceleration index built by ehr_fused_pla
     const int32_t* clink;    // [NC] link of every cluster
     const int32_t* coff;     // [L + 1] first cluster of every link
     const float* laabb;      // [L][6] object-space bounding box of every link (min xyz, max xyz)
+    const float4* cvert;     // [3][NC * 64] object-space corners of every cluster slot, packed (x0 y0 z0 x1 | y1 z1 x2 y2 |
+                             // z2 valid - -): one coalesced round trip instead of the chain ctri -> tris -> verts
     int NC;
 };
 
@@ -229,21 +231,14 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             have = true;
         }
     } else if (c < cl.NC) {
-        t = cl.ctri[(size_t)c * 64 + lane];
+        const size_t cs = (size_t)c * 64 + lane, cn = (size_t)cl.NC * 64;
+        t = cl.ctri[cs];
         l = cl.clink[c];
-        if (t >= 0) {
-            const int v0 = tris[3 * t], v1 = tris[3 * t + 1], v2 = tris[3 * t + 2];
-            if ((unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V) {
-                const int vi[3] = {v0, v1, v2};
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    vx[k] = verts[3 * vi[k]];
-                    vy[k] = verts[3 * vi[k] + 1];
-                    vz[k] = verts[3 * vi[k] + 2];
-                }
-                have = true;
-            }
-        }
+        const float4 q0 = cl.cvert[cs], q1 = cl.cvert[cn + cs], q2 = cl.cvert[2 * cn + cs];
+        vx[0] = q0.x; vy[0] = q0.y; vz[0] = q0.z;
+        vx[1] = q0.w; vy[1] = q1.x; vz[1] = q1.y;
+        vx[2] = q1.z; vy[2] = q1.w; vz[2] = q2.x;
+        have = t >= 0 && q2.y != 0.f;  // padding slots and triangles with a vertex index out of range draw nothing
     }
     if (HEAD && tid < 6) {
         Dual<1> T6[16];
@@ -1443,7 +1438,20 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
     ctx->vb_nc = NC;
     int rc;
     const size_t n_ctri = (size_t)std::max(NC, 1) * 64;
-    if ((rc = ctx->vb_clus.reserve((n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) * sizeof(int32_t)))) return rc;
+    std::vector<float> cvert(12 * n_ctri, 0.f);  // three float4 planes
+    for (size_t i = 0; i < ctri.size(); i++) {
+        const int tt = ctri[i];
+        if (tt < 0) continue;
+        const int v0 = ht[3 * (size_t)tt], v1 = ht[3 * (size_t)tt + 1], v2 = ht[3 * (size_t)tt + 2];
+        if ((unsigned)v0 >= (unsigned)V || (unsigned)v1 >= (unsigned)V || (unsigned)v2 >= (unsigned)V) continue;
+        const float c9[9] = {hv[3 * (size_t)v0], hv[3 * (size_t)v0 + 1], hv[3 * (size_t)v0 + 2], hv[3 * (size_t)v1], hv[3 * (size_t)v1 + 1],
+                             hv[3 * (size_t)v1 + 2], hv[3 * (size_t)v2], hv[3 * (size_t)v2 + 1], hv[3 * (size_t)v2 + 2]};
+        for (int k = 0; k < 4; k++) cvert[4 * i + k] = c9[k];
+        for (int k = 0; k < 4; k++) cvert[4 * (n_ctri + i) + k] = c9[4 + k];
+        cvert[4 * (2 * n_ctri + i)] = c9[8];
+        cvert[4 * (2 * n_ctri + i) + 1] = 1.f;
+    }
+    if ((rc = ctx->vb_clus.reserve((n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) * sizeof(int32_t) + 16 + cvert.size() * sizeof(float)))) return rc;
     int32_t* d = (int32_t*)ctx->vb_clus.ptr;
     if (NC > 0) {
         EHR_HIP(hipMemcpy(d, ctri.data(), (size_t)NC * 64 * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1451,6 +1459,10 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
     }
     EHR_HIP(hipMemcpy(d + n_ctri + std::max(NC, 1), coff.data(), ((size_t)L + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
     EHR_HIP(hipMemcpy(d + n_ctri + std::max(NC, 1) + L + 1, aabb.data(), aabb.size() * sizeof(float), hipMemcpyHostToDevice));
+    {
+        const uintptr_t at = ((uintptr_t)(d + n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) + 15) & ~(uintptr_t)15;
+        EHR_HIP(hipMemcpy((void*)at, cvert.data(), cvert.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     return EHR_OK;
 }
 
@@ -1496,6 +1508,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     }
     ctx->vb_plan_tris = tris;
     ctx->vb_plan_opp = opp;
+    ctx->vb_plan_verts = verts;
     EHR_HIP(hipMemset(ctx->vb_acc.ptr, 0, ctx->vb_acc.cap));
     std::vector<int> boxes((size_t)VB_LBOX_STRIDE * B * L);  // link boxes start "empty"; the finish kernel re-arms them
     for (size_t i = 0; i < boxes.size(); i++) boxes[i] = (i & 2) ? INT_MIN : INT_MAX;
@@ -1590,7 +1603,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                     int T, int H, int W, float* mask, float* loss, float* grad_mvp, const StepHead* head,
                     const StepTail* tail, hipStream_t stream) {
     (void)tri_link;
-    if (tris != ctx->vb_plan_tris || opp != ctx->vb_plan_opp)
+    if (tris != ctx->vb_plan_tris || opp != ctx->vb_plan_opp || verts != ctx->vb_plan_verts)
         return fail(EHR_ERR_INVALID, "fused op: the scene arrays differ from the planned ones; call ehr_fused_plan again");
     BinGeom g = make_geom(H, W, L);
     const int ntiles = B * g.nt;
@@ -1606,6 +1619,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     cl.clink = cl.ctri + (size_t)NC1 * 64;
     cl.coff = cl.clink + NC1;
     cl.laabb = (const float*)(cl.coff + L + 1);
+    cl.cvert = (const float4*)(((uintptr_t)(cl.laabb + 6 * (size_t)L) + 15) & ~(uintptr_t)15);
     cl.NC = NC;
     VbHeavy hv;
     hv.gen = (int*)ctx->vb_heavy.ptr;
