@@ -311,8 +311,19 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         p2 = transform_vertex(M[l], vx[2], vy[2], vz[2]);
         const bool simple = (p0.w > 0.f) && (p1.w > 0.f) && (p2.w > 0.f) && (p0.z + p0.w >= 0.f) &&
                             (p1.z + p1.w >= 0.f) && (p2.z + p2.w >= 0.f);
-        if (!simple) {  // near-plane clipping decides where it lands: keep it a candidate everywhere
-            x0 = 0; y0 = 0; x1 = W - 1; y1 = H - 1;
+        if (!simple) {  // crosses the near plane: the pixel box of its clipped pieces (the whole-wave path draws it)
+            const float4 pp[3] = {p0, p1, p2};
+            const ClipPoly cp = clip_near_poly(pp);
+            for (int sidx = 0; sidx + 2 < cp.n; sidx++) {
+                const Coverage cv = (sidx == 0) ? setup_coverage(cp.q0, cp.q1, cp.q2, W, H) : setup_coverage(cp.q0, cp.q2, cp.q3, W, H);
+                if (!cv.valid) continue;
+                const int ax = max(cv.ix0, 0), ay = max(cv.iy0, 0), bx1 = min(cv.ix1, W - 1), by1 = min(cv.iy1, H - 1);
+                if (ax > bx1 || ay > by1) continue;
+                x0 = min(x0, ax);
+                y0 = min(y0, ay);
+                x1 = max(x1, bx1);
+                y1 = max(y1, by1);
+            }
             r1.w = 1;
         } else {
             const Coverage cv = setup_coverage(p0, p1, p2, W, H);
