@@ -14,7 +14,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CHAIN = ["vb_vertex_kernel", "vb_job_kernel", "vb_composite_kernel", "fused_finish_kernel"]
+CHAIN = ["vb_vertex_kernel", "vb_job_kernel", "vb_resolve_kernel", "vb_composite_kernel", "fused_finish_kernel"]
 DOMINANT = "vb_job_kernel"
 
 
@@ -58,8 +58,10 @@ def main():
            "ratio_whole_op_to_algorithmic": round(sum(hbm.values()) / alg, 3),
            "note": "The step needs 8 B per pixel (one read of ref, one write of mask) + geometry = ~62 MB with the mask output, "
                    "~32 MB without it (the solver step does not write masks); SURVEY 8d's algorithmic figure budgets 16 B per "
-                   "pixel.  The job kernel's writes are mostly register-spill scratch (12-38 VGPRs per lane), its reads the "
-                   "per-triangle raster records (88 B per triangle and view, written by the vertex kernel)."}
+                   "pixel.  The job kernel reads the per-triangle raster records (88 B per triangle and view, written by the "
+                   "vertex kernel, fetched about twice because neighbouring tiles share triangles) and writes the region ids "
+                   "of the drawn jobs (1.36 KB each) plus ~10 MB of register-spill scratch; the vertex kernel reads the "
+                   "packed corner table once per view."}
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
