@@ -664,12 +664,11 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 
 // Stage 2: one WAVE per job = (view, link, 32x8 tile the link's screen box touches); persistent waves over the job list,
 // which is never materialised (every workgroup derives it from the link boxes with a prefix sum over B * L counts).
-// A job culls the link's cluster boxes, then the triangle boxes of the surviving clusters, rasterizes the survivors
-// into the wave's LDS depth/id buffer (tile + 1-pixel halo), finds the covered/uncovered pixel pairs with wave-uniform
-// bit arithmetic on the coverage bitmap, runs the silhouette analysis on the compacted hits and gathers the link's
-// antialiased value per pixel in the oracle's order.  It leaves, in the job's slot (view, link, tile): the 256 values
-// (jval), the blended pairs the backward pass needs (jitems) and their number (jn; -1 = the link contributes nothing
-// here).  No workgroup barriers after the prologue; thousands of independent waves hide each other's latency.
+// A job culls the link's cluster boxes, then the triangle boxes of the surviving clusters, and rasterizes the survivors
+// into the wave's LDS depth/id buffer (tile + 1-pixel halo).  It leaves, in the job's slot (view, link, tile), the
+// triangle id of every region pixel (jid) and a descriptor (jdesc; -1 and jn = -1 when nothing was drawn); the resolve
+// kernel takes it from there.  No workgroup barriers after the prologue except in the heavy-job phase; thousands of
+// independent waves hide each other's latency.
 #ifndef VB_JOB_WAVES
 #define VB_JOB_WAVES 4
 #endif
@@ -829,7 +828,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         VB_PHASE(6);  // publish
     };
     // ---- heavy jobs first, one workgroup each: the four waves share the job's depth/id buffer (wave 0's) and split the
-    //      candidate clusters; wave 0 resolves.  A job alone costs up to ~80 us on one wave (a thousand candidate
+    //      candidate clusters; wave 0 publishes.  A job alone costs up to ~80 us on one wave (a thousand candidate
     //      triangles in one tile), which used to be the duration of this kernel at small batch sizes.
     __shared__ int s_heavy[2];  // drawn flag, survivors
     const int gen = hv.gen[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
