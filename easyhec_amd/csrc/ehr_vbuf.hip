@@ -215,31 +215,45 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     }
     const int tid = threadIdx.x, L = g.L, H = g.H, W = g.W;
     const bool first = bx == 0 && b == 0;
-    const bool vpath = bx < nvb;
-    // geometry loads first: they do not depend on the pose, so their latency hides under the pose arithmetic below
-    const int v = bx * 256 + tid;
-    const int c = (bx - nvb) * 4 + (tid >> 6), lane = tid & 63;
+    // A view's work items: [0, nvb) blocks of 256 vertices (-> posc), then groups of four clusters (one wave per cluster,
+    // one lane per triangle).  The workgroup takes items bx, bx + gx, ...: the pose head above every item (exponential,
+    // matrices: ~3 us of dependent arithmetic) is paid once per workgroup, not once per 256 vertices -- with one item per
+    // workgroup the Franka scene (375 k vertices x 16 views) needed 32 k workgroups and 125 us.
+    const int nitems = nvb + (cl.NC + 3) / 4;
+    const int lane = tid & 63;
+    int item = bx;
     int l = -1, t = -1;
     float vx[3] = {0.f, 0.f, 0.f}, vy[3] = {0.f, 0.f, 0.f}, vz[3] = {0.f, 0.f, 0.f};
     bool have = false;
-    if (vpath) {
-        if (v < V) {
-            l = vert_link[v];
-            vx[0] = verts[3 * v];
-            vy[0] = verts[3 * v + 1];
-            vz[0] = verts[3 * v + 2];
-            have = true;
+    // geometry loads first: they do not depend on the pose, so their latency hides under the pose arithmetic below
+    auto load_geometry = [&](int it) {
+        l = -1;
+        t = -1;
+        have = false;
+        if (it < nvb) {
+            const int v = it * 256 + tid;
+            if (v < V) {
+                l = vert_link[v];
+                vx[0] = verts[3 * v];
+                vy[0] = verts[3 * v + 1];
+                vz[0] = verts[3 * v + 2];
+                have = true;
+            }
+        } else {
+            const int c = (it - nvb) * 4 + (tid >> 6);
+            if (c < cl.NC) {
+                const size_t cs = (size_t)c * 64 + lane, cn = (size_t)cl.NC * 64;
+                t = cl.ctri[cs];
+                l = cl.clink[c];
+                const float4 q0 = cl.cvert[cs], q1 = cl.cvert[cn + cs], q2 = cl.cvert[2 * cn + cs];
+                vx[0] = q0.x; vy[0] = q0.y; vz[0] = q0.z;
+                vx[1] = q0.w; vy[1] = q1.x; vz[1] = q1.y;
+                vx[2] = q1.z; vy[2] = q1.w; vz[2] = q2.x;
+                have = t >= 0 && q2.y != 0.f;  // padding slots and triangles with a vertex index out of range draw nothing
+            }
         }
-    } else if (c < cl.NC) {
-        const size_t cs = (size_t)c * 64 + lane, cn = (size_t)cl.NC * 64;
-        t = cl.ctri[cs];
-        l = cl.clink[c];
-        const float4 q0 = cl.cvert[cs], q1 = cl.cvert[cn + cs], q2 = cl.cvert[2 * cn + cs];
-        vx[0] = q0.x; vy[0] = q0.y; vz[0] = q0.z;
-        vx[1] = q0.w; vy[1] = q1.x; vz[1] = q1.y;
-        vx[2] = q1.z; vy[2] = q1.w; vz[2] = q2.x;
-        have = t >= 0 && q2.y != 0.f;  // padding slots and triangles with a vertex index out of range draw nothing
-    }
+    };
+    if (item < nitems) load_geometry(item);
     if (HEAD && tid < 6) {
         Dual<1> T6[16];
         se3_exp_dual<1>(head.dof, 1e-4f, T6, tid);
@@ -292,15 +306,18 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         for (int i = tid; i < L * 16; i += 256) M[i >> 4][i & 15] = mvp[(size_t)b * L * 16 + i];
     }
     __syncthreads();
-    const bool lv = (unsigned)l < (unsigned)L;
-    if (vpath) {
-        if (v >= V) return;
-        float4 o = make_float4(0.f, 0.f, 0.f, -1.f);  // invalid link -> behind the camera, never drawn
-        if (lv) o = transform_vertex(M[l], vx[0], vy[0], vz[0]);
-        posc[(size_t)b * V + v] = o;
-        return;
-    }
     __shared__ int wbox[4][5];  // per wave: link, box of its cluster
+    for (; item < nitems;) {
+    const bool lv = (unsigned)l < (unsigned)L;
+    if (item < nvb) {
+        const int v = item * 256 + tid;
+        if (v < V) {
+            float4 o = make_float4(0.f, 0.f, 0.f, -1.f);  // invalid link -> behind the camera, never drawn
+            if (lv) o = transform_vertex(M[l], vx[0], vy[0], vz[0]);
+            posc[(size_t)b * V + v] = o;
+        }
+    } else {
+    const int c = (item - nvb) * 4 + (tid >> 6);
     const bool cvalid = c < cl.NC;
     int x0 = 0xffff, y0 = 0xffff, x1 = 0, y1 = 0;  // empty (overlaps nothing)
     int4 r0 = make_int4(-1, -1, -1, 0), r1 = make_int4(0, 0, t, 0);
@@ -386,12 +403,17 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
                     mc = max(mc, wbox[k][3]);
                     md = max(md, wbox[k][4]);
                 }
-            int* bx = lbox + VB_LBOX_STRIDE * ((size_t)b * L + ll);
-            atomicMin(bx + 0, ma);
-            atomicMin(bx + 1, mb);
-            atomicMax(bx + 2, mc);
-            atomicMax(bx + 3, md);
+            int* const lb = lbox + VB_LBOX_STRIDE * ((size_t)b * L + ll);
+            atomicMin(lb + 0, ma);
+            atomicMin(lb + 1, mb);
+            atomicMax(lb + 2, mc);
+            atomicMax(lb + 3, md);
         }
+    }
+    __syncthreads();  // wbox is rewritten by the next cluster group
+    }
+    item += gx;
+    if (item < nitems) load_geometry(item);
     }
 }
 
@@ -1657,7 +1679,11 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     const int vec_ok = ((W & 3) == 0) && (((uintptr_t)ref & 15) == 0) && (!mask || ((uintptr_t)mask & 15) == 0);
     // stage 0: [pose forward] + vertices + screen boxes
     const int nvb = (std::max(V, 1) + 255) / 256;
-    const int gx = nvb + (NC + 3) / 4;
+    // workgroups per view: as many as stay resident together (5 per CU), every one with the same number of work items
+    const int nitems = nvb + (NC + 3) / 4;
+    const int per_view_cap = std::max(8, (ctx->num_cus * 5) / std::max(B, 1));
+    const int items_per_wg = (nitems + per_view_cap - 1) / per_view_cap;
+    const int gx = std::max(1, (nitems + items_per_wg - 1) / std::max(items_per_wg, 1));
     static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
     const int xcd_views = (xcd_align && (B % 8) == 0) ? B / 8 : 0;
     const dim3 vgrid(gx * B);
