@@ -64,8 +64,8 @@ class FusedPoseStep:
         m, sc = self.model, self.scene
         dof = m.dof.data
         hist = m.history_ops
-        # one C call = 7 launches: [pose fwd + counter clear + vertex transform] -> count -> alloc -> fill ->
-        # tiles (lean, slow) -> [reduce + pose bwd (+ Adam)]
+        # one C call = 5 launches: [pose fwd + vertices + raster records] -> jobs -> resolve -> composite ->
+        # [accumulators + pose bwd (+ Adam)]   (7 with EHR_FUSED_PATH=tile, round 1's queue-based chain)
         _lib.check(lib.ehr_solver_step(
             self.glctx.handle, _lib.ptr(sc.verts), _lib.ptr(sc.tris), _lib.ptr(sc.tri_link), _lib.ptr(sc.vert_link),
             _lib.ptr(sc.opp), _lib.ptr(self.K), _lib.ptr(self.link_poses), _lib.ptr(self.ref), self.B, self.L,
@@ -95,8 +95,8 @@ class FusedPoseStep:
         return self.loss
 
     def capture(self):
-        """Record the step's launch chain (7 kernels on the main stream, 2 on the side stream, their fork/join events)
-        into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
+        """Record the step's launch chain (5 kernels on one stream; the round-1 tile chain adds a side stream with its
+        fork/join events) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
         with one host call.  Iteration state lives on the device, so replays are ordinary optimisation steps.  The
         chain is GPU-bound, so this saves host time, not step time.  Single-process only: the data-parallel step has a
         collective between the chain and Adam."""

@@ -133,7 +133,8 @@ def mvp_matrices(K, H, W, Tc_c2b, link_poses, n=0.001, f=10.0):
 import os as _os
 
 # kernels bracketed by ehr_fused_timing's hipEvents, in ms[] order (include/ehr.h).  Visibility-buffer chain (default):
-# vertex + records, jobs, composite, finish (slots 2, 3, 5 unused); round-1 tile chain (EHR_FUSED_PATH=tile): its seven.
+# vertex + records, jobs, resolve, composite, finish (slots 3, 5 unused); round-1 tile chain (EHR_FUSED_PATH=tile): its
+# seven.
 if (_os.environ.get("EHR_FUSED_PATH") or "v")[0] == "t":
     STAGES = ("bin_count", "bin_alloc", "bin_fill", "tile_empty", "tile", "tile_slow", "reduce")
     DOMINANT_STAGE, DOMINANT_KERNEL = "tile", "fused_tile_kernel<false>"

@@ -114,9 +114,10 @@ int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVE
  * hipEvents around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED
  * milliseconds per stage since the last read and the number of calls covered, then resets.  Stages of the default
  * (visibility-buffer) chain: ms[0] vertex kernel (pose forward, clip-space vertices, per-triangle raster records, cluster
- * and link boxes), ms[1] job kernel (one wave per (view, link, tile): culling, LDS rasterizer, silhouette analysis -- the
- * dominant kernel), ms[4] composite kernel (link sum, clamp, loss, mask, backward), ms[6] finish kernel (accumulators ->
- * loss / grad_mvp [-> pose backward -> Adam]); ms[2], ms[3], ms[5] are unused (~0).  With EHR_FUSED_PATH=tile the seven
+ * and link boxes), ms[1] job kernel (one wave per (view, link, tile): box culling, LDS rasterizer -- the dominant
+ * kernel), ms[2] resolve kernel (one wave per drawn job: silhouette analysis, antialiased values, blended pairs), ms[4]
+ * composite kernel (link sum, clamp, loss, mask, backward), ms[6] finish kernel (accumulators -> loss / grad_mvp [-> pose
+ * backward -> Adam]); ms[3], ms[5] are unused (~0).  With EHR_FUSED_PATH=tile the seven
  * slots are the round-1 chain's: count, alloc, fill, empty tiles, tile kernel, its slow instantiation, reduce.
  * Not for use under graph capture. */
 #define EHR_FUSED_STAGES 7
@@ -142,9 +143,9 @@ int ehr_pose_backward(const float* grad_mvp, const float* loss, const float* K, 
 int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* red, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
 
-/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 7 launches: ehr_pose_forward is merged into
- * the vertex-transform kernel (which also clears the queue counters) and ehr_pose_backward + ehr_pose_adam into the
- * last-arriving block of the reduction.  Same arithmetic and outputs as calling the pieces one by one:
+/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 5 launches (7 with EHR_FUSED_PATH=tile):
+ * ehr_pose_forward is merged into the vertex kernel (which also does the per-step housekeeping) and ehr_pose_backward +
+ * ehr_pose_adam into the one-workgroup finish kernel.  Same arithmetic and outputs as calling the pieces one by one:
  * mvp [B,L,16], tc_jac [7,16], loss_b [B], grad_mvp [B,L,16], red [8], loss_out [1], grad_out [6] are all written.
  * defer_adam != 0 stops after `red` so that the caller can all-reduce it across ranks and then call ehr_pose_adam.
  * Requires ehr_fused_plan for (B,L,V,T,H,W); never synchronises or allocates. */
