@@ -1028,20 +1028,27 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
     const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
     const int step = (int)(gridDim.x >> 3) * 4;
     for (int job = jbeg + (int)(blockIdx.x >> 3) * 4 + wave; job < jend; job += step) {
-        const int de = jdesc[job];
-        if (de < 0) continue;  // nothing drawn: the job kernel has already marked the slot
         const size_t slot = (size_t)job;
-        const int u = de & 511, tx = (de >> 9) & 1023, ty = (de >> 19) & 4095;
-        const int b = u / L;
-        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
-        VB_WAVE_SYNC();  // the previous job's reads of S are complete
+        // the ids are requested together with the descriptor (one round trip; an undrawn slot holds stale ids, unused)
+        unsigned idw[VB_WORDS];
         {
             const unsigned* const src = jid + slot * VB_RN;
 #pragma unroll
             for (int k = 0; k < VB_WORDS; k++) {
                 const unsigned i = 64u * k + lane;
-                if (i < (unsigned)VB_RN) S.ids[i] = src[i];
+                idw[k] = (i < (unsigned)VB_RN) ? src[i] : 0xffffffffu;
             }
+        }
+        const int de = jdesc[job];
+        if (de < 0) continue;  // nothing drawn: the job kernel has already marked the slot
+        const int u = de & 511, tx = (de >> 9) & 1023, ty = (de >> 19) & 4095;
+        const int b = u / L;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        VB_WAVE_SYNC();  // the previous job's reads of S are complete
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            if (i < (unsigned)VB_RN) S.ids[i] = idw[k];
         }
         const int r = lane >> 3, c4 = (lane & 7) * 4;
         const int myq = (r + 1) * VB_RW + (c4 + 1);
