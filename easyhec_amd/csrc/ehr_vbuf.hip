@@ -699,7 +699,9 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
               unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, int jcap,
               int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline) {
     __shared__ VbWaveLds lds_all[4];
-    const long long tl_start = (dbg & 128) ? wall_clock64() : 0;  // EHR_VB_DEBUG & 128: a record per wave, see vbuf_meta_read
+#ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
+    const long long tl_start = wall_clock64();
+#endif
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
     __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
     __shared__ int lcoff[33];                 // first cluster of every link
@@ -916,8 +918,10 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     const int hk = (nhw > xcd) ? (nhw - xcd + 7) >> 3 : 0;
     const int kx = blockIdx.x >> 3;                      // this workgroup's index inside its XCD
     const int nsw = ((gridDim.x >> 3) - hk) * 4;         // waves of this XCD that take a static first job
-    const long long tl_heavy = (dbg & 128) ? wall_clock64() : 0;
+#ifdef VB_TIMELINE
+    const long long tl_heavy = wall_clock64();
     int tl_jobs = 0, tl_maxsurv = 0, tl_sumsurv = 0;
+#endif
     bool first_job = kx >= hk;
     int sjob = jbeg + (kx - hk) * 4 + wave;
     for (;;) {
@@ -970,11 +974,11 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         VB_WAVE_SYNC();
         int nsurv = 0;
         const bool drawn = raster_share(S, S.key, b, l, rg, rx0, ry0, 0, 1, nsurv);
-        if (dbg & 128) {
-            tl_jobs++;
-            tl_maxsurv = max(tl_maxsurv, nsurv);
-            tl_sumsurv += nsurv;
-        }
+#ifdef VB_TIMELINE
+        tl_jobs++;
+        tl_maxsurv = max(tl_maxsurv, nsurv);
+        tl_sumsurv += nsurv;
+#endif
         if (nsurv >= VB_HEAVY_T && lane == 0) remember_heavy(dense_id);
         if (!drawn) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
@@ -985,7 +989,8 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         }
         publish(S.key, job, u, tx, ty);
     }
-    if ((dbg & 128) && lane == 0) {
+#ifdef VB_TIMELINE
+    if (lane == 0) {
         const size_t gw = (size_t)blockIdx.x * 4 + wave;
         const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave slot, SIMD, CU, SH, SE
         const unsigned xccid = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
@@ -995,6 +1000,9 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         timeline[4 * gw + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
                                ((long long)(hwid & 0xffff) << 32) | ((long long)(xccid & 0xf) << 48);
     }
+#else
+    (void)timeline;
+#endif
 #ifdef VB_PHASE_TIMING
     if (lane == 0)
         for (int i = 0; i < 8; i++)
@@ -1570,8 +1578,8 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
         for (int k = 0; k < 8; k++)
             EHR_HIP(hipMemcpy(&cur[k], vb_line((int*)((char*)ctx->vb_acc.ptr + off), k), sizeof(int), hipMemcpyDeviceToHost));
         fprintf(stderr, "[ehr vbuf] job cursors %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
-        static const int dbg = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;
-        if (dbg & 128) {
+#ifdef VB_TIMELINE
+        {
             // Timeline of the job kernel's waves (100 MHz clock), written into the (otherwise idle) spill pool: when
             // they started, left the heavy phase and ended; what their single-wave jobs amounted to; where they ran.
             const int nw = 4 * (((ctx->num_cus * 4) + 7) & ~7);
@@ -1622,6 +1630,7 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
             }
             fprintf(stderr, "[ehr timeline] single-wave survivors per SIMD: %d SIMDs with work, mean %.0f, max %lld\n", used, used ? (double)sum / used : 0.0, mx);
         }
+#endif
 #ifdef VB_PHASE_TIMING
         unsigned long long ph[9];
         EHR_HIP(hipMemcpy(ph, (char*)ctx->vb_acc.ptr + off + 8 * sizeof(int), sizeof(ph), hipMemcpyDeviceToHost));
