@@ -1516,6 +1516,10 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
 int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
                    const int32_t* tris, const int32_t* tri_link, const int32_t* opp) {
     if (H > 32767 || W > 32767) return fail(EHR_ERR_INVALID, "ehr_fused_plan: resolution above 32767 is unsupported");
+    if ((long long)B * L > VB_MAX_UNITS)  // the job kernel keeps 8 bytes per (view, link) in LDS
+        return fail(EHR_ERR_INVALID,
+                    "ehr_fused_plan: %d views x %d links exceeds the %d (view, link) units one context handles on the default "
+                    "chain; split the views over several contexts / calls (or set EHR_FUSED_PATH=tile)", B, L, VB_MAX_UNITS);
     if ((V > 0 && !verts) || (T > 0 && (!tris || !tri_link || !opp)))
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: the scene arrays (verts, tris, tri_link, opp) are required");
     int rc;

@@ -332,3 +332,20 @@ def test_fused_edge_cases(env, oracle, xarm7):
     mask, loss, grad = run(fused, ctx, scene, mvp, ref, dev)
     assert np.isfinite(loss).all() and np.isfinite(grad).all() and 0.01 < (mask > 0.5).mean() < 0.6
     assert abs(float(loss[0]) - float((mask.astype(np.float64) ** 2).sum())) <= 1e-6 * float(loss[0])
+
+
+@pytest.mark.gpu
+def test_plan_rejects_more_units_than_a_context_handles(env, xarm7):
+    """views x links above 512 on the default chain: an error that says so at plan time, not an out-of-bounds job table
+    (the round-1 tile chain has no such limit and keeps working)."""
+    fused, ctx, scene, dev = env
+    import os
+    from easyhec_amd import dr
+    ctx2 = dr.RasterizeCudaContext()
+    B, H, W = 65, 16, 32                                # 65 views x 8 links = 520 units
+    if (os.environ.get("EHR_FUSED_PATH") or "v")[0] == "t":
+        fused._ensure_plan(ctx2, scene, B, H, W)        # no limit on this chain
+        return
+    with pytest.raises(RuntimeError, match="exceeds the 512"):
+        fused._ensure_plan(ctx2, scene, B, H, W)
+    fused._ensure_plan(ctx2, scene, 64, H, W)           # 512 units exactly: fine
