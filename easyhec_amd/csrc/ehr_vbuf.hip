@@ -1515,7 +1515,8 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
 
 int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
                    const int32_t* tris, const int32_t* tri_link, const int32_t* opp) {
-    if (H > 32767 || W > 32767) return fail(EHR_ERR_INVALID, "ehr_fused_plan: resolution above 32767 is unsupported");
+    if (H > 32760 || W > 32736)  // tile counts are packed into 10 (columns) and 12 (rows) bits
+        return fail(EHR_ERR_INVALID, "ehr_fused_plan: resolution above 32736 x 32760 (W x H) is unsupported");
     if ((long long)B * L > VB_MAX_UNITS)  // the job kernel keeps 8 bytes per (view, link) in LDS
         return fail(EHR_ERR_INVALID,
                     "ehr_fused_plan: %d views x %d links exceeds the %d (view, link) units one context handles on the default "

@@ -97,7 +97,7 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  * spatially close triangles per link, padded index tables), so it takes the scene arrays -- the SAME device arrays that
  * are later passed to ehr_render_mask_loss / ehr_solver_step (they are checked by address; call it again when the
  * scene, the shape or the arrays change -- also when only the CONTENTS of verts / tris change: the index holds a copy
- * of every triangle's corners).  Limits of the default chain, checked here: B x L <= 512, L <= 32, H, W <= 32767.  The hot calls never synchronise or allocate, so they can be captured in a
+ * of every triangle's corners).  Limits of the default chain, checked here: B x L <= 512, L <= 32, W <= 32736, H <= 32760.  The hot calls never synchronise or allocate, so they can be captured in a
  * hipGraph; a new plan invalidates a captured graph.  One slot per (view, link, tile) is reserved, so nothing on this
  * path can overflow except the fixed-point accumulators (|sum| > 2^31) and a 16 MB spill pool for tiles with more than
  * 64 blended pairs per link: then loss[] is NaN (never a silently wrong image), the optimiser state is left untouched
