@@ -1241,7 +1241,7 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
 // values in link order, clamps, accumulates the frame loss, writes the mask, and back-propagates the tile's blended
 // pairs to 12 numbers per link which go to the view's fixed-point accumulators.  Tiles no link box touches just stream
 // (mask = 0, loss += ref^2).  vec_ok: W % 4 == 0 and 16-byte aligned images.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 8)
 vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const float* __restrict__ verts,
                     const int* __restrict__ lbox, const int* __restrict__ jn, const float* __restrict__ jval,
                     const VbItem* __restrict__ jitems, const int* __restrict__ jspill, const int* __restrict__ jbase,
