@@ -9,7 +9,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libehr_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -amdgpu-use-amdgpu-trackers: the target's own register-pressure trackers during scheduling; the job kernel sits at the
+# 128-VGPR limit and every spilled register shows in its duration (7 instead of 10 spilled VGPRs, +1 % frames/s)
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
 
 
 def sources():
