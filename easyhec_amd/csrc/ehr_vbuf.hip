@@ -44,7 +44,9 @@ constexpr int VB_RH = EHR_TILE_H + 2;
 constexpr int VB_RN = VB_RW * VB_RH;   // 340
 constexpr int VB_WORDS = (VB_RN + 63) / 64;  // 6 coverage words
 constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min y, max x, max y, padding to a 64-byte line
-constexpr int VB_HEAVY_T = 320;       // survivors from which a job counts as heavy (next step: a whole workgroup takes it)
+constexpr int VB_HEAVY_T = 384;       // survivors from which a job counts as heavy (next step: a whole workgroup takes it);
+                                      // measured at 8 views: 224 -> 58.7 k (too many: the phase switches itself off), 320 -> 67.7 k,
+                                      // 384 -> 68.6 k, 448 -> 68.4 k, 512 -> 67.1 k, 640 -> 62.4 k frames/s
 constexpr int VB_HEAVY_CAP = 1024;    // heavy jobs remembered per step
 constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
 constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
