@@ -1737,7 +1737,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
     // stage 1b: drawn jobs -> per-link values and blended pairs
-    static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 4;  // tuning knob
+    static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
     const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
     vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
                                                    jid, jdesc, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
