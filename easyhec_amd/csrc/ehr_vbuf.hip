@@ -1704,7 +1704,8 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     const int nvb = (std::max(V, 1) + 255) / 256;
     // workgroups per view: as many as stay resident together (5 per CU), every one with the same number of work items
     const int nitems = nvb + (NC + 3) / 4;
-    const int per_view_cap = std::max(8, (ctx->num_cus * 5) / std::max(B, 1));
+    static const int vertex_grid = getenv("EHR_VB_VERTEX_GRID") ? atoi(getenv("EHR_VB_VERTEX_GRID")) : 5;  // tuning knob
+    const int per_view_cap = std::max(8, (ctx->num_cus * std::max(1, vertex_grid)) / std::max(B, 1));
     const int items_per_wg = (nitems + per_view_cap - 1) / per_view_cap;
     const int gx = std::max(1, (nitems + items_per_wg - 1) / std::max(items_per_wg, 1));
     static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
