@@ -6,7 +6,7 @@
 // but without per-step triangle binning: no (tile, link) queues are built, counted, allocated or filled.  The meshes
 // project to micro-triangles (median bounding box 8 px, a quarter of them cover no pixel centre at all), for which
 // building and draining per-tile queues cost more than the coverage tests themselves.  Instead ehr_fused_plan groups
-// every link's triangles ONCE into clusters of 64 spatially close ones (Morton order of the centroids in object space,
+// every link's triangles ONCE into clusters of 64 spatially close ones (recursive median split of the centroids in object space,
 // valid for every pose), and a step is four launches:
 //
 //   vb_vertex_kernel    [pose forward] + clip-space vertices (posc) + one wave per cluster: transforms the cluster's
@@ -1407,16 +1407,32 @@ using namespace ehr;
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
-static inline unsigned vb_spread10(unsigned v) {  // 10 bits -> every third bit
-    v &= 1023u;
-    v = (v | (v << 16)) & 0x030000ffu;
-    v = (v | (v << 8)) & 0x0300f00fu;
-    v = (v | (v << 4)) & 0x030c30c3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+// Reorders idx[0..n) (indices into the centroid array) in place: median split along the longest axis, left part
+// rounded to a multiple of 64, recursively.  Against a Morton curve of the centroids (first version) the clusters'
+// screen boxes touch a third fewer tiles (xArm7 at 720p: 4.4 k instead of 6.5 k cluster-tile pairs per view), i.e. a third
+// fewer candidate clusters per job.
+static void vb_kd_order(const float* cen, int* idx, int n) {
+    if (n <= 64) return;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            const float c = cen[3 * (size_t)idx[i] + k];
+            lo[k] = std::min(lo[k], c);
+            hi[k] = std::max(hi[k], c);
+        }
+    int ax = 0;
+    if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1;
+    if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
+    const int half = std::min(std::max(((n / 2 + 63) / 64) * 64, 64), n - 1);
+    std::nth_element(idx, idx + half, idx + n, [&](int a, int b) {
+        const float ca = cen[3 * (size_t)a + ax], cb = cen[3 * (size_t)b + ax];
+        return ca < cb || (ca == cb && a < b);  // index as tie-break: the same scene always gives the same clusters
+    });
+    vb_kd_order(cen, idx, half);
+    vb_kd_order(cen, idx + half, n - half);
 }
 
-// Static acceleration index of a scene: per link, the triangles sorted along a Morton curve of their centroids (object
+// Static acceleration index of a scene: per link, the triangles ordered by a median-split tree over their centroids (object
 // space, so it holds for every pose) and cut into clusters of 64.  Triangle ids stay the caller's: depth ties and the
 // antialias topology are unaffected.
 static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* verts, const int32_t* tris,
@@ -1463,21 +1479,14 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
                 lo[k] = std::min(lo[k], c);
                 hi[k] = std::max(hi[k], c);
             }
-        std::vector<std::pair<unsigned, int>> order((size_t)n);
-        for (int i = 0; i < n; i++) {
-            unsigned code = 0;
-            for (int k = 0; k < 3; k++) {
-                const float ext = hi[k] - lo[k];
-                float f = ext > 0.f ? (cen[3 * (size_t)i + k] - lo[k]) / ext : 0.f;
-                f = std::min(std::max(f, 0.f), 1.f);
-                code |= vb_spread10((unsigned)(f * 1023.f)) << k;
-            }
-            order[i] = std::make_pair(code, t0 + i);
-        }
-        std::sort(order.begin(), order.end());
+        // order the link's triangles so that every run of 64 is spatially compact: recursive median split along the
+        // longest axis of the centroids, the left part a multiple of 64 (so that clusters never straddle a split)
+        std::vector<int> order((size_t)n);
+        for (int i = 0; i < n; i++) order[i] = i;
+        vb_kd_order(cen.data(), order.data(), n);
         for (int i = 0; i < n; i++) {
             if ((i & 63) == 0) clink.push_back(l);
-            ctri.push_back(order[i].second);
+            ctri.push_back(t0 + order[i]);
         }
         while (ctri.size() & 63) ctri.push_back(-1);
     }
