@@ -38,14 +38,15 @@ SIGNATURES = {
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                      c_void_p]),
     "ehr_fused_status": (c_int, [c_void_p]),
+    "ehr_fused_bind_ref": (c_int, [c_void_p, c_void_p, c_void_p]),
     "ehr_pose_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ehr_pose_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                   c_float, c_float, c_void_p, c_void_p]),
     "ehr_pose_adam": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                               c_float, c_void_p, c_void_p, c_void_p]),
-    "ehr_solver_step": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_float] * 2 + [c_void_p] * 5 + [c_int] + [c_float] * 5 +
-                        [c_void_p] * 8 + [c_int, c_void_p]),
+    "ehr_solver_step": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_float] * 2 + [c_void_p] * 5 + [c_int, c_void_p] +
+                        [c_float] * 5 + [c_void_p] * 8 + [c_int, c_void_p]),
     "ehr_mask_variance": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p, c_int, c_void_p]),
     "ehr_graph_begin": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "ehr_graph_end": (c_int, [c_void_p]),

@@ -44,10 +44,12 @@ struct StepTail;
 #define VB_LOSS_SLOTS 32          // partial frame-loss sums per view (spreads same-address atomics)
 #define VB_LOSS_STRIDE 16         // i64 between two of them: one 128-byte line each (atomics on one line serialise)
 #define VB_MAX_UNITS 512          // views x links one context plans for
+#define VB_MAX_VIEWS VB_MAX_UNITS  // (every view has at least one link)
 #define VB_SPILL_ITEMS (1 << 20)  // pool of blended-pair items for tiles that overflow their LDS list (16 MB)
 int vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
               const int32_t* tris, const int32_t* tri_link, const int32_t* opp);
 int vbuf_meta_read(ehr_ctx* ctx, int* meta4);
+int vbuf_bind_ref(ehr_ctx* ctx, const float* ref, hipStream_t stream);
 int vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link, const int32_t* vert_link,
                const int32_t* opp, float* mvp, const float* ref, int B, int L, int V, int T, int H, int W, float* mask,
                float* loss, float* grad_mvp, const StepHead* head, const StepTail* tail, hipStream_t stream);
@@ -66,11 +68,7 @@ struct ehr_ctx {
     // fused path plan
     int pB = 0, pL = 0, pV = 0, pT = 0, pH = 0, pW = 0;
     int num_cus = 256;
-    ehr::Scratch posc;       // float4 [B * V] clip-space vertices of the current step
-    ehr::Scratch tile_part;  // float [B * NT * (1 + 12 * L)] per-tile partial loss + MVP gradients
-    ehr::Scratch tile_list;  // int32 [2 * B * NT]: per-tile entry totals | work list of non-empty tiles
-    // visibility-buffer chain of the fused op (ehr_vbuf.hip); its own scratch, never shared with the drop-in ops
-    bool path_vbuf = true;   // EHR_FUSED_PATH=tile selects the round-1 LDS-tile chain (A/B measurements)
+    // launch chain of the fused op (ehr_vbuf.hip); its own scratch, never shared with the drop-in ops
     ehr::Scratch vb_clus;    // i32 cluster index: ctri [NC][64] | clink [NC] | coff [L + 1] (static, built by the plan)
     ehr::Scratch vb_heavy;   // heavy-job scheduling hint carried from step to step (generation, lists, stamps)
     ehr::Scratch vb_idx;     // int4 [T] padded triangle indices | int4 [T] padded edge topology (static)
@@ -85,12 +83,12 @@ struct ehr_ctx {
     ehr::Scratch vb_posc;    // float4 [B][V] clip-space vertices
     ehr::Scratch vb_jobs;    // per (view, link, tile) job slot: value tile | blended pairs | count | spill base
     ehr::Scratch vb_spill;   // blended pairs of jobs that exceed their slot
+    int vb_spill_cap = 0;    // ... in items
+    ehr::Scratch vb_refsum;  // cached sums of the bound reference mask: tsum i64 [B][nt] | vtot i64 [B] | flag
+    const float* vb_ref = nullptr;  // the reference mask those sums belong to (ehr_fused_bind_ref), or NULL
     // space-explorer scoring (ehr_mask_variance) keeps its own scratch so that it never disturbs a solver plan
     ehr::Scratch sc_counts, sc_offsets, sc_entries, sc_posc;
     size_t sc_entries_cap = 0;
-    // side stream: the empty-tile streaming kernel overlaps the queue fill + tile kernels
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fill = nullptr;
     // natively captured launch chain (ehr_graph_*): capture stream and the instantiated graph
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;

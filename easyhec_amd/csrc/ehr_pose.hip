@@ -53,9 +53,8 @@ __global__ void __launch_bounds__(256) pose_backward_kernel(const float* __restr
                                                             const float* __restrict__ link_poses,
                                                             const float* __restrict__ tc_jac, int B, int L, int H, int W,
                                                             float n, float f, float* __restrict__ red) {
-    __shared__ double S[256][16];
-    __shared__ double lsum[256];
-    pose_backward_block(grad_mvp, loss, K, link_poses, tc_jac, B, L, H, W, n, f, red, S, lsum);
+    __shared__ double S[4][17];
+    pose_backward_block(grad_mvp, loss, K, link_poses, tc_jac, B, L, H, W, n, f, red, S);
 }
 
 // Adam on dof with the gradient of the MEAN per-frame loss: g = red[0..5] / red[7].  adam = {lr, b1, b2, eps, wd}.

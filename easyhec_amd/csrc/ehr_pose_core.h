@@ -171,82 +171,91 @@ __device__ __forceinline__ void mvp_from_pose(const float* Tc, const float* P, c
 }
 
 // d(sum_b loss_b)/d dof, the loss sum and the frame count from d loss_b / d MVP[b,l]; one 256-thread workgroup,
-// fixed-order reductions.  S: LDS double [256][16]; lsum: LDS double [256].  get_g(i, G) fills the 16 floats of
-// d loss / d MVP for (view, link) pair i, get_loss(b) returns frame b's loss: the standalone kernel reads them from
-// global memory, the fused finish kernel straight from its accumulators (no store -> barrier -> reload round trip).
-// red_lds (optional, LDS float[8]) receives a copy of red for a following pose_adam_block in the same workgroup.
+// fixed-order reductions (a shuffle butterfly per wave, then the four waves in order).  S: LDS double [4][17].
+// get_g(i, G) fills the 16 floats of d loss / d MVP for (view, link) pair i, get_loss(b) returns frame b's loss: the
+// standalone kernel reads them from global memory, the in-kernel finish of the fused op straight from its accumulators
+// (no store -> barrier -> reload round trip).  red_lds (optional, LDS float[8]) receives a copy of red for a
+// following pose_adam_apply in the same workgroup.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 template <class GetG, class GetLoss>
 __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_loss, const float* __restrict__ K,
                                                       const float* __restrict__ link_poses,
                                                       const float* __restrict__ tc_jac, int B, int L, int H, int W,
-                                                      float n, float f, float* __restrict__ red, double (*S)[16],
-                                                      double* lsum, float* red_lds) {
-    // Jacobian rows are needed last but depend on nothing computed here: fetch them first
-    float J[16];
-    if (threadIdx.x < 6)
-        for (int k = 0; k < 16; k++) J[k] = tc_jac[16 * (threadIdx.x + 1) + k];
+                                                      float n, float f, float* __restrict__ red, double (*S)[17],
+                                                      float* red_lds) {
+    // Jacobian rows are needed last but depend on nothing computed here: fetch them first (into LDS, not registers:
+    // this body also runs inside the composite kernel, which is compiled for 80 registers)
+    __shared__ float Js[6][16];
+    if (threadIdx.x < 96) Js[threadIdx.x >> 4][threadIdx.x & 15] = tc_jac[16 + threadIdx.x];
     float P[16];
     projection(K, H, W, n, f, P);
     for (int r = 0; r < 4; r++) {  // PF = proj @ opencv2blender
         P[4 * r + 1] = -P[4 * r + 1];
         P[4 * r + 2] = -P[4 * r + 2];
     }
-    double acc[16];
-    for (int k = 0; k < 16; k++) acc[k] = 0.0;
+    // work item = (view-link pair, row r of d/dTc <G, PF @ Tc @ lp> = PF^T @ G @ lp^T): four threads per pair
+    const int r = threadIdx.x & 3;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     double la = 0.0;
-    for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
+    for (int i = threadIdx.x >> 2; i < B * L; i += blockDim.x >> 2) {
         float G[16];
         get_g(i, G);
         const float* lp = link_poses + (size_t)i * 16;
-        float M[16];  // d/dTc of <G, PF @ Tc @ lp>  =  PF^T @ G @ lp^T
-        for (int r = 0; r < 4; r++)
-            for (int c = 0; c < 4; c++) {
-                float s = 0.f;
-                for (int k = 0; k < 4; k++) s = fmaf(P[4 * k + r], G[4 * k + c], s);
-                M[4 * r + c] = s;
-            }
-        for (int r = 0; r < 4; r++)
-            for (int c = 0; c < 4; c++) {
-                float s = 0.f;
-                for (int k = 0; k < 4; k++) s = fmaf(M[4 * r + k], lp[4 * c + k], s);
-                acc[4 * r + c] += (double)s;
-            }
+        float M[4];
+        for (int c = 0; c < 4; c++) {
+            float s = 0.f;
+            for (int k = 0; k < 4; k++) s = fmaf(P[4 * k + r], G[4 * k + c], s);
+            M[c] = s;
+        }
+        for (int c = 0; c < 4; c++) {
+            float s = 0.f;
+            for (int k = 0; k < 4; k++) s = fmaf(M[k], lp[4 * c + k], s);
+            acc[c] += (double)s;
+        }
     }
     for (int i = threadIdx.x; i < B; i += blockDim.x) la += (double)get_loss(i);
-    for (int k = 0; k < 16; k++) S[threadIdx.x][k] = acc[k];
-    lsum[threadIdx.x] = la;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            for (int k = 0; k < 16; k++) S[threadIdx.x][k] += S[threadIdx.x + o][k];
-            lsum[threadIdx.x] += lsum[threadIdx.x + o];
-        }
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // lanes with the same r hold the same row: butterfly over the lane bits above the row index, then the four waves
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        double v = acc[c];
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane < 4) S[wave][4 * lane + c] = v;
     }
+    {
+        const double s = wave_sum_f64(la);
+        if (lane == 0) S[wave][16] = s;
+    }
+    __syncthreads();
     if (threadIdx.x < 8) {
-        float r;
+        float rr;
         if (threadIdx.x < 6) {
             double g = 0.0;
-            for (int k = 0; k < 16; k++) g += S[0][k] * (double)J[k];
-            r = (float)g;
+            for (int k = 0; k < 16; k++)
+                g += (((S[0][k] + S[1][k]) + S[2][k]) + S[3][k]) * (double)Js[threadIdx.x][k];
+            rr = (float)g;
         } else {
-            r = (threadIdx.x == 6) ? (float)lsum[0] : (float)B;
+            rr = (threadIdx.x == 6) ? (float)(((S[0][16] + S[1][16]) + S[2][16]) + S[3][16]) : (float)B;
         }
-        red[threadIdx.x] = r;
-        if (red_lds) red_lds[threadIdx.x] = r;
+        red[threadIdx.x] = rr;
+        if (red_lds) red_lds[threadIdx.x] = rr;
     }
 }
 
 __device__ __forceinline__ void pose_backward_block(const float* __restrict__ grad_mvp, const float* __restrict__ loss,
                                                     const float* __restrict__ K, const float* __restrict__ link_poses,
                                                     const float* __restrict__ tc_jac, int B, int L, int H, int W,
-                                                    float n, float f, float* __restrict__ red, double (*S)[16],
-                                                    double* lsum) {
+                                                    float n, float f, float* __restrict__ red, double (*S)[17]) {
     pose_backward_block_t(
         [&](int i, float* G) {
             for (int k = 0; k < 16; k++) G[k] = grad_mvp[(size_t)i * 16 + k];
         },
-        [&](int b) { return loss[b]; }, K, link_poses, tc_jac, B, L, H, W, n, f, red, S, lsum, nullptr);
+        [&](int b) { return loss[b]; }, K, link_poses, tc_jac, B, L, H, W, n, f, red, S, nullptr);
 }
 
 // torch.optim.Adam with L2 weight decay on dof, gradient of the MEAN per-frame loss = red[0..5] / red[7].

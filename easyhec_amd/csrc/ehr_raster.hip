@@ -175,7 +175,7 @@ using namespace ehr;
 
 extern "C" {
 
-int ehr_version(void) { return 2; }
+int ehr_version(void) { return 3; }
 
 const char* ehr_last_error(void) { return g_last_error.c_str(); }
 
@@ -205,8 +205,6 @@ int ehr_ctx_create(int device, ehr_ctx** out) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-        const char* path = getenv("EHR_FUSED_PATH");
-        c->path_vbuf = !(path && path[0] == 't');
     }
     hipError_t e = hipHostMalloc((void**)&c->host_pinned, 8 * sizeof(int), hipHostMallocDefault);
     (void)hipSetDevice(cur);
@@ -226,9 +224,6 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->counts.release();
     c->offsets.release();
     c->entries.release();
-    c->tile_part.release();
-    c->tile_list.release();
-    c->posc.release();
     c->sc_counts.release();
     c->sc_offsets.release();
     c->sc_entries.release();
@@ -242,14 +237,11 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->vb_posc.release();
     c->vb_spill.release();
     c->vb_units.release();
+    c->vb_refsum.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->ev_fill) (void)hipEventDestroy(c->ev_fill);
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
-    if (c->side) (void)hipStreamDestroy(c->side);
     (void)hipSetDevice(cur);
     delete c;
     return EHR_OK;

@@ -56,7 +56,7 @@ constexpr u64 VB_EMPTY = ~0ull;
 
 // Counters that many waves hit with atomics each get a 128-byte line of their own behind the meta block (atomics on
 // one line serialise memory-side at ~12 ns each): line xcd = job cursor of that XCD.
-#define VB_LINES 16
+#define VB_LINES 24   // 0-7 job cursors of the XCDs, 8-15 composite arrival tickets of the XCDs, 16 the top ticket
 __host__ __device__ __forceinline__ int* vb_line(int* meta, int k) {
     return (int*)((((uintptr_t)(meta + EHR_META_INTS)) + 127) & ~(uintptr_t)127) + 32 * k;
 }
@@ -266,10 +266,12 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
                 if (tid == 0) head.tc_jac[i] = T6[i].v;
                 head.tc_jac[16 * (tid + 1) + i] = T6[i].d[0];
             }
-            if (tid == 0 && head.history && head.step) {
-                int row = head.step[0];
-                if (row >= 0 && row < head.history_rows)
+            if (tid == 0 && head.history && head.hist_row) {  // rb_solver.py:50-51: the pose goes to the next free row
+                const int row = head.hist_row[0];
+                if (row >= 0 && row < head.history_rows) {
                     for (int k = 0; k < 6; k++) head.history[6 * row + k] = head.dof[k];
+                    head.hist_row[0] = row + 1;
+                }
             }
         }
     }
@@ -675,6 +677,14 @@ struct alignas(16) VbWaveLds {   // per wave of the job kernel
     unsigned sq[128];            // survivors of the box culling waiting for a full round: record slots (ring)
 };
 
+// What the composite kernel iterates over with a bound reference mask: per view the tile rectangle that encloses all
+// its links' tile ranges (vrect: tx0 | ty0 << 10 | nx << 22) and the running count of those tiles (vpre [B + 1]);
+// written by workgroup 0 of the job kernel.
+struct VbViewRects {
+    int* vpre;
+    unsigned* vrect;
+};
+
 // tiles (+ 1-pixel halo) a link's pixel box touches: the jobs of that (view, link)
 __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W, int H, int& tx0, int& ty0, int& nx, int& ny) {
     const int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
@@ -699,7 +709,7 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
 vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
               unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, int jcap,
-              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline) {
+              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline, VbViewRects vr) {
     __shared__ VbWaveLds lds_all[4];
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
@@ -740,8 +750,37 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         // job slots are numbered like the jobs: stage 3 finds a (view, link, tile) slot from the link's first job
         for (int u = tid; u < U; u += 256) jbase[u] = upre[u];
         if (tid == 0) {
-            meta[5] = total;  // diagnostics (EHR_VB_PRINT)
+            meta[5] = total;  // number of jobs (the resolve kernel's loop bound)
             if (total > jcap) meta[EHR_META_OVERFLOW] = 1;  // cannot happen with one slot per (view, link, tile)
+        }
+        // per view the tile rectangle that encloses its links' tile ranges: the composite kernel's work list when the
+        // reference mask is bound (the wave buffers are idle during the prologue)
+        int* const tmp = reinterpret_cast<int*>(&lds_all[0]);
+        for (int b = tid; b < B; b += 256) {
+            int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+            for (int l = 0; l < L; l++) {
+                const int u = b * L + l, n = upre[u + 1] - upre[u];
+                if (n > 0) {
+                    const unsigned ut = utile[u];
+                    const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
+                    x0 = min(x0, tx0);
+                    y0 = min(y0, ty0);
+                    x1 = max(x1, tx0 + nx - 1);
+                    y1 = max(y1, ty0 + n / nx - 1);
+                }
+            }
+            const bool ne = x1 >= x0;
+            vr.vrect[b] = ne ? ((unsigned)x0 | ((unsigned)y0 << 10) | ((unsigned)(x1 - x0 + 1) << 22)) : (1u << 22);
+            tmp[b] = ne ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int b = 0; b < B; b++) {
+                vr.vpre[b] = run;
+                run += tmp[b];
+            }
+            vr.vpre[B] = run;
         }
     }
     total = min(total, jcap);
@@ -1186,18 +1225,18 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
                         if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
                         spill_base = __builtin_amdgcn_readfirstlane(base);
                     }
+                    // items this job can keep: its slot, then its block of the spill pool as far as the pool reaches
+                    int room = VB_JOB_ITEMS;
+                    if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
                     if (keep) {
-                        if (at < VB_JOB_ITEMS) {
+                        if (at < VB_JOB_ITEMS)
                             jitems[slot * VB_JOB_ITEMS + at] = it;
-                        } else {
-                            const int gi = at - VB_JOB_ITEMS;
-                            if (gi < VB_SPILL_BLOCK && spill_base + gi < spill_cap)
-                                spill[spill_base + gi] = it;
-                            else
-                                meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
-                        }
+                        else if (at < room)
+                            spill[spill_base + (at - VB_JOB_ITEMS)] = it;
+                        else
+                            meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
                     }
-                    nitems = min(nnew, VB_JOB_ITEMS + VB_SPILL_BLOCK);
+                    nitems = min(nnew, room);  // never more than were stored: the composite kernel reads exactly these
                 }
             }
             VB_WAVE_SYNC();
@@ -1239,36 +1278,25 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
 #undef KT
 }
 
-// Stage 3: one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers): sums the links'
-// values in link order, clamps, accumulates the frame loss, writes the mask, and back-propagates the tile's blended
-// pairs to 12 numbers per link which go to the view's fixed-point accumulators.  Tiles no link box touches just stream
-// (mask = 0, loss += ref^2).  vec_ok: W % 4 == 0 and 16-byte aligned images.
-__global__ void __launch_bounds__(256, 8)
-vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const float* __restrict__ verts,
-                    const int* __restrict__ lbox, const int* __restrict__ jn, const float* __restrict__ jval,
-                    const VbItem* __restrict__ jitems, const int* __restrict__ jspill, const int* __restrict__ jbase,
-                    int jcap, const float* __restrict__ ref,
-                    float* __restrict__ mask, long long* __restrict__ facc, int nls, int want_grad, int vec_ok,
-                    const VbItem* __restrict__ spill, int* __restrict__ meta, int dbg) {
-    __shared__ float gpix_all[4][EHR_TILE_W * EHR_TILE_H];
+// Per (view, tile) of a BOUND reference mask: the fixed-point value the composite kernel would add to the view's frame
+// loss for a tile no link touches (mask = 0, so the tile contributes sum(ref^2), summed exactly like vb_composite_kernel
+// sums it: four pixels per lane, then the shuffle tree), and per view the total over all tiles.  The reference mask does
+// not change during a solve, so these are constants of the solve (ehr_fused_bind_ref); with them the composite kernel only
+// visits tiles inside the view's link boxes and adds fix(new) - cached there.  Integer sums are associative: bit-identical
+// to streaming every tile.
+__global__ void __launch_bounds__(256)
+vb_refsum_kernel(BinGeom g, int B, const float* __restrict__ ref, int vec_ok, long long* __restrict__ tsum,
+                 long long* __restrict__ vtot, int* __restrict__ flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* const gpix = gpix_all[wave];
-    const int W = g.W, H = g.H, L = g.L;
-    // XCD-aware order (locality only): every XCD takes a contiguous run of tiles
-    const int nwg = gridDim.x, per = (nwg + 7) >> 3;
-    const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int gw = wg * 4 + wave;  // (view, tile)
-    if (wg >= nwg || gw >= B * g.nt) return;
+    const int gw = blockIdx.x * 4 + wave;
+    if (gw >= B * g.nt) return;
+    const int W = g.W, H = g.H;
     const int b = gw / g.nt, tile = gw - b * g.nt;
     const int tx = tile % g.ntx, ty = tile / g.ntx;
-    const int acc_stride = 12 * L + nls * VB_LOSS_STRIDE;
-    long long* const vacc = facc + (size_t)b * acc_stride;
-    long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
-
     const int r = lane >> 3, c4 = (lane & 7) * 4;
-    const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
+    const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;
     const bool row_in = iy < H;
-    const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
+    const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;
     float rf[4] = {0.f, 0.f, 0.f, 0.f};
     bool pin[4];
 #pragma unroll
@@ -1283,6 +1311,90 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
         for (int j = 0; j < 4; j++)
             if (pin[j]) rf[j] = ref[im + j];
     }
+    float e2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (pin[j]) {
+            const float e = 0.f - rf[j];
+            e2 += e * e;
+        }
+    const float s = wave_sum(e2);
+    if (lane == 0) {
+        long long q = 0;
+        if (!(fabsf(s) < 1.0e9f))
+            atomicOr(flag, 1);  // every step on this reference reports the overflow (loss = NaN)
+        else if (s != 0.f)
+            q = fix_of(s);
+        tsum[gw] = q;
+        if (q != 0) atomicAdd((unsigned long long*)&vtot[b], (unsigned long long)q);
+    }
+}
+
+// Stage 3: one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers): sums the links'
+// values in link order, clamps, accumulates the frame loss, writes the mask, and back-propagates the tile's blended
+// pairs to 12 numbers per link which go to the view's fixed-point accumulators.  Persistent waves over
+//   tsum == NULL: every tile of every view (tiles no link box touches just stream: mask = 0, loss += ref^2);
+//   tsum != NULL (bound reference mask, no mask output): the tiles of the views' link rectangles only; a tile that no
+//                 link contributes to is skipped without touching the image -- its cached sum is already in vtot.
+// The workgroup that finishes LAST (a ticket per XCD, then one over the XCDs) runs the finish stage: accumulators ->
+// loss / grad_mvp [-> pose backward -> Adam], re-arms the link boxes.  vec_ok: W % 4 == 0 and 16-byte aligned images.
+template <bool TAIL>
+__global__ void __launch_bounds__(256, 6)
+vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const float* __restrict__ verts,
+                    int* __restrict__ lbox, const int* __restrict__ jn, const float* __restrict__ jval,
+                    const VbItem* __restrict__ jitems, const int* __restrict__ jspill, const int* __restrict__ jbase,
+                    int jcap, const float* __restrict__ ref,
+                    float* __restrict__ mask, long long* __restrict__ facc, int nls, int want_grad, int vec_ok,
+                    const VbItem* __restrict__ spill, int spill_cap, int* __restrict__ meta, int dbg,
+                    const long long* __restrict__ tsum, const long long* __restrict__ vtot,
+                    const int* __restrict__ ref_flag, VbViewRects vr, float* __restrict__ loss,
+                    float* __restrict__ grad_mvp, StepTail tail) {
+    __shared__ float gpix_all[4][EHR_TILE_W * EHR_TILE_H];
+    __shared__ int s_vpre[VB_MAX_VIEWS + 1];
+    __shared__ unsigned s_vrect[VB_MAX_VIEWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const gpix = gpix_all[wave];
+    const int W = g.W, H = g.H, L = g.L;
+    const bool sparse = tsum != nullptr;
+    int nitems = B * g.nt;
+    if (sparse) {
+        for (int i = tid; i <= B; i += 256) s_vpre[i] = vr.vpre[i];
+        for (int i = tid; i < B; i += 256) s_vrect[i] = vr.vrect[i];
+        __syncthreads();
+        nitems = s_vpre[B];
+    }
+    // XCD-aware order (locality only): every XCD takes a contiguous run of items
+    const int nwg = gridDim.x;
+    const int per_xcd = (nitems + 7) >> 3, xcd = blockIdx.x & 7;
+    const int ibeg = xcd * per_xcd, iend = min(ibeg + per_xcd, nitems);
+    const int istep = (nwg >> 3) * 4;
+    const int acc_stride = 12 * L + nls * VB_LOSS_STRIDE;
+    const int r = lane >> 3, c4 = (lane & 7) * 4;
+    for (int item = ibeg + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += istep) {
+    int b, tx, ty;
+    if (sparse) {
+        int lo = 0, hi = B - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_vpre[mid] <= item)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        b = lo;
+        const unsigned vrc = s_vrect[b];
+        const int nx = (int)(vrc >> 22), k = item - s_vpre[b];
+        ty = (int)((vrc >> 10) & 4095u) + k / nx;
+        tx = (int)(vrc & 1023u) + k - (k / nx) * nx;
+    } else {
+        b = item / g.nt;
+        const int tile = item - b * g.nt;
+        tx = tile % g.ntx;
+        ty = tile / g.ntx;
+    }
+    const int tile = ty * g.ntx + tx;
+    long long* const vacc = facc + (size_t)b * acc_stride;
+    long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
     const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
     // links whose screen box touches the tile + halo region (lane l tests link l): exactly the jobs stage 2 ran
     unsigned tmask;
@@ -1300,6 +1412,24 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
             }
         }
         tmask = (unsigned)__ballot(myn >= 0);  // links that contribute a value here
+    }
+    if (sparse && tmask == 0) continue;  // nothing drawn here: the tile's cached sum(ref^2) is part of vtot already
+    const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
+    const bool row_in = iy < H;
+    const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
+    float rf[4] = {0.f, 0.f, 0.f, 0.f};
+    bool pin[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pin[j] = row_in && (ix + j) < W;
+    if (vec_ok) {
+        if (pin[0]) {
+            const float4 r4 = *reinterpret_cast<const float4*>(ref + im);
+            rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (pin[j]) rf[j] = ref[im + j];
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned todo = tmask;
@@ -1339,13 +1469,19 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     }
     {
         const float s = wave_sum(e2);
-        if (lane == 0) fix_add(lacc, s, meta);
+        if (lane == 0) {
+            if (sparse)
+                fix_add_delta(lacc, s, tsum[(size_t)b * g.nt + tile], meta);
+            else
+                fix_add(lacc, s, meta);
+        }
     }
     const unsigned bmask = (unsigned)__ballot(myn > 0);  // links with blended pairs to back-propagate
-    if (!want_grad || bmask == 0 || (dbg & 4)) return;
+    if (!want_grad || bmask == 0 || (dbg & 4)) continue;
 
     // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
     const float4* const pv = posc + (size_t)b * V;
+    VB_WAVE_SYNC();  // the previous tile's reads of gpix are complete
 #pragma unroll
     for (int j = 0; j < 4; j++) gpix[r * EHR_TILE_W + c4 + j] = gv[j];
     VB_WAVE_SYNC();
@@ -1354,8 +1490,13 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
         const int l = __ffs(links) - 1;
         links &= links - 1;
         const size_t slot = (size_t)vb_readlane(myslot, l);
-        const int n = vb_readlane(myn, l);
-        const int sbase = (n > VB_JOB_ITEMS) ? jspill[slot] : 0;
+        int n = vb_readlane(myn, l);
+        int sbase = 0;
+        if (n > VB_JOB_ITEMS) {  // the rest of the list lives in the spill pool; never read outside it
+            sbase = jspill[slot];
+            if (sbase < 0 || sbase >= spill_cap) n = VB_JOB_ITEMS;
+            else n = min(n, VB_JOB_ITEMS + (spill_cap - sbase));
+        }
         float G[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) G[k] = 0.f;
@@ -1394,6 +1535,31 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
         }
         if (lane < 12) fix_add(&vacc[12 * l + lane], mine, meta);
     }
+    }
+    // ---- the workgroup whose atomics are performed last runs the finish stage.  Every wave first waits until its own
+    //      atomics have been performed (vmcnt covers them), then one lane takes a ticket on the XCD's counter and the
+    //      last of an XCD one on the top counter: two levels, because a few thousand arrivals on ONE address serialise
+    //      at ~12 ns each.  The accumulators are only ever touched by agent-scope atomics and read back with agent-scope
+    //      loads (acc_load), so no cache maintenance is needed between the two.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) {
+        int last = 0;
+        const int per = nwg >> 3;  // workgroups per XCD counter (nwg is a multiple of 8)
+        if (atomicAdd(vb_line(meta, 8 + xcd), 1) == per - 1) last = atomicAdd(vb_line(meta, 16), 1) == 7;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (ref_flag && tid == 0 && ref_flag[0]) atomicOr(&meta[EHR_META_OVERFLOW], 1);  // the bound reference's own sums overflowed
+    __syncthreads();
+    __shared__ double S[4][17];
+    __shared__ float red_lds[8];
+#ifndef VB_NO_FINISH
+    finish_body<TAIL>(g, B, facc, sparse ? vtot : nullptr, loss, grad_mvp, meta, tail, nls, lbox, VB_LOSS_STRIDE,
+                      gpix_all[0], S, red_lds);
+#endif
 }
 
 // [T][3] int32 -> [T] int4 (one aligned 16-byte gather per triangle in the silhouette analysis)
@@ -1530,8 +1696,8 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: resolution above 32736 x 32760 (W x H) is unsupported");
     if ((long long)B * L > VB_MAX_UNITS)  // the job kernel keeps 8 bytes per (view, link) in LDS
         return fail(EHR_ERR_INVALID,
-                    "ehr_fused_plan: %d views x %d links exceeds the %d (view, link) units one context handles on the default "
-                    "chain; split the views over several contexts / calls (or set EHR_FUSED_PATH=tile)", B, L, VB_MAX_UNITS);
+                    "ehr_fused_plan: %d views x %d links exceeds the %d (view, link) units one context handles; split the "
+                    "views over several contexts / calls", B, L, VB_MAX_UNITS);
     if ((V > 0 && !verts) || (T > 0 && (!tris || !tri_link || !opp)))
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: the scene arrays (verts, tris, tri_link, opp) are required");
     int rc;
@@ -1541,8 +1707,19 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     if ((rc = ctx->vb_posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
     // per step and (view, cluster slot): tdep 48 B | trec 32 B | tbox 8 B, then cbox 8 B per (view, cluster)
     if ((rc = ctx->vb_boxes.reserve((size_t)B * NC * (64 * 88 + 8)))) return rc;
-    if ((rc = ctx->vb_spill.reserve((size_t)VB_SPILL_ITEMS * sizeof(VbItem)))) return rc;
-    if ((rc = ctx->vb_units.reserve((size_t)VB_LBOX_STRIDE * B * L * sizeof(int)))) return rc;
+    {  // pool of blended pairs for jobs that exceed their slot (EHR_VB_SPILL_ITEMS: test hook for the overflow path)
+        const char* e = getenv("EHR_VB_SPILL_ITEMS");
+        ctx->vb_spill_cap = e ? std::max(0, atoi(e)) : VB_SPILL_ITEMS;
+        // (the -DVB_TIMELINE profiling build parks its per-wave records here: keep room for them)
+        if ((rc = ctx->vb_spill.reserve(std::max((size_t)ctx->vb_spill_cap * sizeof(VbItem), (size_t)1 << 20)))) return rc;
+    }
+    // link boxes (one 64-byte line each) | per-view tile rectangles: vpre [B + 1] | vrect [B]
+    if ((rc = ctx->vb_units.reserve(((size_t)VB_LBOX_STRIDE * B * L + 2 * (size_t)B + 1) * sizeof(int)))) return rc;
+    {  // a bound reference mask's cached sums: tsum [B][nt] | vtot [B] | flag
+        BinGeom g0 = make_geom(H, W, L);
+        if ((rc = ctx->vb_refsum.reserve(((size_t)B * g0.nt + B + 1) * sizeof(long long)))) return rc;
+        ctx->vb_ref = nullptr;  // a new plan forgets the binding
+    }
     {  // job slots, compact (numbered like the jobs): value tile 1 KB | items 1 KB | count | spill base | region ids 1.36 KB;
        // descriptor; then the links' first jobs
         BinGeom g = make_geom(H, W, L);
@@ -1742,8 +1919,11 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     int* jdesc = (int*)(jid + nslot * VB_RN);
     int* jbase = jdesc + nslot;
     const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
+    VbViewRects vr;
+    vr.vpre = lbox + (size_t)VB_LBOX_STRIDE * B * L;
+    vr.vrect = (unsigned*)(vr.vpre + B + 1);
     vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jn, jid, jdesc, jbase, ctx->vb_jcap, meta, dbg, hv,
-                                                (long long*)ctx->vb_spill.ptr);
+                                                (long long*)ctx->vb_spill.ptr, vr);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
     // stage 1b: drawn jobs -> per-link values and blended pairs
@@ -1751,31 +1931,57 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
     vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
                                                    jid, jdesc, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
-                                                   VB_SPILL_ITEMS, meta, dbg);
+                                                   ctx->vb_spill_cap, meta, dbg);
     EHR_LAUNCH_CHECK();
     if (ev) {
         for (int k = 3; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
     }
-    // stage 2: composite, loss, mask, backward
-    int nwg = (ntiles + 3) / 4;
-    nwg = (nwg + 7) & ~7;  // a multiple of 8 keeps the XCD remap a bijection
-    vb_composite_kernel<<<nwg, 256, 0, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, ctx->vb_jcap, ref, mask,
-                                                 facc,
-                                                 VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, meta, dbg);
-    EHR_LAUNCH_CHECK();
-    if (ev) {
-        EHR_HIP(hipEventRecord(ev[5], stream));
-        EHR_HIP(hipEventRecord(ev[6], stream));
-    }
-    // stage 2: accumulators -> loss / grad_mvp (+ pose backward and Adam in the solver-step form), one workgroup;
-    // it also re-arms the link boxes for the next step
+    // stage 2: composite, loss, mask, backward; its last-arriving workgroup runs the finish stage (accumulators -> loss /
+    // grad_mvp, + pose backward and Adam in the solver-step form; re-arms the link boxes).  With a bound reference mask
+    // and no mask output only the tiles inside the views' link rectangles are visited.
+    static const int no_sparse = getenv("EHR_VB_NO_SPARSE") ? atoi(getenv("EHR_VB_NO_SPARSE")) : 0;  // A/B aid
+    const bool sparse = !no_sparse && !mask && ctx->vb_ref != nullptr && ctx->vb_ref == ref;
+    static const int comp_grid = getenv("EHR_VB_COMPOSITE_GRID") ? atoi(getenv("EHR_VB_COMPOSITE_GRID")) : 6;  // tuning knob (6 resident per CU)
+    int nwg = ctx->num_cus * std::max(1, comp_grid);
+    if (!sparse) nwg = std::min(nwg, (ntiles + 3) / 4);
+    nwg = std::max(8, (nwg + 7) & ~7);  // a multiple of 8: the XCD split and the two-level arrival ticket rely on it
+    const long long* tsum = sparse ? (const long long*)ctx->vb_refsum.ptr : nullptr;
+    const long long* vtot = sparse ? tsum + (size_t)B * g.nt : nullptr;
+    const int* ref_flag = sparse ? (const int*)(vtot + B) : nullptr;
     if (tail) {
-        fused_finish_kernel<true><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, *tail, VB_LOSS_SLOTS, lbox, VB_LOSS_STRIDE);
+        vb_composite_kernel<true><<<nwg, 256, 0, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase,
+                                                         ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0,
+                                                         vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag,
+                                                         vr, loss, grad_mvp, *tail);
     } else {
         StepTail none = {};
-        fused_finish_kernel<false><<<1, 256, 0, stream>>>(g, B, facc, loss, grad_mvp, meta, none, VB_LOSS_SLOTS, lbox, VB_LOSS_STRIDE);
+        vb_composite_kernel<false><<<nwg, 256, 0, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase,
+                                                          ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0,
+                                                          vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot,
+                                                          ref_flag, vr, loss, grad_mvp, none);
     }
     EHR_LAUNCH_CHECK();
-    if (ev) EHR_HIP(hipEventRecord(ev[7], stream));
+    if (ev) {
+        for (int k = 5; k <= 7; k++) EHR_HIP(hipEventRecord(ev[k], stream));
+    }
+    return EHR_OK;
+}
+
+
+// Binds a reference mask to the plan (ehr_fused_bind_ref): one pass stores per (view, tile) the fixed-point sum(ref^2)
+// exactly as the composite kernel would add it for a tile no link touches, and per view the total.  ref == NULL unbinds.
+int ehr::vbuf_bind_ref(ehr_ctx* ctx, const float* ref, hipStream_t stream) {
+    ctx->vb_ref = nullptr;
+    if (!ref) return EHR_OK;
+    const int B = ctx->pB, H = ctx->pH, W = ctx->pW;
+    BinGeom g = make_geom(H, W, ctx->pL);
+    long long* tsum = (long long*)ctx->vb_refsum.ptr;
+    long long* vtot = tsum + (size_t)B * g.nt;
+    EHR_HIP(hipMemsetAsync(vtot, 0, ((size_t)B + 1) * sizeof(long long), stream));
+    const int vec_ok = ((W & 3) == 0) && (((uintptr_t)ref & 15) == 0);
+    const int nw = B * g.nt;
+    vb_refsum_kernel<<<(nw + 3) / 4, 256, 0, stream>>>(g, B, ref, vec_ok, tsum, vtot, (int*)(vtot + B));
+    EHR_LAUNCH_CHECK();
+    ctx->vb_ref = ref;
     return EHR_OK;
 }

@@ -38,12 +38,14 @@ class FusedPoseStep:
         self.near, self.far = near, far
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
-        # optimiser state (torch.optim.Adam names).  step_t counts the optimisation steps taken AND is the row of
-        # ``history_ops`` the next step records its pose in (the reference's first all-zero row, rb_solver.py:50-51):
-        # it starts at the model's history cursor so that a solver built on a loaded checkpoint appends.
+        # optimiser state (torch.optim.Adam names): a fresh Adam (step 0, zero moments) unless load_state_dict restores
+        # one -- like the reference's load_model path.  The row of ``history_ops`` the next step records its pose in is a
+        # counter of its own (the reference's first all-zero row, rb_solver.py:50-51): it starts at the model's history
+        # cursor, so a solver built on a loaded checkpoint appends whatever the optimiser's step count is.
         self.exp_avg = torch.zeros(6, device=dev)
         self.exp_avg_sq = torch.zeros(6, device=dev)
-        self.step_t = torch.full((1,), int(model.history_cursor()), dtype=torch.int32, device=dev)
+        self.step_t = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.hist_row = torch.full((1,), int(model.history_cursor()), dtype=torch.int32, device=dev)
         # work buffers, allocated once
         self.mvp = torch.empty((self.B, self.L, 4, 4), device=dev)
         self.grad_mvp = torch.empty((self.B, self.L, 4, 4), device=dev)
@@ -54,6 +56,9 @@ class FusedPoseStep:
         self.grad = torch.zeros((6,), device=dev)
         self.mask = torch.empty((self.B, self.H, self.W), device=dev)
         fused._ensure_plan(self.glctx, self.scene, self.B, self.H, self.W)
+        # the reference masks are constants of the solve: cache the loss of the tiles no link touches once
+        # (ehr_fused_bind_ref; bit-identical results).  self.ref is this object's private copy, never written to.
+        fused.bind_ref(self.glctx, self.scene, self.ref)
         self._graph = None
 
     # -- one step -------------------------------------------------------------------------------------------------
@@ -64,14 +69,14 @@ class FusedPoseStep:
         m, sc = self.model, self.scene
         dof = m.dof.data
         hist = m.history_ops
-        # one C call = 5 launches: [pose fwd + vertices + raster records] -> jobs -> resolve -> composite ->
-        # [accumulators + pose bwd (+ Adam)]   (7 with EHR_FUSED_PATH=tile, round 1's queue-based chain)
+        # one C call = 4 launches: [pose fwd + vertices + raster records] -> jobs -> resolve -> composite [+ in its last
+        # workgroup: accumulators + pose bwd (+ Adam)]
         _lib.check(lib.ehr_solver_step(
             self.glctx.handle, _lib.ptr(sc.verts), _lib.ptr(sc.tris), _lib.ptr(sc.tri_link), _lib.ptr(sc.vert_link),
             _lib.ptr(sc.opp), _lib.ptr(self.K), _lib.ptr(self.link_poses), _lib.ptr(self.ref), self.B, self.L,
             sc.num_verts, sc.num_tris, self.H, self.W, _f(self.near), _f(self.far), _lib.ptr(dof),
             _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), _lib.ptr(self.step_t), _lib.ptr(hist), hist.shape[0],
-            _f(self.lr), _f(self.betas[0]), _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.mvp),
+            _lib.ptr(self.hist_row), _f(self.lr), _f(self.betas[0]), _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.mvp),
             _lib.ptr(self.tc_jac), _lib.ptr(self.mask if want_mask else None), _lib.ptr(self.loss_b),
             _lib.ptr(self.grad_mvp), _lib.ptr(self.red), _lib.ptr(self.loss), _lib.ptr(self.grad),
             int(self.distributed), stream), "ehr_solver_step")
@@ -95,8 +100,7 @@ class FusedPoseStep:
         return self.loss
 
     def capture(self):
-        """Record the step's launch chain (5 kernels on one stream; the round-1 tile chain adds a side stream with its
-        fork/join events) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
+        """Record the step's launch chain (4 kernels on one stream) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
         with one host call.  Iteration state lives on the device, so replays are ordinary optimisation steps.  The
         chain is GPU-bound, so this saves host time, not step time.  Single-process only: the data-parallel step has a
         collective between the chain and Adam."""

@@ -63,6 +63,7 @@ def _ensure_plan(glctx, scene, B, H, W):
     plan = getattr(glctx, "_plan", None)
     if plan is None or plan.key != _plan_key(scene, B, H, W):
         glctx._plan = _Plan(glctx, scene, B, H, W)
+        glctx._bound_ref = None  # ehr_fused_plan forgets a bound reference mask
 
 
 def check_status(glctx):
@@ -130,17 +131,28 @@ def mvp_matrices(K, H, W, Tc_c2b, link_poses, n=0.001, f=10.0):
     return proj @ (o2b @ Tc_c2l)                      # nvdiffrast_renderer.py:35,37 (same association)
 
 
-import os as _os
+# kernels bracketed by ehr_fused_timing's hipEvents, in ms[] order (include/ehr.h): vertex + records, jobs, resolve,
+# composite (+ the finish stage in its last workgroup); slots 3, 5, 6 are unused.
+STAGES = ("vertex", "job", "resolve", "unused3", "composite", "unused5", "unused6")
+DOMINANT_STAGE, DOMINANT_KERNEL = "job", "vb_job_kernel"
 
-# kernels bracketed by ehr_fused_timing's hipEvents, in ms[] order (include/ehr.h).  Visibility-buffer chain (default):
-# vertex + records, jobs, resolve, composite, finish (slots 3, 5 unused); round-1 tile chain (EHR_FUSED_PATH=tile): its
-# seven.
-if (_os.environ.get("EHR_FUSED_PATH") or "v")[0] == "t":
-    STAGES = ("bin_count", "bin_alloc", "bin_fill", "tile_empty", "tile", "tile_slow", "reduce")
-    DOMINANT_STAGE, DOMINANT_KERNEL = "tile", "fused_tile_kernel<false>"
-else:
-    STAGES = ("vertex", "job", "resolve", "unused3", "composite", "unused5", "finish")
-    DOMINANT_STAGE, DOMINANT_KERNEL = "job", "vb_job_kernel"
+
+def bind_ref(glctx, scene, ref):
+    """Bind a reference-mask batch to the context's plan (``ehr_fused_bind_ref``): the loss contribution of the tiles no
+    link touches is cached once, and later calls with THIS tensor and no mask output only visit the tiles inside the
+    views' link boxes -- bit-identical results (64-bit fixed-point sums).  The caller must not modify ``ref`` in place
+    while it is bound; ``ref=None`` unbinds.  The context keeps a reference to the tensor."""
+    if ref is None:
+        _lib.check(_lib.lib().ehr_fused_bind_ref(glctx.handle, None, None), "ehr_fused_bind_ref")
+        glctx._bound_ref = None
+        return
+    dr._check_dev("ref", ref, torch.float32)
+    dr._require(ref.dim() == 3 and ref.is_contiguous(), "ref must be a contiguous [B, H, W] tensor")
+    _ensure_plan(glctx, scene, ref.shape[0], ref.shape[1], ref.shape[2])
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with torch.cuda.device(glctx.device):
+        _lib.check(_lib.lib().ehr_fused_bind_ref(glctx.handle, _lib.ptr(ref), stream), "ehr_fused_bind_ref")
+    glctx._bound_ref = ref
 
 
 def set_timing(glctx, enable):

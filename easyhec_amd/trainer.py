@@ -112,7 +112,7 @@ class RBSolverTrainer:
         rendered = f.mask.clone()
         ref = self.batch["mask"]
         out = {"rendered_masks": rendered, "ref_masks": ref, "error_maps": (rendered - ref.float()).abs()}
-        row = (f.step_t.long() - 1).clamp(0, m.history_ops.shape[0] - 1)
+        row = (f.hist_row.long() - 1).clamp(0, m.history_ops.shape[0] - 1)
         dof_before = m.history_ops[row][0]
         gt_dof6 = self.batch.get("gt_dof6")
         if gt_dof6 is not None:
@@ -161,15 +161,32 @@ class RBSolverTrainer:
         d = torch.load(path, map_location="cpu", weights_only=False)
         self.model.load_state_dict(d["model"])  # also invalidates the model's history cursor
         if self.fast is not None:
-            self.fast.step_t.fill_(int(self.model.history_cursor()))
+            # the history row always comes from the restored model (first all-zero row); the Adam state only from a
+            # saved optimiser -- without one the solve continues with a fresh Adam, like the reference's load_model path
+            self.fast.hist_row.fill_(int(self.model.history_cursor()))
+            self.fast.step_t.zero_()
+            self.fast.exp_avg.zero_()
+            self.fast.exp_avg_sq.zero_()
             if "optimizer" in d:
                 self.fast.load_state_dict(d["optimizer"])
         elif "optimizer" in d and len(d["optimizer"].get("state", {})) > 0:
-            st = d["optimizer"]["state"]
-            st = st[sorted(st.keys())[0]]
-            p = self.model.dof
-            self.optimizer.state[p] = {
-                "step": torch.as_tensor(st["step"], dtype=torch.float32).reshape(()).clone(),
-                "exp_avg": torch.as_tensor(st["exp_avg"], dtype=p.dtype).reshape(p.shape).to(p.device).clone(),
-                "exp_avg_sq": torch.as_tensor(st["exp_avg_sq"], dtype=p.dtype).reshape(p.shape).to(p.device).clone()}
+            sd = d["optimizer"]
+            first = sd["state"][sorted(sd["state"].keys())[0]]
+            if "param_groups" in sd and all(torch.is_tensor(v) or not isinstance(v, (list, tuple)) for v in first.values()):
+                # a torch-shaped state dict (base.py:388-440 does exactly this): moments, step AND param_groups (lr);
+                # works for every optimiser make_optimizer builds (Adam's exp_avg / SGD's momentum_buffer)
+                sd = {"state": {k: {n: (torch.as_tensor(t).reshape(()).float() if n == "step" else t)
+                                    for n, t in st.items()} for k, st in sd["state"].items()},
+                      "param_groups": sd["param_groups"]}
+                try:
+                    self.optimizer.load_state_dict(sd)
+                    sd = None
+                except (ValueError, KeyError):
+                    pass  # saved by a different optimiser type / group layout: fall through to the moment copy
+            if sd is not None and {"exp_avg", "exp_avg_sq", "step"} <= set(first.keys()):
+                p = self.model.dof  # the launch chain's Adam state into torch.optim.Adam
+                self.optimizer.state[p] = {
+                    "step": torch.as_tensor(first["step"], dtype=torch.float32).reshape(()).clone(),
+                    "exp_avg": torch.as_tensor(first["exp_avg"], dtype=p.dtype).reshape(p.shape).to(p.device).clone(),
+                    "exp_avg_sq": torch.as_tensor(first["exp_avg_sq"], dtype=p.dtype).reshape(p.shape).to(p.device).clone()}
         self.global_steps = d.get("global_steps", 0)

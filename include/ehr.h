@@ -36,7 +36,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 2 (2: ehr_fused_plan takes the scene arrays) */
+int ehr_version(void);                 /* ABI version, currently 3 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
@@ -110,15 +110,26 @@ int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, 
                          int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream);
 int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVERFLOW */
 
+/* Binds a reference-mask batch ref [B,H,W] (the planned shape) to the plan.  The reference masks of a solve do not
+ * change (rb_solver.py:70 compares every step with the same dps['mask']), so the part of the frame loss that comes from
+ * image tiles no link touches -- sum(ref^2) over those tiles, 90 % of a 1280x720 frame -- is a constant of the solve.
+ * This call stores it once (one pass over ref: per tile the fixed-point value the composite stage would add, per view the
+ * total); afterwards ehr_render_mask_loss / ehr_solver_step calls that pass THIS pointer and mask == NULL visit only the
+ * tiles inside the views' link boxes and correct the cached total by integer differences.  The sums are 64-bit fixed
+ * point, so loss and gradients are bit-identical to the unbound path; it is an exact algebraic saving, not skipped
+ * work.  The caller promises not to modify ref's contents while it is bound: call again after changing them, or with
+ * ref == NULL to unbind.  ehr_fused_plan unbinds.  Calls with another pointer or with a mask output take the unbound
+ * path.  Enqueues on `stream`; not to be called inside a graph capture. */
+int ehr_fused_bind_ref(ehr_ctx* ctx, const float* ref, void* stream);
+
 /* Measurement hook (bench.py's roofline leg): when enabled, every ehr_render_mask_loss / ehr_solver_step call records
  * hipEvents around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED
  * milliseconds per stage since the last read and the number of calls covered, then resets.  Stages of the default
  * (visibility-buffer) chain: ms[0] vertex kernel (pose forward, clip-space vertices, per-triangle raster records, cluster
  * and link boxes), ms[1] job kernel (one wave per (view, link, tile): box culling, LDS rasterizer -- the dominant
  * kernel), ms[2] resolve kernel (one wave per drawn job: silhouette analysis, antialiased values, blended pairs), ms[4]
- * composite kernel (link sum, clamp, loss, mask, backward), ms[6] finish kernel (accumulators -> loss / grad_mvp [-> pose
- * backward -> Adam]); ms[3], ms[5] are unused (~0).  With EHR_FUSED_PATH=tile the seven
- * slots are the round-1 chain's: count, alloc, fill, empty tiles, tile kernel, its slow instantiation, reduce.
+ * composite kernel (link sum, clamp, loss, mask, backward; its last-arriving workgroup runs the finish stage:
+ * accumulators -> loss / grad_mvp [-> pose backward -> Adam]); ms[3], ms[5], ms[6] are unused (~0).
  * Not for use under graph capture. */
 #define EHR_FUSED_STAGES 7
 int ehr_fused_timing(ehr_ctx* ctx, int enable);
@@ -143,19 +154,23 @@ int ehr_pose_backward(const float* grad_mvp, const float* loss, const float* K, 
 int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* red, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
 
-/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 5 launches (7 with EHR_FUSED_PATH=tile):
+/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 4 launches:
  * ehr_pose_forward is merged into the vertex kernel (which also does the per-step housekeeping) and ehr_pose_backward +
- * ehr_pose_adam into the one-workgroup finish kernel.  Same arithmetic and outputs as calling the pieces one by one:
+ * ehr_pose_adam into the finish stage of the composite kernel.  Same arithmetic and outputs as calling the pieces one by one:
  * mvp [B,L,16], tc_jac [7,16], loss_b [B], grad_mvp [B,L,16], red [8], loss_out [1], grad_out [6] are all written.
+ * `step` [1] is Adam's step count (bias correction); `history_row` [1] is the row of history [history_rows,6] that
+ * receives this step's pose (rb_solver.py:50-51: the first free row) and is advanced by the call -- two counters,
+ * because a solver built on a loaded model starts a fresh optimiser but keeps appending to the history.  history ==
+ * NULL records nothing.
  * defer_adam != 0 stops after `red` so that the caller can all-reduce it across ranks and then call ehr_pose_adam.
  * Requires ehr_fused_plan for (B,L,V,T,H,W); never synchronises or allocates. */
 int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
                     const int32_t* vert_link, const int32_t* opp, const float* K, const float* link_poses,
                     const float* ref, int B, int L, int V, int T, int H, int W, float near_plane, float far_plane,
-                    float* dof, float* adam_m, float* adam_v, int32_t* step, float* history, int history_rows, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, float* mvp, float* tc_jac, float* mask,
-                    float* loss_b, float* grad_mvp, float* red, float* loss_out, float* grad_out, int defer_adam,
-                    void* stream);
+                    float* dof, float* adam_m, float* adam_v, int32_t* step, float* history, int history_rows,
+                    int32_t* history_row, float lr, float beta1, float beta2, float eps, float weight_decay, float* mvp,
+                    float* tc_jac, float* mask, float* loss_b, float* grad_mvp, float* red, float* loss_out,
+                    float* grad_out, int defer_adam, void* stream);
 
 /* hipGraph capture of launch chains.  ehr_graph_begin opens a capture on a stream the context owns and returns it; every
  * library call made with THAT stream until ehr_graph_end (e.g. one ehr_solver_step, or ehr_solver_step with defer_adam

@@ -54,7 +54,8 @@ def test_64_views_equal_their_8_shards(xarm7):
             fs.glctx.handle, _lib.ptr(sc.verts), _lib.ptr(sc.tris), _lib.ptr(sc.tri_link), _lib.ptr(sc.vert_link),
             _lib.ptr(sc.opp), _lib.ptr(fs.K), _lib.ptr(fs.link_poses), _lib.ptr(fs.ref), fs.B, fs.L, sc.num_verts,
             sc.num_tris, fs.H, fs.W, f(fs.near), f(fs.far), _lib.ptr(m.dof.data), _lib.ptr(fs.exp_avg),
-            _lib.ptr(fs.exp_avg_sq), _lib.ptr(fs.step_t), _lib.ptr(hist), hist.shape[0], f(fs.lr), f(fs.betas[0]),
+            _lib.ptr(fs.exp_avg_sq), _lib.ptr(fs.step_t), _lib.ptr(hist), hist.shape[0], _lib.ptr(fs.hist_row), f(fs.lr),
+            f(fs.betas[0]),
             f(fs.betas[1]), f(fs.eps), f(fs.wd), _lib.ptr(fs.mvp), _lib.ptr(fs.tc_jac), _lib.ptr(fs.mask),
             _lib.ptr(fs.loss_b), _lib.ptr(fs.grad_mvp), _lib.ptr(fs.red), _lib.ptr(fs.loss), _lib.ptr(fs.grad), 1,
             stream), "ehr_solver_step")

@@ -108,7 +108,8 @@ def test_merged_step_equals_the_separate_kernels(xarm7, B, H, W, scale):
         dof, hist = mb.dof.data, mb.history_ops
         _lib.check(lib.ehr_pose_forward(_lib.ptr(dof), _lib.ptr(fb.K), _lib.ptr(fb.link_poses), fb.B, fb.L, fb.H, fb.W,
                                         f(fb.near), f(fb.far), _lib.ptr(fb.mvp), _lib.ptr(fb.tc_jac),
-                                        _lib.ptr(fb.step_t), _lib.ptr(hist), hist.shape[0], stream), "fwd")
+                                        _lib.ptr(fb.hist_row), _lib.ptr(hist), hist.shape[0], stream), "fwd")
+        fb.hist_row += 1  # ehr_solver_step advances the history row itself, the stand-alone kernel only reads it
         fused._launch(fb.glctx, fb.scene, fb.mvp, fb.ref, None, fb.loss_b, fb.grad_mvp)
         _lib.check(lib.ehr_pose_backward(_lib.ptr(fb.grad_mvp), _lib.ptr(fb.loss_b), _lib.ptr(fb.K),
                                          _lib.ptr(fb.link_poses), _lib.ptr(fb.tc_jac), fb.B, fb.L, fb.H, fb.W,
@@ -117,7 +118,8 @@ def test_merged_step_equals_the_separate_kernels(xarm7, B, H, W, scale):
                                      _lib.ptr(fb.red), f(fb.lr), f(fb.betas[0]), f(fb.betas[1]), f(fb.eps), f(fb.wd),
                                      _lib.ptr(fb.loss), _lib.ptr(fb.grad), stream), "adam")
         torch.cuda.synchronize()
-        for name in ["mvp", "tc_jac", "loss_b", "grad_mvp", "red", "loss", "grad", "exp_avg", "exp_avg_sq", "step_t"]:
+        for name in ["mvp", "tc_jac", "loss_b", "grad_mvp", "red", "loss", "grad", "exp_avg", "exp_avg_sq", "step_t",
+                     "hist_row"]:
             assert torch.equal(getattr(fa, name), getattr(fb, name)), (it, name)
         assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(ma.history_ops[:8], mb.history_ops[:8])
     fused.check_status(fa.glctx)
@@ -179,3 +181,57 @@ def test_outputs_step_shares_the_optimiser_state(xarm7):
     torch.cuda.synchronize()
     assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(ta.fast.exp_avg, tb.fast.exp_avg)
     assert ta.global_steps == tb.global_steps == 9 and int(tb.fast.step_t) == 9
+
+
+def test_fresh_optimiser_on_a_loaded_model_is_adam_step_one(xarm7, tmp_path):
+    """A solver built on a model that already holds N history rows (the reference's load_model path, or a checkpoint
+    without an optimiser) starts a FRESH Adam: step count 0, zero moments -- the first update is lr * sign(g), exactly
+    what torch.optim.Adam does on the same gradient -- while the pose history keeps appending at row N.  (The launch
+    chain used to take N as Adam's step count: bias corrections of step N + 1 on zero moments, a 2.5-3x lr first update.)"""
+    from easyhec_amd.fast import FusedPoseStep
+    from easyhec_amd.trainer import RBSolverTrainer
+    cfg, make, batch = problem(xarm7, 2, 120, 160, 0.125)
+    t0 = RBSolverTrainer(cfg, make(), batch, fast=True)
+    for _ in range(40):
+        t0.step()
+    path = str(tmp_path / "m.pth")
+    t0.save(path)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    del ck["optimizer"]                                  # what the reference's load_model path sees
+    torch.save(ck, path)
+    hist40 = t0.model.history_ops[:40].clone()
+    # (a) FusedPoseStep on a loaded model
+    m = make()
+    m.load_state_dict(ck["model"])
+    fs = FusedPoseStep(m, batch)
+    assert int(fs.step_t) == 0 and int(fs.hist_row) == 40
+    dof0 = m.dof.detach().clone()
+    fs.step()
+    torch.cuda.synchronize()
+    g = fs.grad.clone()                                  # gradient of the mean loss at dof0 (before weight decay)
+    p = dof0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=fs.lr, betas=fs.betas, eps=fs.eps, weight_decay=fs.wd)
+    p.grad = g.clone()
+    opt.step()
+    assert (m.dof.detach() - p.detach()).abs().max() <= 1e-7
+    assert float((m.dof.detach() - dof0).abs().max()) <= fs.lr * 1.0001   # |first update| = lr, not 2.5-3 lr
+    assert int(fs.step_t) == 1 and int(fs.hist_row) == 41
+    assert torch.equal(m.history_ops[:40], hist40) and torch.equal(m.history_ops[40], dof0)
+    # (b) trainer.resume() on the optimiser-less checkpoint: same semantics
+    tr = RBSolverTrainer(cfg, make(), batch, fast=True)
+    tr.resume(path)
+    assert int(tr.fast.step_t) == 0 and int(tr.fast.hist_row) == 40 and float(tr.fast.exp_avg.abs().max()) == 0
+    tr.step()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.model.dof.detach(), m.dof.detach())
+    # (c) a loaded optimiser whose step count is smaller than the history cursor never overwrites history rows
+    ck2 = torch.load(path, map_location="cpu", weights_only=False)
+    ck2["optimizer"] = {"state": {0: {"step": torch.tensor(5.0), "exp_avg": torch.zeros(6), "exp_avg_sq": torch.zeros(6)}},
+                        "param_groups": []}
+    torch.save(ck2, path)
+    tr2 = RBSolverTrainer(cfg, make(), batch, fast=True)
+    tr2.resume(path)
+    assert int(tr2.fast.step_t) == 5 and int(tr2.fast.hist_row) == 40
+    tr2.step()
+    torch.cuda.synchronize()
+    assert torch.equal(tr2.model.history_ops[:40], hist40)

@@ -186,7 +186,6 @@ def test_overflow_is_reported_not_silent(env, oracle, xarm7):
     limits that remain (fixed-point accumulator range) still fail loudly: second half of the test."""
     fused, _, _, dev = env
     from easyhec_amd import dr
-    tile_chain = (os.environ.get("EHR_FUSED_PATH") or "v")[0] == "t"  # round-1 chain: its per-tile list still overflows
     H, W, L = 8, 32, 10
     vs, fs = [], []
     for l in range(L):
@@ -212,19 +211,25 @@ def test_overflow_is_reported_not_silent(env, oracle, xarm7):
     toff = np.cumsum([0] + [len(f) for f in fs]).astype(np.int32)
     tris = np.concatenate([f + voff[i] for i, f in enumerate(fs)]).astype(np.int32)
     m_ref, l_ref, g_ref = oracle.render_mask_loss(verts, tris, toff, voff, mvp_np, ref)
-    if tile_chain:
+    mask, loss, grad = run(fused, ctx2, scene, mvp_np, ref, dev)
+    assert (mask == m_ref).all()
+    assert np.abs(loss - l_ref).max() <= 1e-6 * np.abs(l_ref).max()
+    assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+    fused.check_status(ctx2)
+    # the same scene with a spill pool of 100 items (EHR_VB_SPILL_ITEMS, read at plan time): the jobs that do not fit
+    # report the overflow (NaN loss, raised status) and nothing is read or written outside the pool
+    os.environ["EHR_VB_SPILL_ITEMS"] = "100"
+    try:
+        ctx3 = dr.RasterizeCudaContext()
         tm = torch.tensor(mvp_np, device=dev, requires_grad=True)
-        _, loss_t = fused.render_mask_loss(ctx2, scene, tm, torch.tensor(ref, device=dev))
+        _, loss_t = fused.render_mask_loss(ctx3, scene, tm, torch.tensor(ref, device=dev))
+        loss_t.sum().backward()
         torch.cuda.synchronize()
-        assert torch.isnan(loss_t).all()
-        with pytest.raises(RuntimeError, match="overflow"):
-            fused.check_status(ctx2)
-    else:
-        mask, loss, grad = run(fused, ctx2, scene, mvp_np, ref, dev)
-        assert (mask == m_ref).all()
-        assert np.abs(loss - l_ref).max() <= 1e-6 * np.abs(l_ref).max()
-        assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
-        fused.check_status(ctx2)
+    finally:
+        del os.environ["EHR_VB_SPILL_ITEMS"]
+    assert torch.isnan(loss_t).all() and torch.isnan(tm.grad).all()
+    with pytest.raises(RuntimeError, match="overflow"):
+        fused.check_status(ctx3)
     # the fixed-point accumulators saturate loudly too: the robot scaled by 1e9 (and the clip matrices' first three
     # columns by 1e-9) renders the same picture, but its gradients w.r.t. the matrix entries exceed the representable
     # +-2^31 -> NaN gradient + raised status, never a wrapped sum
@@ -334,18 +339,55 @@ def test_fused_edge_cases(env, oracle, xarm7):
     assert abs(float(loss[0]) - float((mask.astype(np.float64) ** 2).sum())) <= 1e-6 * float(loss[0])
 
 
-@pytest.mark.gpu
 def test_plan_rejects_more_units_than_a_context_handles(env, xarm7):
-    """views x links above 512 on the default chain: an error that says so at plan time, not an out-of-bounds job table
-    (the round-1 tile chain has no such limit and keeps working)."""
+    """views x links above 512: an error that says so at plan time, not an out-of-bounds job table."""
     fused, ctx, scene, dev = env
-    import os
     from easyhec_amd import dr
     ctx2 = dr.RasterizeCudaContext()
     B, H, W = 65, 16, 32                                # 65 views x 8 links = 520 units
-    if (os.environ.get("EHR_FUSED_PATH") or "v")[0] == "t":
-        fused._ensure_plan(ctx2, scene, B, H, W)        # no limit on this chain
-        return
     with pytest.raises(RuntimeError, match="exceeds the 512"):
         fused._ensure_plan(ctx2, scene, B, H, W)
     fused._ensure_plan(ctx2, scene, 64, H, W)           # 512 units exactly: fine
+
+
+@pytest.mark.parametrize("H,W,scale,B", [(720, 1280, 1.0, 8), (100, 150, 0.12, 3)])
+def test_bound_reference_is_bit_identical(env, xarm7, H, W, scale, B):
+    """ehr_fused_bind_ref caches, per tile, the fixed-point sum(ref^2) the composite stage would add for a tile no link
+    touches; with it the stage only visits tiles inside the link boxes.  Integer sums: loss and gradient must equal the
+    unbound path BIT FOR BIT (random reference mask, so every tile has a non-trivial cached value), for several poses
+    against the same binding, and re-binding after the contents changed must pick up the new contents."""
+    fused, _, scene, dev = env
+    from easyhec_amd import dr
+    ctx = dr.RasterizeCudaContext()
+    rng = np.random.default_rng(W)
+    ref = torch.tensor(rng.uniform(size=(B, H, W)).astype(np.float32), device=dev)
+    outs = []
+    for seed in (1, 2):
+        K, lp, Tc, mvp = workload(xarm7, H, W, scale, B, seed=seed)
+        tm = torch.tensor(mvp, device=dev)
+        res = []
+        for bound in (False, True):
+            fused.bind_ref(ctx, scene, ref if bound else None)
+            loss = torch.empty((B,), device=dev)
+            grad = torch.empty((B, scene.num_links, 4, 4), device=dev)
+            fused._ensure_plan(ctx, scene, B, H, W)
+            fused._launch(ctx, scene, tm, ref, None, loss, grad)
+            torch.cuda.synchronize()
+            res.append((loss.clone(), grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert float(res[0][0].min()) > 0
+        outs.append(res[1][0])
+    assert not torch.equal(outs[0], outs[1])
+    # new contents + re-bind; and the mask-output form (always the full pass) agrees with both
+    ref2 = torch.tensor((rng.uniform(size=(B, H, W)) > 0.7).astype(np.float32), device=dev)
+    ref.copy_(ref2)
+    fused.bind_ref(ctx, scene, ref)
+    loss_b, loss_m = torch.empty((B,), device=dev), torch.empty((B,), device=dev)
+    mask = torch.empty((B, H, W), device=dev)
+    fused._launch(ctx, scene, tm, ref, None, loss_b, None)
+    fused._launch(ctx, scene, tm, ref, mask, loss_m, None)
+    torch.cuda.synchronize()
+    assert torch.equal(loss_b, loss_m)
+    sse = ((mask.double() - ref.double()) ** 2).sum(dim=(1, 2))
+    assert (loss_b.double() - sse).abs().max() <= 1e-6 * sse.max()
+    fused.check_status(ctx)
