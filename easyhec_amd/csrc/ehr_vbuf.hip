@@ -10,8 +10,8 @@
 // valid for every pose), and a step is four launches:
 //
 //   vb_vertex_kernel    [pose forward] + clip-space vertices (posc) + one wave per cluster: transforms the cluster's
-//                       triangles, snaps them, and publishes per triangle its pixel box (tbox), its raster record
-//                       (integer edge functions with the tie rule folded in, trec) and its clip-space vertices (tdep);
+//                       triangles, snaps them, and publishes per triangle its pixel box (tbox) and its raster record
+//                       (integer edge functions with the tie rule folded in, depth-range class; trec);
 //                       per cluster and per link the union of the boxes (cbox; lbox through integer atomics).
 //   vb_job_kernel       one WAVE per job = (view, link, 32x8 tile the link's box touches), persistent waves over a job
 //                       list that is never materialised.  A job culls cluster boxes, then triangle boxes, rasterizes the
@@ -44,10 +44,10 @@ constexpr int VB_RH = EHR_TILE_H + 2;
 constexpr int VB_RN = VB_RW * VB_RH;   // 340
 constexpr int VB_WORDS = (VB_RN + 63) / 64;  // 6 coverage words
 constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min y, max x, max y, padding to a 64-byte line
-constexpr int VB_HEAVY_T = 384;       // survivors from which a job counts as heavy (next step: a whole workgroup takes it);
-                                      // measured at 8 views: 224 -> 58.7 k (too many: the phase switches itself off), 320 -> 67.7 k,
-                                      // 384 -> 68.6 k, 448 -> 68.4 k, 512 -> 67.1 k, 640 -> 62.4 k frames/s
-constexpr int VB_HEAVY_CAP = 1024;    // heavy jobs remembered per step
+#define VB_HEAVY_T_DEFAULT 2500        // cost (4-pixel units walked + 256 per rasterizer round) from which a job counts as
+                                      // heavy: next step a whole workgroup takes it.  Units, not triangles: a tile of 130 long
+                                      // thin triangles (7000 units) keeps a wave busy for 60 us, one of 380 small ones for 25
+constexpr int VB_HEAVY_CAP = 4096;    // heavy jobs remembered per step
 constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
 constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
 constexpr u64 VB_EMPTY = ~0ull;
@@ -56,21 +56,18 @@ constexpr u64 VB_EMPTY = ~0ull;
 
 // Counters that many waves hit with atomics each get a 128-byte line of their own behind the meta block (atomics on
 // one line serialise memory-side at ~12 ns each): line xcd = job cursor of that XCD.
-#define VB_LINES 24   // 0-7 job cursors of the XCDs, 8-15 composite arrival tickets of the XCDs, 16 the top ticket
+#define VB_LINES 24   // 0-7 job cursors of the XCDs, 8-15 composite arrival tickets of the XCDs, 16 the top ticket, 17 jobs put aside for vb_slow_kernel
 __host__ __device__ __forceinline__ int* vb_line(int* meta, int k) {
     return (int*)((((uintptr_t)(meta + EHR_META_INTS)) + 127) & ~(uintptr_t)127) + 32 * k;
 }
 
 #define VB_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#ifdef VB_PHASE_TIMING  // profiling build only (-DVB_PHASE_TIMING): cycles per phase, kept per wave, summed at its end
-#define VB_PHASE(i)                                                          \
-    do {                                                                     \
-        const long long now_ = __builtin_readcyclecounter();                 \
-        ph_acc[i] += now_ - ph_last;                                         \
-        ph_last = __builtin_readcyclecounter();                              \
-    } while (0)
+#ifdef VB_TIMELINE
+#define VB_TL_BEGIN() const long long tl_t0_ = __builtin_readcyclecounter()
+#define VB_TL_END(S_, i) do { if (lane_id() == 0) (S_).tl_c[i] += __builtin_readcyclecounter() - tl_t0_; } while (0)
 #else
-#define VB_PHASE(i) do { } while (0)
+#define VB_TL_BEGIN() do { } while (0)
+#define VB_TL_END(S_, i) do { } while (0)
 #endif
 
 struct VbItem {
@@ -181,19 +178,43 @@ __device__ __forceinline__ VbEdges vb_edges(int X0, int Y0, int X1, int Y1, int 
     return r;
 }
 
-// Per-triangle raster record written by the cluster pass, read by the tile waves (so a triangle is set up once per
+// Per-triangle raster record written by the cluster pass, read by the job waves (so a triangle is set up once per
 // step, not once per tile it touches):
 //   trec[2 i]     = { e0, e1, e2, dX0 | dY0 << 16 }   edge functions (tie rule folded in) at the centre of the box's
-//   trec[2 i + 1] = { dX1 | dY1 << 16, dX2 | dY2 << 16, triangle id, kind }   first pixel; kind 0 = 32-bit fast path,
-//                                                      1 = needs clipping / 64-bit (handled from the vertices)
-//   tdep[3 i ..]  = the three clip-space vertices (depth is evaluated from them per covered pixel)
+//   trec[2 i + 1] = { dX1 | dY1 << 16, dX2 | dY2 << 16, triangle id, kind }   first pixel; kind 0 = 32-bit fast path and
+//                   every coverable pixel passes the depth-range test, 2 = fast path but the depth range must be tested
+//                   per pixel, 1 = needs clipping / 64-bit (handled from the vertices)
+// Depth is evaluated from the clip-space vertices (posc) of the few units that need it.
 struct VbRecs {
     uint2* tbox;   // [B][NC][64] pixel box, VB_BOX_EMPTY if the triangle cannot cover a pixel centre
     uint2* cbox;   // [B][NC] union over the cluster
     int4* trec;    // [2][B][NC][64]: component-major, so that consecutive slots read consecutive 16-byte words
-    float4* tdep;  // [3][B][NC][64]
     size_t n;      // B * NC * 64 (component stride)
 };
+
+// True if every pixel centre the triangle's SNAPPED outline can cover evaluates to a depth z/w inside [-1, 1] in
+// vb_depth_test's arithmetic, so that coverage = the integer edge test alone.  All w > 0 (no near-plane crossing).
+// z/w is affine over the screen; a covered pixel centre lies within 1/32 pixel (per axis) of the unsnapped triangle, and
+// the float evaluation perturbs the barycentric weights by at most ~5e-5 pixel / thickness.  Hence: depth of the
+// vertices, widened by the depth gradient over 0.6 sixteenth-pixels and by a quarter of the depth range, must stay
+// 1e-5 inside the planes; thickness (2 area / longest edge) at least 0.05 sixteenth-pixels; w within a factor 4.
+// Everything else -- NaNs included -- is "unsafe" and gets the exact per-pixel test.  For a robot in front of the
+// camera (z/w = 0.998 at 1 m with near 1 mm, far 10 m; depth range of a triangle ~1e-5) only edge-on slivers fail.
+__device__ __forceinline__ bool vb_depth_safe(const float4& p0, const float4& p1, const float4& p2, int W, int H) {
+    const float z0 = p0.z / p0.w, z1 = p1.z / p1.w, z2 = p2.z / p2.w;
+    const float sx = (float)(8 * W), sy = (float)(8 * H);
+    const float x0 = p0.x / p0.w * sx, y0 = p0.y / p0.w * sy;
+    const float d1x = p1.x / p1.w * sx - x0, d1y = p1.y / p1.w * sy - y0;
+    const float d2x = p2.x / p2.w * sx - x0, d2y = p2.y / p2.w * sy - y0;
+    const float q1 = fabsf(z1 - z0), q2 = fabsf(z2 - z0);
+    const float A = fabsf(d1x * d2y - d2x * d1y);
+    const float l1 = fabsf(d1x) + fabsf(d1y), l2 = fabsf(d2x) + fabsf(d2y);
+    const float delta = 0.6f * (q1 * l2 + q2 * l1) / A + 0.25f * (q1 + q2);
+    const float zmax = fmaxf(z0, fmaxf(z1, z2)), zmin = fminf(z0, fminf(z1, z2));
+    const float wmax = fmaxf(p0.w, fmaxf(p1.w, p2.w)), wmin = fminf(p0.w, fminf(p1.w, p2.w));
+    return (A >= 0.05f * (l1 + l2) + 1e-3f) && (wmax <= 4.f * wmin) && (zmax + delta <= 1.f - 1e-5f) &&
+           (zmin - delta >= -1.f + 1e-5f);
+}
 
 template <bool HEAD>
 __global__ void __launch_bounds__(256)
@@ -325,11 +346,10 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     const bool cvalid = c < cl.NC;
     int x0 = 0xffff, y0 = 0xffff, x1 = 0, y1 = 0;  // empty (overlaps nothing)
     int4 r0 = make_int4(-1, -1, -1, 0), r1 = make_int4(0, 0, t, 0);
-    float4 p0 = make_float4(0.f, 0.f, 0.f, -1.f), p1 = p0, p2 = p0;
     if (have && lv) {
-        p0 = transform_vertex(M[l], vx[0], vy[0], vz[0]);
-        p1 = transform_vertex(M[l], vx[1], vy[1], vz[1]);
-        p2 = transform_vertex(M[l], vx[2], vy[2], vz[2]);
+        const float4 p0 = transform_vertex(M[l], vx[0], vy[0], vz[0]);
+        const float4 p1 = transform_vertex(M[l], vx[1], vy[1], vz[1]);
+        const float4 p2 = transform_vertex(M[l], vx[2], vy[2], vz[2]);
         const bool simple = (p0.w > 0.f) && (p1.w > 0.f) && (p2.w > 0.f) && (p0.z + p0.w >= 0.f) &&
                             (p1.z + p1.w >= 0.f) && (p2.z + p2.w >= 0.f);
         if (!simple) {  // crosses the near plane: the pixel box of its clipped pieces (the whole-wave path draws it)
@@ -359,6 +379,7 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
                     r0 = make_int4(ed.e0, ed.e1, ed.e2, (int)(((unsigned)(ed.sy0 / 16) & 0xffffu) | ((unsigned)(-ed.sx0 / 16) << 16)));
                     r1.x = (int)(((unsigned)(ed.sy1 / 16) & 0xffffu) | ((unsigned)(-ed.sx1 / 16) << 16));
                     r1.y = (int)(((unsigned)(ed.sy2 / 16) & 0xffffu) | ((unsigned)(-ed.sx2 / 16) << 16));
+                    r1.w = vb_depth_safe(p0, p1, p2, W, H) ? 0 : 2;
                 }
             }
         }
@@ -368,9 +389,6 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     if (cvalid && x0 <= x1) {
         rc.trec[slot] = r0;
         rc.trec[rc.n + slot] = r1;
-        rc.tdep[slot] = p0;
-        rc.tdep[rc.n + slot] = p1;
-        rc.tdep[2 * rc.n + slot] = p2;
     }
     const bool ne = x0 <= x1;
     int a = ne ? x0 : INT_MAX, bq = ne ? y0 : INT_MAX, cc = ne ? x1 : -1, d = ne ? y1 : -1;
@@ -421,16 +439,83 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     }
 }
 
-// ---- stage 2: one wave per tile: cull, rasterize into LDS, resolve --------------------------------------------------
+// ---- stage 2: one wave per job: cull, coverage into LDS, depth only where the silhouette analysis will look ---------
 
 struct VbRegion {
     int x0, y0, x1, y1;  // pixels of the region inside the image (inclusive); region origin = (rx0, ry0) below
 };
 
-// General path, whole wave per triangle, wave-uniform arguments: near-plane clipping, 64-bit edge functions.  Rare
-// (triangles crossing the near plane or spanning more than 512 pixels).
-__device__ __noinline__ void vb_raster_wide(float4 pa, float4 pb, float4 pc, int t, int W, int H, VbRegion rg, int rx0,
-                                            int ry0, u64* key) {
+// What stage 2 has to leave behind for a (view, link, region) is (a) which region pixels the link covers and (b) the
+// nearest triangle at those covered pixels that have an uncovered 4-neighbour: only pairs of one covered and one
+// uncovered pixel reach the silhouette analysis (with constant colour inside a link a blend between two covered pixels
+// is alpha * (1 - 1) = 0 in value and in gradient), and the analysis looks at the covered pixel's triangle.  So the
+// rasterizer works COVERAGE FIRST: the walker ORs 4-pixel coverage masks into a bitmap (one 64-bit word per region row)
+// and appends the covered units to a deferred list; when the job's coverage is complete (or the list is full) the
+// list is filtered against the pixels that can still matter and only the survivors -- typically a sixth of the
+// fragments -- are depth tested (one IEEE division per pixel, a 64-bit LDS atomic min each).  Filtering against a PARTIAL
+// coverage is conservative: a pixel that is interior to the partial coverage stays interior, so what a partial flush
+// drops could never have been looked at.
+//
+// A covered pixel is only drawn if its depth z/w lies in [-1, 1] (depth_test_write in ehr_raster_core.h, the oracle's
+// z-buffer loop): the vertex kernel marks a triangle SAFE (kind 0) when that holds for every pixel centre its snapped
+// outline can cover -- vertex depths away from the planes by more than the plane's screen-space depth gradient over the
+// snapping distance plus the evaluation's rounding (see vb_depth_safe) -- which is every triangle of a robot in front
+// of the camera.  The others (kind 2: edge-on slivers, geometry at the far plane) take the same walker, but their
+// units do not enter the bitmap: they are always depth tested, and a pixel that passes sets its coverage bit then.
+constexpr int VB_DL = 768;             // deferred units per wave (LDS); a full list is flushed against the partial coverage
+constexpr unsigned VB_ID_COVERED = 0xfffffffeu;  // published id of a covered pixel whose triangle nobody will ask for
+constexpr u64 VB_ROW_MASK = (1ull << VB_RW) - 1ull;
+
+struct alignas(16) VbRaster {  // staging area of one rasterizer round (64 candidate triangles)
+    int e[64][3];          // edge functions at the first pixel of the job's box inside the region
+    unsigned dxy[64][3];   // dX | dY << 16 of the three edges
+    unsigned box[64];      // box inside the region: x0 | y0 << 8 | w << 16 | h << 24 (region-relative)
+    unsigned ent[64];      // deferred-list entry of this triangle without pixel and mask: flag << 13 | link-relative slot << 14
+    int pre[65];           // exclusive prefix of the jobs' work units (+ total)
+};
+struct alignas(16) VbWaveLds {   // per wave of the job kernel
+    u64 key[VB_RN];              // depth/id of the region's pixels: ordered(z/w) << 32 | triangle, all-ones = never tested
+    u64 cov[VB_RH];              // coverage bitmap, one word per region row (bit x = region column x)
+    u64 need[VB_RH];             // flush: covered pixels with an uncovered 4-neighbour
+    u64 intr[VB_RH];             // rounds: covered pixels whose four neighbours are covered too (as of the round's start)
+    VbRaster R;
+    unsigned dl[VB_DL];          // deferred units: pixel (9 bits) | 4-bit coverage << 9 | R.ent
+    unsigned sq[128];            // survivors of the box culling waiting for a full round: record slots (ring)
+#ifdef VB_TIMELINE
+    int tl_units, tl_rounds;     // profiling build: 4-pixel units walked / rounds run by this wave
+    int tl_flushes, tl_tested, tl_deferred;
+    long long tl_c[4];           // cycles: staging, prefix + search, walk, flush
+#endif
+};
+
+// z/w at the centre of pixel (ix, iy) from the triangle's clip-space vertices, the oracle's arithmetic
+// (depth_test_write); true if the pixel is drawn (depth inside [-1, 1]), and then the z-buffer is updated.
+__device__ __forceinline__ bool vb_depth_test(const float4 p[3], int t, int ix, int iy, int W, int H, u64* slot) {
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    const float fx = (float)ix * xs + xo;
+    const float fy = (float)iy * ys + yo;
+    float a0, a1, a2;
+    eval_pixel(p, fx, fy, a0, a1, a2);
+    const float zw = eval_zw(p, a0, a1, a2);
+    if (zw >= -1.f && zw <= 1.f) {
+        atomicMin(slot, ((u64)ord_key(zw) << 32) | (unsigned)t);
+        return true;
+    }
+    return false;
+}
+
+// Static per-cluster-slot table (plan time): the three vertex ids and the triangle id of every cluster slot, so that a
+// deferred unit finds its clip-space vertices (posc) with one 16-byte gather + three.
+struct VbSlotIdx {
+    const int4* cvidx;  // [NC * 64] {v0, v1, v2, triangle}; padding slots hold {0, 0, 0, -1}
+};
+
+// General path, whole wave per triangle, wave-uniform arguments: near-plane clipping, 64-bit edge functions, immediate
+// depth test.  Rare (triangles crossing the near plane or spanning more than 512 pixels); only compiled into
+// vb_job_slow, which redoes a job in which the lean code met such a triangle.
+__device__ __forceinline__ void vb_raster_wide(float4 pa, float4 pb, float4 pc, int t, int W, int H, VbRegion rg, int rx0,
+                                            int ry0, u64* key, u64* cov) {
     const int lane = lane_id();
     const float4 p[3] = {pa, pb, pc};
     const ClipPoly c = clip_near_poly(p);
@@ -451,66 +536,123 @@ __device__ __noinline__ void vb_raster_wide(float4 pa, float4 pb, float4 pc, int
                 const i64 e2 = ee.e[2] + dx * ee.sx[2] + dy * ee.sy[2];
                 if ((e0 | e1 | e2) >= 0) {
                     const int ix = bx0 + dx, iy = by0 + dy;
-                    depth_test_write(p, t, ix, iy, W, H, &key[(iy - ry0) * VB_RW + (ix - rx0)]);
+                    if (vb_depth_test(p, t, ix, iy, W, H, &key[(iy - ry0) * VB_RW + (ix - rx0)]))
+                        atomicOr((unsigned long long*)&cov[iy - ry0], 1ull << (ix - rx0));
                 }
             }
         }
     }
 }
 
-// LDS scratch of the wave-level balanced rasterizer (aliases the blend-weight / hit arrays, which are only live
-// after a link's coverage is complete).
-struct alignas(16) VbRaster {
-    float4 pf[64][3];      // clip-space vertices of the staged jobs (depth)
-    int e[64][3];          // edge functions at the first pixel of the job's box inside the region
-    unsigned dxy[64][3];   // dX | dY << 16 of the three edges
-    unsigned box[64];      // box inside the region: x0 | y0 << 8 | w << 16 | h << 24 (region-relative)
-    int tri[64];
-    int pre[65];           // exclusive prefix of the jobs' work units (+ total)
-    unsigned ring[128];    // covered units waiting for their depth test: first pixel | 4-bit coverage << 12 | job << 16
-};
-
-// Depth-test `n` (<= 64) ring entries, one per lane.  An entry is a run of up to 4 horizontally adjacent pixels of one
-// staged job.
-__device__ __forceinline__ void vb_drain(VbRaster& R, int head, int n, int W, int H, int rx0, int ry0, u64* key) {
+// Flush of the deferred list (n entries): the pixels that can still matter under the CURRENT coverage (`cov`, complete
+// or partial; shared by the four waves of a workgroup in the heavy-job phase) are the covered ones with an uncovered
+// 4-neighbour inside the region; entries that touch none of them are dropped, the others are depth tested at exactly
+// those pixels.  Units of unsafe triangles (flag) are always tested, at all their pixels, and set their coverage bits.
+__device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n, const float4* __restrict__ pv,
+                                      const int4* __restrict__ cvidx_link, int W, int H, int rx0, int ry0) {
     const int lane = lane_id();
-    if (lane < n) {
-        const unsigned f = R.ring[(head + lane) & 127];
-        const int pix = f & 0xfffu, j = f >> 16;
-        const unsigned m4 = (f >> 12) & 15u;
-        const float4 p[3] = {R.pf[j][0], R.pf[j][1], R.pf[j][2]};
-        const int t = R.tri[j];
-        const int py = pix / VB_RW, px = pix - py * VB_RW;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (m4 & (1u << i)) depth_test_write(p, t, rx0 + px + i, ry0 + py, W, H, &key[pix + i]);
+    VB_TL_BEGIN();
+    VB_WAVE_SYNC();
+    if (lane < VB_RH) {
+        const u64 c = cov[lane];
+        const u64 up = (lane + 1 < VB_RH) ? cov[lane + 1] : VB_ROW_MASK;
+        const u64 dn = (lane > 0) ? cov[lane - 1] : VB_ROW_MASK;
+        // neighbour x + 1 is bit x of c >> 1, neighbour x - 1 bit x of c << 1; past the region's edge counts as covered
+        const u64 inner = ((c >> 1) | (1ull << (VB_RW - 1))) & ((c << 1) | 1ull) & up & dn;
+        S.need[lane] = c & ~inner & VB_ROW_MASK;
     }
+    VB_WAVE_SYNC();
+    int nk = 0;  // wave-uniform
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        unsigned e = 0;
+        bool keep = false;
+        if (i < n) {
+            e = S.dl[i];
+            const int pix = e & 511u, row = pix / VB_RW, col = pix - row * VB_RW;
+            const unsigned m4 = (e >> 9) & 15u;
+            const unsigned m = (e & (1u << 13)) ? m4 : (m4 & (unsigned)(S.need[row] >> col));
+            keep = m != 0;
+            e = (e & ~(15u << 9)) | (m << 9);
+        }
+        const u64 km = __ballot(keep);
+        if (keep) S.dl[nk + vb_mbcnt(km)] = e;  // in place: nk <= base, and this round's reads are done
+        nk += __popcll(km);
+    }
+    VB_WAVE_SYNC();
+    for (int base = 0; base < nk; base += 64) {
+        const int i = base + lane;
+        if (i < nk) {
+            const unsigned e = S.dl[i];
+            const int4 vi = cvidx_link[e >> 14];
+            const float4 p[3] = {pv[vi.x], pv[vi.y], pv[vi.z]};
+            const int pix = e & 511u, row = pix / VB_RW, col = pix - row * VB_RW;
+            const unsigned m = (e >> 9) & 15u;
+            const bool flag = (e >> 13) & 1u;
+            unsigned drawn = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (m & (1u << k))
+                    if (vb_depth_test(p, vi.w, rx0 + col + k, ry0 + row, W, H, &key[pix + k])) drawn |= 1u << k;
+            if (flag && drawn) atomicOr((unsigned long long*)&cov[row], (u64)drawn << col);
+        }
+    }
+    VB_WAVE_SYNC();
+#ifdef VB_TIMELINE
+    if (lane == 0) {
+        S.tl_flushes += 1;
+        S.tl_tested += nk;
+        S.tl_deferred += n;
+    }
+#endif
+    VB_TL_END(S, 3);
 }
 
-// One round of the wave-level rasterizer: up to 64 candidate triangles (lane `sv` holds one, described by its pixel
-// box `bx` and record slot) are rasterized into the region's LDS depth/id buffer -- ds_min_u64 on
-// ordered(z/w) << 32 | triangle, which is order independent, so the result is the oracle's nearest-wins /
-// lowest-index-wins z-buffer bit for bit.  The triangles' boxes (clamped to the region) are cut into units of 4
-// horizontally adjacent pixels; a wave-wide prefix sum splits the concatenated unit sequence EVENLY over the 64 lanes
-// (a third of the candidates have boxes above 16 pixels, so one lane per triangle would leave most lanes idle), each
-// lane walks its contiguous run stepping 32-bit edge functions, covered units are compacted through an LDS ring with
-// ballot/popcount and depth-tested 64 at a time.  Same scheme as round 1's block-wide raster_queue, at wave scope (no
-// workgroup barriers) and fed by the per-triangle records of the cluster pass instead of a per-tile setup.
-__device__ __forceinline__ void vb_raster_round(bool sv, size_t slot, const VbRecs& rc, const VbRegion& rg,
-                                                int rx0, int ry0, int W, int H, VbRaster& R, u64* key,
-                                                long long* ph_acc, long long& ph_last) {
+// One round of the wave-level rasterizer: up to 64 candidate triangles (lane `sv` holds one: record slot `slot` of the
+// view, `srel` the same relative to the link's first cluster slot) are rasterized into the job's coverage bitmap and
+// their covered 4-pixel units appended to the wave's deferred list (n entries on entry; returns the new count).  The
+// triangles' boxes (clamped to the region) are cut into units of 4 horizontally adjacent pixels; a wave-wide prefix sum
+// splits the concatenated unit sequence EVENLY over the 64 lanes (a third of the candidates have boxes above 16
+// pixels, so one lane per triangle would leave most lanes idle) and each lane walks its contiguous run stepping 32-bit
+// edge functions.  Fed by the per-triangle records of the vertex kernel; nothing but LDS is touched inside the walk.
+template <bool WIDE>
+__device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned srel, const VbRecs& rc, const VbRegion& rg,
+                                               int rx0, int ry0, int W, int H, VbWaveLds& S, u64* key, u64* cov, int n,
+                                               const float4* __restrict__ pv, const int4* __restrict__ cvidx_link, bool& full,
+                                               int& cost) {
+    VbRaster& R = S.R;
     const int lane = lane_id();
-    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    (void)ph_acc;
-    (void)ph_last;
+    VB_TL_BEGIN();
     int units = 0;
     bool wide = false;
+    uint2 bx = VB_BOX_EMPTY;
+    int4 r0 = make_int4(0, 0, 0, 0), r1 = r0;
     if (sv) {
-        const uint2 bx = rc.tbox[slot];
-        const int4 r0 = rc.trec[slot], r1 = rc.trec[rc.n + slot];
-        const float4 q0 = rc.tdep[slot], q1 = rc.tdep[rc.n + slot], q2 = rc.tdep[2 * rc.n + slot];
-        const int tid_tri = r1.z;
-        if (r1.w != 0) {
+        bx = rc.tbox[slot];
+        r0 = rc.trec[slot];
+        r1 = rc.trec[rc.n + slot];
+    }
+    // Interior of the coverage so far: covered pixels whose four neighbours (inside the region) are covered too.  Nobody
+    // will ever ask which triangle is visible there, and coverage cannot change there: a triangle whose box lies inside
+    // the interior is skipped, units inside it are not deferred, and a region that is all interior ends the job (the
+    // inner tiles of a link seen from close by: a few large triangles cover everything, the other layers add nothing).
+    {
+        u64 in = 0;
+        if (lane < VB_RH) {
+            const u64 c = cov[lane];
+            const u64 up = (lane + 1 < VB_RH) ? cov[lane + 1] : VB_ROW_MASK;
+            const u64 dn = (lane > 0) ? cov[lane - 1] : VB_ROW_MASK;
+            in = c & ((c >> 1) | (1ull << (VB_RW - 1))) & ((c << 1) | 1ull) & up & dn & VB_ROW_MASK;
+            S.intr[lane] = in;
+        }
+        if (__ballot(lane < VB_RH && in != VB_ROW_MASK) == 0) {
+            full = true;
+            return n;
+        }
+        VB_WAVE_SYNC();
+    }
+    if (sv) {
+        if (r1.w == 1) {
             wide = true;
         } else {
             const int ix0 = bx.x & 0xffffu, iy0 = bx.x >> 16, ix1 = bx.y & 0xffffu, iy1 = bx.y >> 16;
@@ -526,28 +668,42 @@ __device__ __forceinline__ void vb_raster_round(bool sv, size_t slot, const VbRe
                 R.dxy[lane][k] = w[k];
             }
             R.box[lane] = (unsigned)(cx0 - rx0) | ((unsigned)(cy0 - ry0) << 8) | ((unsigned)bw << 16) | ((unsigned)bh << 24);
-            R.tri[lane] = tid_tri;
-            R.pf[lane][0] = q0;
-            R.pf[lane][1] = q1;
-            R.pf[lane][2] = q2;
-            units = ((bw + 3) >> 2) * bh;
+            R.ent[lane] = (srel << 14) | ((r1.w == 2) ? (1u << 13) : 0u);
+            const u64 bm = ((1ull << bw) - 1ull) << (cx0 - rx0);
+            bool hidden = true;
+#pragma unroll
+            for (int r = 0; r < VB_RH; r++) {
+                const bool mine = (unsigned)(r - (cy0 - ry0)) < (unsigned)bh;
+                hidden = hidden && (!mine || (S.intr[r] & bm) == bm);
+            }
+            units = hidden ? 0 : ((bw + 3) >> 2) * bh;
         }
     }
-    VB_PHASE(2);  // record loads + staging
+    if (!WIDE && __ballot(wide)) return -1;  // the lean instantiation hands the whole job to vb_job_slow
     int incl = units;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(incl, o, 64);
         if (lane >= o) incl += v;
     }
-    const int S = vb_readlane(incl, 63);
-    if (S > 0) {
+    const int Stot = vb_readlane(incl, 63);
+    cost += Stot + 256;  // what the job costs a wave: a step per 64 units, and about four steps' worth per round
+#ifdef VB_TIMELINE
+    if (lane == 0) {
+        S.tl_units += Stot;
+        S.tl_rounds += 1;
+    }
+#endif
+    VB_TL_END(S, 0);
+    if (Stot > 0) {
+        VB_TL_BEGIN();
         R.pre[lane] = incl - units;
-        if (lane == 63) R.pre[64] = S;
+        if (lane == 63) R.pre[64] = Stot;
         VB_WAVE_SYNC();
-        const int K = (S + 63) >> 6;
-        const int start = lane * K, end = min(start + K, S);
-        int j = 0, bw = 1, bh = 1, gw = 1, gx = 0, dy = 0, pix = 0, rowpix = 0;
+        const int K = (Stot + 63) >> 6;
+        const int start = lane * K, end = min(start + K, Stot);
+        int j = 0, bw = 1, bh = 1, gw = 1, gx = 0, dy = 0, crow = 0, ccol0 = 0;
+        unsigned eb = 0;
         int e0 = -1, e1 = -1, e2 = -1, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0, er0 = 0, er1 = 0, er2 = 0;
         if (start < end) {
             int lo = 0, hi = 63;
@@ -561,10 +717,12 @@ __device__ __forceinline__ void vb_raster_round(bool sv, size_t slot, const VbRe
             }
             j = lo;
             const unsigned b4 = R.box[j];
-            const int x0r = b4 & 255, y0r = (b4 >> 8) & 255;
+            ccol0 = b4 & 255;
+            const int y0r = (b4 >> 8) & 255;
             bw = (b4 >> 16) & 255;
             bh = b4 >> 24;
             gw = (bw + 3) >> 2;
+            eb = R.ent[j];
             const unsigned w0 = R.dxy[j][0], w1 = R.dxy[j][1], w2 = R.dxy[j][2];
             sx0 = -16 * (int)(short)(w0 >> 16); sy0 = 16 * (int)(short)(w0 & 0xffffu);
             sx1 = -16 * (int)(short)(w1 >> 16); sy1 = 16 * (int)(short)(w1 & 0xffffu);
@@ -578,103 +736,108 @@ __device__ __forceinline__ void vb_raster_round(bool sv, size_t slot, const VbRe
             e0 = er0 + 4 * gx * sx0;
             e1 = er1 + 4 * gx * sx1;
             e2 = er2 + 4 * gx * sx2;
-            rowpix = (y0r + dy) * VB_RW + x0r;
-            pix = rowpix + 4 * gx;
+            crow = y0r + dy;
         }
-        int qhead = 0, qcount = 0;
-        VB_PHASE(3);  // prefix + search
+        VB_TL_END(S, 1);
+        const long long tl_w0 = __builtin_readcyclecounter();
+        (void)tl_w0;
+        for (int it0 = 0; it0 < K;) {
+            // the deferred list takes at most 64 entries per step: walk as many steps as it has room for
+            const int room = (VB_DL - n) >> 6;
+            if (room == 0) {
+                vb_flush(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
+                n = 0;
+                continue;
+            }
+            const int it1 = min(K, it0 + room);
 #pragma nounroll
-        for (int it = 0; it < K; it++) {
-            const bool act = start + it < end;
-            unsigned m4 = 0;
-            if (act) {
-                const int a1 = e0 + sx0, a2 = a1 + sx0, a3 = a2 + sx0;
-                const int b1 = e1 + sx1, b2 = b1 + sx1, b3 = b2 + sx1;
-                const int c1 = e2 + sx2, c2 = c1 + sx2, c3 = c2 + sx2;
-                m4 = ((e0 | e1 | e2) >= 0 ? 1u : 0u) | ((a1 | b1 | c1) >= 0 ? 2u : 0u) | ((a2 | b2 | c2) >= 0 ? 4u : 0u) |
-                     ((a3 | b3 | c3) >= 0 ? 8u : 0u);
-                const int rem = bw - 4 * gx;  // pixels of this unit that lie inside the box
-                if (rem < 4) m4 &= (1u << rem) - 1u;
-            }
-            const bool inside = m4 != 0;
-            const u64 m = __ballot(inside);
-            if (m) {
-                if (inside) R.ring[(qhead + qcount + __popcll(m & lt)) & 127] = (unsigned)pix | (m4 << 12) | ((unsigned)j << 16);
-                qcount += __popcll(m);
-                if (qcount >= 64) {
-                    VB_WAVE_SYNC();
-                    vb_drain(R, qhead, 64, W, H, rx0, ry0, key);
-                    qhead = (qhead + 64) & 127;
-                    qcount -= 64;
+            for (int it = it0; it < it1; it++) {
+                const bool act = start + it < end;
+                unsigned m4 = 0;
+                if (act) {
+                    const int a1 = e0 + sx0, a2 = a1 + sx0, a3 = a2 + sx0;
+                    const int b1 = e1 + sx1, b2 = b1 + sx1, b3 = b2 + sx1;
+                    const int c1 = e2 + sx2, c2 = c1 + sx2, c3 = c2 + sx2;
+                    m4 = ((e0 | e1 | e2) >= 0 ? 1u : 0u) | ((a1 | b1 | c1) >= 0 ? 2u : 0u) | ((a2 | b2 | c2) >= 0 ? 4u : 0u) |
+                         ((a3 | b3 | c3) >= 0 ? 8u : 0u);
+                    const int rem = bw - 4 * gx;  // pixels of this unit that lie inside the box
+                    if (rem < 4) m4 &= (1u << rem) - 1u;
                 }
-            }
-            if (act && start + it + 1 < end) {
-                gx++;
-                pix += 4;
-                e0 += 4 * sx0;
-                e1 += 4 * sx1;
-                e2 += 4 * sx2;
-                if (gx == gw) {
-                    gx = 0;
-                    dy++;
-                    rowpix += VB_RW;
-                    pix = rowpix;
-                    er0 += sy0;
-                    er1 += sy1;
-                    er2 += sy2;
-                    e0 = er0;
-                    e1 = er1;
-                    e2 = er2;
-                    if (dy == bh) {  // next job with a non-empty box
-                        do {
-                            j++;
-                        } while (R.pre[j + 1] == R.pre[j]);
-                        const unsigned b4 = R.box[j];
-                        const int x0r = b4 & 255, y0r = (b4 >> 8) & 255;
-                        bw = (b4 >> 16) & 255;
-                        bh = b4 >> 24;
-                        gw = (bw + 3) >> 2;
-                        const unsigned w0 = R.dxy[j][0], w1 = R.dxy[j][1], w2 = R.dxy[j][2];
-                        sx0 = -16 * (int)(short)(w0 >> 16); sy0 = 16 * (int)(short)(w0 & 0xffffu);
-                        sx1 = -16 * (int)(short)(w1 >> 16); sy1 = 16 * (int)(short)(w1 & 0xffffu);
-                        sx2 = -16 * (int)(short)(w2 >> 16); sy2 = 16 * (int)(short)(w2 & 0xffffu);
-                        er0 = e0 = R.e[j][0];
-                        er1 = e1 = R.e[j][1];
-                        er2 = e2 = R.e[j][2];
-                        dy = 0;
-                        rowpix = y0r * VB_RW + x0r;
-                        pix = rowpix;
+                const bool inside = m4 != 0;
+                const u64 m = __ballot(inside);
+                if (m) {
+                    // deferred for a depth test: the unit's covered pixels outside the interior (as of the round's start)
+                    unsigned md = 0;
+                    if (inside) {
+                        const int ccol = ccol0 + 4 * gx;
+                        if (!(eb & (1u << 13))) atomicOr((unsigned long long*)&cov[crow], (u64)m4 << ccol);
+                        md = m4 & ~(unsigned)(S.intr[crow] >> ccol);
+                    }
+                    const u64 ma = __ballot(md != 0);
+                    if (md) S.dl[n + vb_mbcnt(ma)] = eb | (unsigned)(crow * VB_RW + ccol0 + 4 * gx) | (md << 9);
+                    n += __popcll(ma);
+                }
+                if (act && start + it + 1 < end) {
+                    gx++;
+                    e0 += 4 * sx0;
+                    e1 += 4 * sx1;
+                    e2 += 4 * sx2;
+                    if (gx == gw) {
+                        gx = 0;
+                        dy++;
+                        crow++;
+                        er0 += sy0;
+                        er1 += sy1;
+                        er2 += sy2;
+                        e0 = er0;
+                        e1 = er1;
+                        e2 = er2;
+                        if (dy == bh) {  // next job with a non-empty box
+                            do {
+                                j++;
+                            } while (R.pre[j + 1] == R.pre[j]);
+                            const unsigned b4 = R.box[j];
+                            ccol0 = b4 & 255;
+                            crow = (b4 >> 8) & 255;
+                            bw = (b4 >> 16) & 255;
+                            bh = b4 >> 24;
+                            gw = (bw + 3) >> 2;
+                            eb = R.ent[j];
+                            const unsigned w0 = R.dxy[j][0], w1 = R.dxy[j][1], w2 = R.dxy[j][2];
+                            sx0 = -16 * (int)(short)(w0 >> 16); sy0 = 16 * (int)(short)(w0 & 0xffffu);
+                            sx1 = -16 * (int)(short)(w1 >> 16); sy1 = 16 * (int)(short)(w1 & 0xffffu);
+                            sx2 = -16 * (int)(short)(w2 >> 16); sy2 = 16 * (int)(short)(w2 & 0xffffu);
+                            er0 = e0 = R.e[j][0];
+                            er1 = e1 = R.e[j][1];
+                            er2 = e2 = R.e[j][2];
+                            dy = 0;
+                        }
                     }
                 }
             }
-        }
-        if (qcount) {
-            VB_WAVE_SYNC();
-            vb_drain(R, qhead, qcount, W, H, rx0, ry0, key);
+            it0 = it1;
         }
         VB_WAVE_SYNC();  // the staging area is rewritten by the next round
-        VB_PHASE(4);  // walk + depth
+#ifdef VB_TIMELINE
+        if (lane == 0) S.tl_c[2] += __builtin_readcyclecounter() - tl_w0;
+#endif
     }
-    u64 wm = __ballot(wide);  // rare: near-plane clipping / very large extents, one triangle at a time
-    while (wm) {
-        const int s = __ffsll((unsigned long long)wm) - 1;
-        wm &= wm - 1;
-        const unsigned wl = vb_readlane((int)(unsigned)(slot & 0xffffffffu), s), wh = vb_readlane((int)(unsigned)(slot >> 32), s);
-        const size_t ws = ((size_t)wh << 32) | wl;
-        vb_raster_wide(rc.tdep[ws], rc.tdep[rc.n + ws], rc.tdep[2 * rc.n + ws], rc.trec[rc.n + ws].z, W, H, rg, rx0, ry0,
-                       key);
+    if (WIDE) {  // rare: near-plane clipping / very large extents, one triangle at a time, depth tested at once
+        u64 wm = __ballot(wide);
+        while (wm) {
+            const int s = __ffsll((unsigned long long)wm) - 1;
+            wm &= wm - 1;
+            const int4 vi = cvidx_link[vb_readlane((int)srel, s)];
+            vb_raster_wide(pv[vi.x], pv[vi.y], pv[vi.z], vi.w, W, H, rg, rx0, ry0, key, cov);
+        }
     }
+    return n;
 }
 
 struct alignas(16) VbResolveLds {  // per wave of the resolve kernel
     unsigned ids[VB_RN];         // triangle id of each region pixel (all-ones = uncovered), copied from the job's slot
     float pairA[2 * VB_RN];      // blend weight of pair (q, d) at [d * RN + q]
     unsigned short hits[2 * VB_RN];
-};
-struct alignas(16) VbWaveLds {   // per wave of the job kernel
-    u64 key[VB_RN];              // depth/id of each region pixel: ordered(z/w) << 32 | triangle, all-ones = uncovered
-    VbRaster R;                  // staging area of the rasterizer rounds
-    unsigned sq[128];            // survivors of the box culling waiting for a full round: record slots (ring)
 };
 
 // What the composite kernel iterates over with a bound reference mask: per view the tile rectangle that encloses all
@@ -696,6 +859,162 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
     return true;
 }
 
+// Kernel-wide arguments of a job (what the job kernel's helpers need besides the job itself).
+struct VbJobArgs {
+    VbRecs rc;
+    const float4* posc;   // [B][V] clip-space vertices
+    const int4* cvidx;    // [NC * 64] {v0, v1, v2, triangle} of every cluster slot
+    const int* lcoff;     // LDS: first cluster of every link
+    unsigned* jid;        // job slots: triangle ids of the region's pixels
+    u64* jcov;            //            coverage rows
+    int* jdesc;
+    int* jn;
+    int NC, V, W, H, L;
+};
+
+// Culls the link's clusters and triangles against the job's region and rasterizes this wave's share of them into the
+// job's coverage bitmap `cov_` / depth-id buffer `key_` (LDS, initialised by the caller).  share / nshare: the wave takes
+// every nshare-th candidate cluster -- 0 / 1 for a job of its own, wave / 4 when the whole workgroup works on one heavy
+// job.  The survivors' covered units are left in the wave's deferred list (dln entries on return): the caller flushes it
+// once the job's coverage is complete.  Returns 1 if anything survived the culling, 0 if not, and -1 (lean
+// instantiation only) if a survivor needs the general path: the caller then redoes the job with vb_job_slow.
+template <bool WIDE>
+__device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, u64* key_, u64* cov_, int b, int l,
+                                             const VbRegion& rg, int rx0, int ry0, int share, int nshare, int& nsurv,
+                                             int& dln) {
+    const int lane = lane_id();
+    const int c0 = A.lcoff[l], c1 = A.lcoff[l + 1];
+    const uint2* const cb = A.rc.cbox + (size_t)b * A.NC;
+    const unsigned rlo = (unsigned)rg.x0 | ((unsigned)rg.y0 << 16), rhi = (unsigned)rg.x1 | ((unsigned)rg.y1 << 16);
+    // Survivors of the triangle-box test are queued (record slots) until 64 are waiting, so that every round of
+    // the rasterizer is full; the triangle boxes of up to four candidate clusters are fetched per round trip.
+    const size_t vbase = (size_t)b * A.NC * 64;
+    const float4* const pv = A.posc + (size_t)b * A.V;
+    const int4* const cvl = A.cvidx + (size_t)c0 * 64;  // the link's first cluster slot
+    const unsigned srel0 = (unsigned)c0 * 64u;
+    bool full = false;   // set by a round that finds the whole region interior
+    int qh = 0, qn = 0;  // wave-uniform ring state
+    int cord = 0;        // running ordinal of the candidate clusters
+    bool drawn = false;
+    for (int cbase = c0; cbase < c1; cbase += 64) {
+        const int c = cbase + lane;
+        bool hit = false;
+        if (c < c1) {
+            const uint2 bx = cb[c];
+            hit = (bx.x & 0xffffu) <= (rhi & 0xffffu) && (bx.y & 0xffffu) >= (rlo & 0xffffu) &&
+                  (bx.x >> 16) <= (rhi >> 16) && (bx.y >> 16) >= (rlo >> 16);
+        }
+        u64 cm = __ballot(hit);
+        if (nshare > 1) {  // cooperative job: this wave takes every nshare-th candidate cluster
+            u64 mine = 0;
+            u64 all = cm;
+            while (all) {
+                const u64 low = all & (~all + 1);
+                if ((cord++ % nshare) == share) mine |= low;
+                all ^= low;
+            }
+            cm = mine;
+        }
+        while (cm) {  // wave-uniform
+            int cc[4];
+            uint2 tb[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                cc[k] = -1;
+                tb[k] = VB_BOX_EMPTY;
+                if (cm) {
+                    cc[k] = cbase + __ffsll((unsigned long long)cm) - 1;
+                    cm &= cm - 1;
+                    tb[k] = A.rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
+                }
+            }
+            u64 smk[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                smk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
+                                  (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
+            // not unrolled: one copy of the rasterizer round per call site (the kernel was 69 KB of code, more
+            // than the instruction cache two CUs share)
+#pragma nounroll
+            for (int k = 0; k < 4; k++) {
+                const u64 sm = (k == 0) ? smk[0] : (k == 1) ? smk[1] : (k == 2) ? smk[2] : smk[3];
+                const int ck = (k == 0) ? cc[0] : (k == 1) ? cc[1] : (k == 2) ? cc[2] : cc[3];
+                if (!sm) continue;  // wave-uniform (an unused batch entry holds the empty box)
+                if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
+                qn += __popcll(sm);
+                drawn = true;
+                if (qn >= 64) {
+                    VB_WAVE_SYNC();
+                    const unsigned sl = W_.sq[(qh + lane) & 127];
+                    dln = vb_raster_round<WIDE>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
+                    if (dln < 0) return -1;
+                    if (full) return 1;  // every pixel of the region is interior: nothing can change any more
+                    qh = (qh + 64) & 127;
+                    qn -= 64;
+                }
+            }
+        }
+    }
+    if (qn) {
+        VB_WAVE_SYNC();
+        const bool sv = lane < qn;
+        const unsigned sl = sv ? W_.sq[(qh + lane) & 127] : srel0;
+        dln = vb_raster_round<WIDE>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
+        if (dln < 0) return -1;
+    }
+    return drawn ? 1 : 0;
+}
+
+// A drawn job leaves, in its slot, the coverage rows of its region and the triangle id of every pixel the depth test ran
+// for (all-ones elsewhere), then its descriptor; the resolve kernel takes it from there (an undrawn job's descriptor is
+// -1).  No list of drawn jobs: appending to one costs every job a returning atomic (~3 us under load), and three
+// quarters of the jobs are drawn anyway.
+__device__ __forceinline__ void vb_publish(const VbJobArgs& A, const u64* key_, const u64* cov_, int job, int u, int tx,
+                                           int ty) {
+    const int lane = lane_id();
+    VB_WAVE_SYNC();
+    unsigned* const dst = A.jid + (size_t)job * VB_RN;
+#pragma unroll
+    for (int k = 0; k < VB_WORDS; k++) {
+        const unsigned i = 64u * k + lane;
+        if (i < (unsigned)VB_RN) dst[i] = (unsigned)key_[i];  // low word = triangle id; all-ones stays all-ones
+    }
+    if (lane < VB_RH) A.jcov[(size_t)job * VB_RH + lane] = cov_[lane];
+    if (lane == 0) A.jdesc[job] = u | (tx << 9) | (ty << 19);
+}
+
+// A whole job on one wave with the general triangle path compiled in (near-plane clipping, 64-bit edge functions): what a
+// job falls back to when the lean code meets such a triangle.  Runs in a kernel of its own (vb_slow_kernel) over the list
+// of such jobs: compiled into the job kernel -- inline or as a call, in the rounds or at the job loop's end -- the general
+// path cost the lean code 50-70 spilled registers and 13 us at 8 views.
+__device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, int job, int u, int tx, int ty) {
+    const int lane = lane_id();
+    const int b = u / A.L, l = u - b * A.L;
+    const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+    VbRegion rg;
+    rg.x0 = max(rx0, 0);
+    rg.y0 = max(ry0, 0);
+    rg.x1 = min(rx0 + VB_RW - 1, A.W - 1);
+    rg.y1 = min(ry0 + VB_RH - 1, A.H - 1);
+    VB_WAVE_SYNC();
+#pragma unroll
+    for (int k = 0; k < VB_WORDS; k++) {
+        const unsigned i = 64u * k + lane;
+        if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
+    }
+    if (lane < VB_RH) S.cov[lane] = 0ull;
+    VB_WAVE_SYNC();
+    int nsurv = 0, dln = 0;
+    const int drawn = vb_job_raster<true>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
+    if (dln > 0) vb_flush(S, S.key, S.cov, dln, A.posc + (size_t)b * A.V, A.cvidx + (size_t)A.lcoff[l] * 64, A.W, A.H, rx0, ry0);
+    if (drawn > 0) {
+        vb_publish(A, S.key, S.cov, job, u, tx, ty);
+    } else if (lane == 0) {
+        A.jn[job] = -1;
+        A.jdesc[job] = -1;
+    }
+}
+
 // Stage 2: one WAVE per job = (view, link, 32x8 tile the link's screen box touches); persistent waves over the job list,
 // which is never materialised (every workgroup derives it from the link boxes with a prefix sum over B * L counts).
 // A job culls the link's cluster boxes, then the triangle boxes of the surviving clusters, and rasterizes the survivors
@@ -709,7 +1028,9 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
 vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
               unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, int jcap,
-              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline, VbViewRects vr) {
+              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline, VbViewRects vr,
+              const float4* __restrict__ posc, int V, VbSlotIdx si, u64* __restrict__ jcov,
+              int4* __restrict__ slow_list, int heavy_t) {
     __shared__ VbWaveLds lds_all[4];
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
@@ -793,105 +1114,20 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     const int per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
     const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
     int* const cursor = vb_line(meta, xcd);
-    long long ph_last = __builtin_readcyclecounter();
-    long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)ph_last;
-    (void)ph_acc;
-    // Culls the link's clusters and triangles against the job's region and rasterizes this wave's share of them into
-    // `key_` (the job's LDS depth/id buffer, initialised by the caller).  share / nshare: the wave takes every nshare-th
-    // candidate cluster -- 0 / 1 for a job of its own, wave / 4 when the whole workgroup works on one heavy job.
-    auto raster_share = [&](VbWaveLds& W_, u64* key_, int b, int l, const VbRegion& rg, int rx0, int ry0, int share, int nshare,
-                            int& nsurv) -> bool
-    {
-            const int c0 = lcoff[l], c1 = lcoff[l + 1];
-            const uint2* const cb = rc.cbox + (size_t)b * cl.NC;
-            const unsigned rlo = (unsigned)rg.x0 | ((unsigned)rg.y0 << 16), rhi = (unsigned)rg.x1 | ((unsigned)rg.y1 << 16);
-            // Survivors of the triangle-box test are queued (record slots) until 64 are waiting, so that every round of
-            // the rasterizer is full; the triangle boxes of up to four candidate clusters are fetched per round trip.
-            const size_t vbase = (size_t)b * cl.NC * 64;
-            int qh = 0, qn = 0;  // wave-uniform ring state
-            int cord = 0;        // running ordinal of the candidate clusters
-            bool drawn = false;
-            for (int cbase = c0; cbase < c1; cbase += 64) {
-                const int c = cbase + lane;
-                bool hit = false;
-                if (c < c1) {
-                    const uint2 bx = cb[c];
-                    hit = (bx.x & 0xffffu) <= (rhi & 0xffffu) && (bx.y & 0xffffu) >= (rlo & 0xffffu) &&
-                          (bx.x >> 16) <= (rhi >> 16) && (bx.y >> 16) >= (rlo >> 16);
-                }
-                u64 cm = __ballot(hit);
-                if (nshare > 1) {  // cooperative job: this wave takes every nshare-th candidate cluster
-                    u64 mine = 0;
-                    u64 all = cm;
-                    while (all) {
-                        const u64 low = all & (~all + 1);
-                        if ((cord++ % nshare) == share) mine |= low;
-                        all ^= low;
-                    }
-                    cm = mine;
-                }
-                VB_PHASE(1);  // cluster box culling
-                while (cm) {  // wave-uniform
-                    int cc[4];
-                    uint2 tb[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        cc[k] = -1;
-                        tb[k] = VB_BOX_EMPTY;
-                        if (cm) {
-                            cc[k] = cbase + __ffsll((unsigned long long)cm) - 1;
-                            cm &= cm - 1;
-                            tb[k] = rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
-                        }
-                    }
-                    u64 smk[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        smk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
-                                          (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
-                    // not unrolled: one copy of the rasterizer round per call site (the kernel was 69 KB of code, more
-                    // than the instruction cache two CUs share)
-#pragma nounroll
-                    for (int k = 0; k < 4; k++) {
-                        const u64 sm = (k == 0) ? smk[0] : (k == 1) ? smk[1] : (k == 2) ? smk[2] : smk[3];
-                        const int ck = (k == 0) ? cc[0] : (k == 1) ? cc[1] : (k == 2) ? cc[2] : cc[3];
-                        if (!sm) continue;  // wave-uniform (an unused batch entry holds the empty box)
-                        if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
-                        qn += __popcll(sm);
-                        drawn = true;
-                        nsurv += __popcll(sm);
-                        VB_PHASE(7);  // triangle box culling
-                        if (qn >= 64) {
-                            VB_WAVE_SYNC();
-                            vb_raster_round(true, vbase + W_.sq[(qh + lane) & 127], rc, rg, rx0, ry0, W, H, W_.R, key_, ph_acc, ph_last);
-                            qh = (qh + 64) & 127;
-                            qn -= 64;
-                        }
-                    }
-                }
-            }
-            if (qn) {
-                VB_WAVE_SYNC();
-                const bool sv = lane < qn;
-                vb_raster_round(sv, vbase + (sv ? W_.sq[(qh + lane) & 127] : 0u), rc, rg, rx0, ry0, W, H, W_.R, key_, ph_acc, ph_last);
-            }
-            return drawn;
-        };
-    // A drawn job leaves the triangle id of every region pixel and its descriptor in its slot; the resolve kernel takes it
-    // from there (an undrawn one the descriptor -1).  No list of drawn jobs: appending to one costs every job a returning
-    // atomic (~3 us under load), and three quarters of the jobs are drawn anyway.
-    auto publish = [&](const u64* key_, int job, int u, int tx, int ty) {
-        VB_WAVE_SYNC();
-        unsigned* const dst = jid + (size_t)job * VB_RN;
-#pragma unroll
-        for (int k = 0; k < VB_WORDS; k++) {
-            const unsigned i = 64u * k + lane;
-            if (i < (unsigned)VB_RN) dst[i] = (unsigned)key_[i];  // low word = triangle id; all-ones stays all-ones
-        }
-        if (lane == 0) jdesc[job] = u | (tx << 9) | (ty << 19);
-        VB_PHASE(6);  // publish
-    };
+    VbJobArgs A;
+    A.rc = rc;
+    A.posc = posc;
+    A.cvidx = si.cvidx;
+    A.lcoff = lcoff;
+    A.jid = jid;
+    A.jcov = jcov;
+    A.jdesc = jdesc;
+    A.jn = jn;
+    A.NC = cl.NC;
+    A.V = V;
+    A.W = W;
+    A.H = H;
+    A.L = L;
     // ---- heavy jobs first, one workgroup each: the four waves share the job's depth/id buffer (wave 0's) and split the
     //      candidate clusters; wave 0 publishes.  A job alone costs up to ~80 us on one wave (a thousand candidate
     //      triangles in one tile), which used to be the duration of this kernel at small batch sizes.
@@ -904,7 +1140,8 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     // meshes at 1080p have ~3000 of them in 8100 jobs and run 17 % slower with the heavy phase; the 8-view xArm7
     // workload has ~220 in 5000).
     const int nheavy_prev = hv.gen[1 + hcur];
-    const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > (int)gridDim.x / 2) ? 0 : nheavy_prev;
+    const int hmax = (dbg >> 8) ? (dbg >> 8) : (int)gridDim.x / 2;  // (EHR_VB_DEBUG bits 8..: experiment with the limit)
+    const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > hmax) ? 0 : min(nheavy_prev, VB_HEAVY_CAP);
     auto remember_heavy = [&](int id) {
         const int at = atomicAdd(&hv.gen[1 + hnxt], 1);
         if (at < VB_HEAVY_CAP) hv.list[hnxt * VB_HEAVY_CAP + at] = id;
@@ -928,27 +1165,34 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         rg.y1 = min(ry0 + VB_RH - 1, H - 1);
         VbWaveLds& S0 = lds_all[0];
         for (int i = tid; i < VB_RN; i += 256) S0.key[i] = VB_EMPTY;
+        if (tid < VB_RH) S0.cov[tid] = 0ull;
         __syncthreads();
-        int nsurv = 0;
-        const bool drawn = raster_share(S, S0.key, b, l, rg, rx0, ry0, wave, 4, nsurv);
+        int nsurv = 0, dln = 0;
+        const int drawn = vb_job_raster<false>(A, S, S0.key, S0.cov, b, l, rg, rx0, ry0, wave, 4, nsurv, dln);
         if (lane == 0) {
-            if (drawn) atomicOr(&s_heavy[0], 1);
+            if (drawn > 0) atomicOr(&s_heavy[0], 1);
+            if (drawn < 0) atomicOr(&s_heavy[0], 2);  // a triangle for the general path: wave 0 redoes the job alone
             atomicAdd(&s_heavy[1], nsurv);
         }
-        __syncthreads();
-        const int any_drawn = s_heavy[0], tot_surv = s_heavy[1];
+        __syncthreads();  // the job's coverage is complete: every wave filters its own deferred units against it
+        const int any_drawn = s_heavy[0];
+        int tot_surv = s_heavy[1];
+        if (!(any_drawn & 2) && dln > 0)
+            vb_flush(S, S0.key, S0.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
         __syncthreads();
         if (wave == 0) {
+            if (any_drawn & 2) {  // put aside for vb_slow_kernel
+                if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
+            } else if (any_drawn) {
+                vb_publish(A, S0.key, S0.cov, job, u, tx, ty);
+            } else if (lane == 0) {
+                jn[job] = -1;
+                jdesc[job] = -1;
+            }
             if (lane == 0) {
                 s_heavy[0] = 0;
                 s_heavy[1] = 0;
-                if (tot_surv >= VB_HEAVY_T) remember_heavy(id);
-            }
-            if (any_drawn)
-                publish(S0.key, job, u, tx, ty);
-            else if (lane == 0) {
-                jn[job] = -1;
-                jdesc[job] = -1;
+                if (tot_surv >= heavy_t) remember_heavy(id);
             }
         }
         __syncthreads();
@@ -963,6 +1207,12 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     const long long tl_heavy = wall_clock64();
     int tl_jobs = 0, tl_maxsurv = 0, tl_sumsurv = 0;
 #endif
+#ifdef VB_TIMELINE
+    if (lane == 0) {
+        S.tl_units = S.tl_rounds = S.tl_flushes = S.tl_tested = S.tl_deferred = 0;
+        S.tl_c[0] = S.tl_c[1] = S.tl_c[2] = S.tl_c[3] = 0;
+    }
+#endif
     bool first_job = kx >= hk;
     int sjob = jbeg + (kx - hk) * 4 + wave;
     for (;;) {
@@ -976,7 +1226,6 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             job = __builtin_amdgcn_readfirstlane(job);
         }
         if (job >= jend) break;
-        VB_PHASE(0);  // claim / previous job's tail
         int u;
         {
             int lo = 0, hi = U - 1;
@@ -1012,23 +1261,29 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             const unsigned i = 64u * k + lane;
             if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
         }
+        if (lane < VB_RH) S.cov[lane] = 0ull;
         VB_WAVE_SYNC();
-        int nsurv = 0;
-        const bool drawn = raster_share(S, S.key, b, l, rg, rx0, ry0, 0, 1, nsurv);
+        int nsurv = 0, dln = 0;
+        const int drawn = vb_job_raster<false>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
+        if (drawn < 0) {  // a triangle for the general path (near-plane clipping, huge extent): put the job aside
+            if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
+            continue;
+        }
+        if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
 #ifdef VB_TIMELINE
         tl_jobs++;
         tl_maxsurv = max(tl_maxsurv, nsurv);
         tl_sumsurv += nsurv;
 #endif
-        if (nsurv >= VB_HEAVY_T && lane == 0) remember_heavy(dense_id);
-        if (!drawn) {  // the link's box touches this tile, its triangles do not
+        if (nsurv >= heavy_t && lane == 0) remember_heavy(dense_id);
+        if (drawn == 0) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
                 jn[slot] = -1;
                 jdesc[slot] = -1;
             }
             continue;
         }
-        publish(S.key, job, u, tx, ty);
+        vb_publish(A, S.key, S.cov, job, u, tx, ty);
     }
 #ifdef VB_TIMELINE
     if (lane == 0) {
@@ -1040,15 +1295,45 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         timeline[4 * gw + 2] = tl_heavy;
         timeline[4 * gw + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
                                ((long long)(hwid & 0xffff) << 32) | ((long long)(xccid & 0xf) << 48);
+        long long* const tx = timeline + 4 * (size_t)gridDim.x * 4 + 8 * gw;
+        tx[0] = S.tl_units;
+        tx[1] = S.tl_rounds;
+        tx[2] = (long long)S.tl_flushes | ((long long)S.tl_tested << 16) | ((long long)S.tl_deferred << 40);
+        for (int k = 0; k < 4; k++) tx[3 + k] = S.tl_c[k];
     }
 #else
     (void)timeline;
 #endif
-#ifdef VB_PHASE_TIMING
-    if (lane == 0)
-        for (int i = 0; i < 8; i++)
-            if (ph_acc[i]) atomicAdd((unsigned long long*)(meta + 8) + i, (unsigned long long)ph_acc[i]);
-#endif
+}
+
+// Stage 2a (normally empty): the jobs the lean code put aside, one wave each, with the general triangle path.
+__global__ void __launch_bounds__(256)
+vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ posc, int V, VbSlotIdx si,
+               unsigned* __restrict__ jid, u64* __restrict__ jcov, int* __restrict__ jdesc, int* __restrict__ jn,
+               const int4* __restrict__ slow_list, const int* __restrict__ meta) {
+    const int n = *vb_line(const_cast<int*>(meta), 17);
+    if (n == 0) return;
+    __shared__ VbWaveLds lds_all[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VbJobArgs A;
+    A.rc = rc;
+    A.posc = posc;
+    A.cvidx = si.cvidx;
+    A.lcoff = cl.coff;
+    A.jid = jid;
+    A.jcov = jcov;
+    A.jdesc = jdesc;
+    A.jn = jn;
+    A.NC = cl.NC;
+    A.V = V;
+    A.W = g.W;
+    A.H = g.H;
+    A.L = g.L;
+    (void)lane;
+    for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+        const int4 e = slow_list[i];
+        vb_job_slow(A, lds_all[wave], e.x, e.y, e.z, e.w);
+    }
 }
 
 // Stage 2b: one WAVE per DRAWN job, persistent waves over the per-XCD lists the job kernel appended to.  From the
@@ -1060,8 +1345,9 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 // and the rasterizer's do not fit 128 VGPRs together: fused, the job kernel kept 350 bytes per lane in scratch and its
 // 4096 waves' 91 MB of scratch evicted each other from the 4 MB L2s.
 __global__ void __launch_bounds__(256)
-vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const int4* __restrict__ tri4,
-                  const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const int* __restrict__ jdesc,
+vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, const int4* __restrict__ tri4,
+                  const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const u64* __restrict__ jcov,
+                  const int* __restrict__ jdesc,
                   int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems,
                   int* __restrict__ jspill, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
                   int* __restrict__ meta, int dbg) {
@@ -1088,16 +1374,41 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
                 idw[k] = (i < (unsigned)VB_RN) ? src[i] : 0xffffffffu;
             }
         }
+        const u64 myrow = (lane < VB_RH) ? jcov[slot * VB_RH + lane] : 0ull;  // coverage rows of the region
         const int de = jdesc[job];
         if (de < 0) continue;  // nothing drawn: the job kernel has already marked the slot
         const int u = de & 511, tx = (de >> 9) & 1023, ty = (de >> 19) & 4095;
         const int b = u / L;
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        // coverage in region-linear order (bit i = region pixel i), assembled from the rows: wave-uniform shifts
+        u64 C[VB_WORDS];
+        {
+            u64 crow[VB_RH];
+#pragma unroll
+            for (int r = 0; r < VB_RH; r++) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myrow, r);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myrow >> 32), r);
+                crow[r] = (((u64)hi << 32) | lo) & ((1ull << VB_RW) - 1ull);
+            }
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                u64 w = 0;
+#pragma unroll
+                for (int r = 0; r < VB_RH; r++) {
+                    const int sh = VB_RW * r - 64 * k;  // compile-time
+                    if (sh >= 0 && sh < 64) w |= crow[r] << sh;
+                    if (sh < 0 && -sh < VB_RW) w |= crow[r] >> (-sh);
+                }
+                C[k] = w;
+            }
+        }
         VB_WAVE_SYNC();  // the previous job's reads of S are complete
 #pragma unroll
         for (int k = 0; k < VB_WORDS; k++) {
             const unsigned i = 64u * k + lane;
-            if (i < (unsigned)VB_RN) S.ids[i] = idw[k];
+            // covered pixels whose triangle was never asked for (no uncovered neighbour) carry a marker instead of an id
+            if (i < (unsigned)VB_RN)
+                S.ids[i] = (idw[k] != 0xffffffffu) ? idw[k] : (((C[k] >> lane) & 1ull) ? VB_ID_COVERED : 0xffffffffu);
         }
         const int r = lane >> 3, c4 = (lane & 7) * 4;
         const int myq = (r + 1) * VB_RW + (c4 + 1);
@@ -1129,12 +1440,6 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
                 Vh[k] = Iw[k] & s1[k] & KH[k];
                 Vv[k] = Iw[k] & s34[k] & KV[k];
             }
-        }
-        u64 C[VB_WORDS];
-#pragma unroll
-        for (int k = 0; k < VB_WORDS; k++) {
-            const unsigned i = 64u * k + lane;
-            C[k] = __ballot(i < (unsigned)VB_RN && S.ids[i] != 0xffffffffu);
         }
         // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
         //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
@@ -1187,7 +1492,7 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, cons
                     const int nq = q + (d ? VB_RW : 1);
                     const unsigned k0 = KT(q), k1 = KT(nq);
                     const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
-                    const int t = (int)(chose0 ? k0 : k1);
+                    const int t = min((int)(chose0 ? k0 : k1) & 0x7fffffff, T - 1);  // (always a triangle id: the pixel has an uncovered neighbour)
                     int px = rx0 + qx, py = ry0 + qy;
                     if (!chose0) {
                         px += 1 - d;
@@ -1675,7 +1980,21 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
         cvert[4 * (2 * n_ctri + i)] = c9[8];
         cvert[4 * (2 * n_ctri + i) + 1] = 1.f;
     }
-    if ((rc = ctx->vb_clus.reserve((n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) * sizeof(int32_t) + 16 + cvert.size() * sizeof(float)))) return rc;
+    std::vector<int32_t> cvidx(4 * n_ctri, 0);  // {v0, v1, v2, triangle} of every cluster slot
+    for (size_t i = 0; i < n_ctri; i++) {
+        const int tt = i < ctri.size() ? ctri[i] : -1;
+        cvidx[4 * i + 3] = tt;
+        if (tt < 0) continue;
+        for (int k = 0; k < 3; k++) {
+            const int v = ht[3 * (size_t)tt + k];
+            cvidx[4 * i + k] = ((unsigned)v < (unsigned)V) ? v : 0;  // (such a triangle draws nothing: never looked up)
+        }
+    }
+    for (int l = 0; l < L; l++)  // a deferred unit names its triangle by an 18-bit slot relative to its link's first cluster
+        if (coff[l + 1] - coff[l] > 4096)
+            return fail(EHR_ERR_INVALID, "ehr_fused_plan: link %d has more than 262144 triangles", l);
+    if ((rc = ctx->vb_clus.reserve((n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) * sizeof(int32_t) + 32 + cvert.size() * sizeof(float) +
+                                   cvidx.size() * sizeof(int32_t)))) return rc;
     int32_t* d = (int32_t*)ctx->vb_clus.ptr;
     if (NC > 0) {
         EHR_HIP(hipMemcpy(d, ctri.data(), (size_t)NC * 64 * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1686,6 +2005,7 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
     {
         const uintptr_t at = ((uintptr_t)(d + n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) + 15) & ~(uintptr_t)15;
         EHR_HIP(hipMemcpy((void*)at, cvert.data(), cvert.size() * sizeof(float), hipMemcpyHostToDevice));
+        EHR_HIP(hipMemcpy((char*)at + cvert.size() * sizeof(float), cvidx.data(), cvidx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     return EHR_OK;
 }
@@ -1705,8 +2025,8 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     const int NC = std::max(ctx->vb_nc, 1);
     if ((rc = ctx->vb_acc.reserve(((size_t)B * (12 * (size_t)L + VB_LOSS_SLOTS * VB_LOSS_STRIDE)) * sizeof(long long) + EHR_META_INTS * sizeof(int) + (VB_LINES + 1) * 128))) return rc;
     if ((rc = ctx->vb_posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
-    // per step and (view, cluster slot): tdep 48 B | trec 32 B | tbox 8 B, then cbox 8 B per (view, cluster)
-    if ((rc = ctx->vb_boxes.reserve((size_t)B * NC * (64 * 88 + 8)))) return rc;
+    // per step and (view, cluster slot): trec 32 B | tbox 8 B, then cbox 8 B per (view, cluster)
+    if ((rc = ctx->vb_boxes.reserve((size_t)B * NC * (64 * 40 + 8)))) return rc;
     {  // pool of blended pairs for jobs that exceed their slot (EHR_VB_SPILL_ITEMS: test hook for the overflow path)
         const char* e = getenv("EHR_VB_SPILL_ITEMS");
         ctx->vb_spill_cap = e ? std::max(0, atoi(e)) : VB_SPILL_ITEMS;
@@ -1730,9 +2050,9 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         if (want > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles exceeds 2e9");
         ctx->vb_jcap = (int)want;
         const size_t nslot = (size_t)ctx->vb_jcap;
-        if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + 2 * sizeof(int) +
-                                                VB_RN * sizeof(unsigned) + sizeof(int)) +
-                                       (size_t)B * L * sizeof(int)))) return rc;
+        if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + VB_RH * sizeof(u64) +
+                                                2 * sizeof(int) + VB_RN * sizeof(unsigned) + sizeof(int) + sizeof(int4)) +
+                                       (size_t)B * L * sizeof(int) + 16))) return rc;
     }
     {  // heavy-job hint: generation + two counts | two lists | stamp table
         BinGeom g = make_geom(H, W, L);
@@ -1776,7 +2096,7 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
             // Timeline of the job kernel's waves (100 MHz clock), written into the (otherwise idle) spill pool: when
             // they started, left the heavy phase and ended; what their single-wave jobs amounted to; where they ran.
             const int nw = 4 * (((ctx->num_cus * 4) + 7) & ~7);
-            std::vector<long long> tl((size_t)4 * nw);
+            std::vector<long long> tl((size_t)12 * nw);
             EHR_HIP(hipMemcpy(tl.data(), ctx->vb_spill.ptr, tl.size() * sizeof(long long), hipMemcpyDeviceToHost));
             long long t0 = tl[0], t1 = tl[1];
             for (int i = 0; i < nw; i++) {
@@ -1810,9 +2130,11 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                 const int i = order[k].second;
                 const long long x = tl[4 * i + 3];
                 const unsigned hw = (unsigned)(x >> 32) & 0xffff;
-                fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; xcc %lld se %u cu %u simd %u slot %u\n", i, i / 4,
+                const long long* tx = &tl[4 * (size_t)nw + 8 * i];
+                fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; %lld units in %lld rounds ; %lld flushes: %lld of %lld units tested ; kcycles stage %.0f search %.0f walk %.0f flush %.0f ; xcc %lld cu %u simd %u\n", i, i / 4,
                         (tl[4 * i] - t0) * 0.01, (tl[4 * i + 2] - t0) * 0.01, (tl[4 * i + 1] - t0) * 0.01, x & 0xff, (x >> 8) & 0xfff,
-                        (x >> 20) & 0xfff, (x >> 48) & 0xf, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3, hw & 15);
+                        (x >> 20) & 0xfff, tx[0], tx[1], tx[2] & 0xffff, (tx[2] >> 16) & 0xffffff, tx[2] >> 40, tx[3] * 1e-3, tx[4] * 1e-3, tx[5] * 1e-3,
+                        tx[6] * 1e-3, (x >> 48) & 0xf, (hw >> 8) & 15, (hw >> 4) & 3);
             }
             long long mx = 0, sum = 0;
             int used = 0;
@@ -1822,18 +2144,25 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                 used += per[k] > 0;
             }
             fprintf(stderr, "[ehr timeline] single-wave survivors per SIMD: %d SIMDs with work, mean %.0f, max %lld\n", used, used ? (double)sum / used : 0.0, mx);
+            {
+                long long us = 0, rs = 0, umax = 0;
+                long long fl = 0, te = 0, de = 0;
+                double cyc[4] = {0, 0, 0, 0};
+                for (int i = 0; i < nw; i++) {
+                    const long long* tx = &tl[4 * (size_t)nw + 8 * i];
+                    us += tx[0];
+                    rs += tx[1];
+                    umax = std::max(umax, tx[0]);
+                    fl += tx[2] & 0xffff;
+                    te += (tx[2] >> 16) & 0xffffff;
+                    de += tx[2] >> 40;
+                    for (int k = 0; k < 4; k++) cyc[k] += (double)tx[3 + k];
+                }
+                fprintf(stderr, "[ehr timeline] single-wave jobs: %lld units in %lld rounds (%.0f units per round), at most %lld units on one wave\n", us, rs, rs ? (double)us / rs : 0.0, umax);
+                fprintf(stderr, "[ehr timeline] flushes %lld, deferred units %lld, depth-tested units %lld; wave-Mcycles: staging %.1f, prefix+search %.1f, walk %.1f, flush %.1f (of %.1f in total)\n",
+                        fl, de, te, cyc[0] * 1e-6, cyc[1] * 1e-6, cyc[2] * 1e-6, cyc[3] * 1e-6, busy * 0.01 * 2100.0 * 1e-6);
+            }
         }
-#endif
-#ifdef VB_PHASE_TIMING
-        unsigned long long ph[9];
-        EHR_HIP(hipMemcpy(ph, (char*)ctx->vb_acc.ptr + off + 8 * sizeof(int), sizeof(ph), hipMemcpyDeviceToHost));
-        const char* names[8] = {"job prologue", "cluster culling", "records+staging", "prefix+search", "walk+depth", "resolve", "publish", "triangle culling"};
-
-        unsigned long long tot = 0;
-        for (int i = 0; i < 8; i++) tot += ph[i];
-        for (int i = 0; i < 8; i++)
-            fprintf(stderr, "[ehr phase] %-16s %14llu cycles %5.1f %%\n", names[i], ph[i], tot ? 100.0 * ph[i] / tot : 0.0);
-        EHR_HIP(hipMemset((char*)ctx->vb_acc.ptr + off + 8 * sizeof(int), 0, sizeof(ph)));
 #endif
     }
     return EHR_OK;
@@ -1862,14 +2191,15 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     cl.laabb = (const float*)(cl.coff + L + 1);
     cl.cvert = (const float4*)(((uintptr_t)(cl.laabb + 6 * (size_t)L) + 15) & ~(uintptr_t)15);
     cl.NC = NC;
+    VbSlotIdx si;
+    si.cvidx = (const int4*)(cl.cvert + 3 * (size_t)NC1 * 64);
     VbHeavy hv;
     hv.gen = (int*)ctx->vb_heavy.ptr;
     hv.list = hv.gen + 4;
     hv.stamp = hv.list + 2 * VB_HEAVY_CAP;
     VbRecs recs;
     recs.n = (size_t)B * NC1 * 64;
-    recs.tdep = (float4*)ctx->vb_boxes.ptr;
-    recs.trec = (int4*)(recs.tdep + recs.n * 3);
+    recs.trec = (int4*)ctx->vb_boxes.ptr;
     recs.tbox = (uint2*)(recs.trec + recs.n * 2);
     recs.cbox = recs.tbox + recs.n;
 
@@ -1910,27 +2240,33 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     // stage 1: jobs = (view, link, tile) -> per-link values and blended pairs
     static const int dbg = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;  // measurement aid only
     static const int job_grid = getenv("EHR_VB_JOB_GRID") ? atoi(getenv("EHR_VB_JOB_GRID")) : 4;   // tuning knob
+    static const int heavy_t = getenv("EHR_VB_HEAVY_T") ? atoi(getenv("EHR_VB_HEAVY_T")) : VB_HEAVY_T_DEFAULT;  // tuning knob
     const size_t nslot = (size_t)ctx->vb_jcap;
     float* jval = (float*)ctx->vb_jobs.ptr;
     VbItem* jitems = (VbItem*)(jval + nslot * 256);
-    int* jn = (int*)(jitems + nslot * VB_JOB_ITEMS);
+    u64* jcov = (u64*)(jitems + nslot * VB_JOB_ITEMS);
+    int* jn = (int*)(jcov + nslot * VB_RH);
     int* jspill = jn + nslot;
     unsigned* jid = (unsigned*)(jspill + nslot);
     int* jdesc = (int*)(jid + nslot * VB_RN);
     int* jbase = jdesc + nslot;
+    int4* slow_list = (int4*)(((uintptr_t)(jbase + (size_t)B * L) + 15) & ~(uintptr_t)15);  // [nslot] jobs for vb_slow_kernel
     const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
     VbViewRects vr;
     vr.vpre = lbox + (size_t)VB_LBOX_STRIDE * B * L;
     vr.vrect = (unsigned*)(vr.vpre + B + 1);
     vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jn, jid, jdesc, jbase, ctx->vb_jcap, meta, dbg, hv,
-                                                (long long*)ctx->vb_spill.ptr, vr);
+                                                (long long*)ctx->vb_spill.ptr, vr, posc, V, si, jcov, slow_list, heavy_t);
+    EHR_LAUNCH_CHECK();
+    // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
+    vb_slow_kernel<<<ctx->num_cus, 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
     // stage 1b: drawn jobs -> per-link values and blended pairs
     static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
     const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
-    vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
-                                                   jid, jdesc, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
+    vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, T, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
+                                                   jid, jcov, jdesc, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
                                                    ctx->vb_spill_cap, meta, dbg);
     EHR_LAUNCH_CHECK();
     if (ev) {
