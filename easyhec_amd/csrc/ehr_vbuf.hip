@@ -835,14 +835,6 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
 }
 
 
-// What the composite kernel iterates over with a bound reference mask: per view the tile rectangle that encloses all
-// its links' tile ranges (vrect: tx0 | ty0 << 10 | nx << 22) and the running count of those tiles (vpre [B + 1]);
-// written by workgroup 0 of the job kernel.
-struct VbViewRects {
-    int* vpre;
-    unsigned* vrect;
-};
-
 // tiles (+ 1-pixel halo) a link's pixel box touches: the jobs of that (view, link)
 __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W, int H, int& tx0, int& ty0, int& nx, int& ny) {
     const int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
@@ -1019,8 +1011,9 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
 #define VB_JOB_WAVES 4
 #endif
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
-vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, int jcap,
-              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline, VbViewRects vr,
+vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, unsigned* __restrict__ jid,
+              int* __restrict__ jdesc, int* __restrict__ jbase, unsigned* __restrict__ jutile, int jcap,
+              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline,
               const float4* __restrict__ posc, int V, VbSlotIdx si, u64* __restrict__ jcov,
               int4* __restrict__ slow_list, int heavy_t) {
     __shared__ VbWaveLds lds_all[4];
@@ -1061,39 +1054,11 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     int total = upre[U];
     if (blockIdx.x == 0) {
         // job slots are numbered like the jobs: stage 3 finds a (view, link, tile) slot from the link's first job
-        for (int u = tid; u < U; u += 256) jbase[u] = upre[u];
+        for (int u = tid; u <= U; u += 256) jbase[u] = upre[u];
+        for (int u = tid; u < U; u += 256) jutile[u] = utile[u];
         if (tid == 0) {
             meta[5] = total;  // number of jobs (the resolve kernel's loop bound)
             if (total > jcap) meta[EHR_META_OVERFLOW] = 1;  // cannot happen with one slot per (view, link, tile)
-        }
-        // per view the tile rectangle that encloses its links' tile ranges: the composite kernel's work list when the
-        // reference mask is bound (the wave buffers are idle during the prologue)
-        int* const tmp = reinterpret_cast<int*>(&lds_all[0]);
-        for (int b = tid; b < B; b += 256) {
-            int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
-            for (int l = 0; l < L; l++) {
-                const int u = b * L + l, n = upre[u + 1] - upre[u];
-                if (n > 0) {
-                    const unsigned ut = utile[u];
-                    const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
-                    x0 = min(x0, tx0);
-                    y0 = min(y0, ty0);
-                    x1 = max(x1, tx0 + nx - 1);
-                    y1 = max(y1, ty0 + n / nx - 1);
-                }
-            }
-            const bool ne = x1 >= x0;
-            vr.vrect[b] = ne ? ((unsigned)x0 | ((unsigned)y0 << 10) | ((unsigned)(x1 - x0 + 1) << 22)) : (1u << 22);
-            tmp[b] = ne ? (x1 - x0 + 1) * (y1 - y0 + 1) : 0;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int b = 0; b < B; b++) {
-                vr.vpre[b] = run;
-                run += tmp[b];
-            }
-            vr.vpre[B] = run;
         }
     }
     total = min(total, jcap);
@@ -1376,15 +1341,17 @@ vb_refsum_kernel(BinGeom g, int B, const float* __restrict__ ref, int vec_ok, lo
     }
 }
 
-// Stage 3: one WAVE per 32x8 tile, for every link whose job drew something there: from the job's coverage rows and
-// triangle ids (tile + 1-pixel halo) the covered / uncovered pixel pairs by wave-uniform bit arithmetic, silhouette
-// analysis of the compacted hits (restates nvdiffrast's antialias mesh kernel), gather of the link's antialiased value
-// per pixel in the oracle's order; then the links' values summed in link order, clamp, frame loss, mask, and the
-// blended pairs back-propagated to 12 numbers per link which go to the view's fixed-point accumulators.  Round 2 ran
-// this as two kernels (per-job resolve -> per-tile composite) with the per-link value tiles and pair lists passing
-// through HBM; fused, a tile is one dependent chain (boxes -> descriptors / ids -> triangle indices -> vertices) instead
-// of two plus a kernel boundary.  4 pixels per lane, float4 image accesses, no workgroup barriers in the tile loop.
-// Persistent waves over
+// Stage 3: one WAVE per 32x8 tile, all the links whose job drew something there TOGETHER: from every such job's coverage
+// rows the covered / uncovered pixel pairs (wave-uniform bit arithmetic) go into one hit list with the covered pixel's
+// triangle id; the silhouette analysis (restates nvdiffrast's antialias mesh kernel) runs over that list 64 hits at a
+// time; then per link the antialiased value of every pixel is gathered in the oracle's order, the links' values summed
+// in link order, clamp, frame loss, mask, and the blended pairs back-propagated to 12 numbers per link which go to the
+// view's fixed-point accumulators.  Round 2 ran this as two kernels (per-job resolve -> per-tile composite) with the
+// per-link value tiles and pair lists passing through HBM.  What bounds the stage is its chain of dependent memory round
+// trips (~1 us each: the data was written by the previous kernel through another XCD's L2), so the tile is organised
+// around the shortest chain: link tables in LDS -> {descriptors, coverage rows, ids} of all links at once -> triangle
+// indices -> vertices -> [composite] -> the pairs' vertices -> atomics, whatever the number of links.
+// 4 pixels per lane, float4 image accesses, no workgroup barriers in the tile loop.  Persistent waves over
 //   tsum == NULL: every tile of every view (tiles no link draws into just stream: mask = 0, loss += ref^2);
 //   tsum != NULL (bound reference mask, no mask output): the tiles of the views' link rectangles only; a tile that no
 //                 link draws into is skipped without touching the image -- its cached sum is already in vtot.
@@ -1393,42 +1360,48 @@ vb_refsum_kernel(BinGeom g, int B, const float* __restrict__ ref, int vec_ok, lo
 #ifndef VB_TILE_WAVES
 #define VB_TILE_WAVES 4
 #endif
-constexpr int VB_TILE_ITEMS = 96;  // blended pairs of a tile (all links) kept in LDS; the rest spills to a global pool
-struct alignas(16) VbTileLds {     // per wave of the tile kernel
-    unsigned ids[VB_RN];           // triangle id of each region pixel of the current link (all-ones = uncovered)
-    float pairA[2 * VB_RN];        // blend weight of pair (q, d) at [d * RN + q]; later the tile's loss gradient (256 floats)
-    unsigned short hits[2 * VB_RN];
-    VbItem items[VB_TILE_ITEMS];   // blended pairs of all links of the tile, link by link
-    int istart[36];                // first item of every link (istart[l + 1] - istart[l] items), [L] = total
+constexpr int VB_TILE_ITEMS = 96;   // blended pairs of a tile (all links) kept in LDS; the rest spills to a global pool
+constexpr int VB_TILE_HITS = 704;   // hits analysed together (>= 2 * VB_RN: one link's worst case)
+constexpr int VB_TILE_GROUP = 8;    // links analysed together
+struct alignas(16) VbTileLds {      // per wave of the tile kernel
+    union {
+        unsigned ids[VB_RN];        // collecting hits: triangle id of each region pixel of the current link
+        float pairA[2 * VB_RN];     // gathering values: blend weight of pair (q, d) at [d * RN + q]
+        float gpix[EHR_TILE_W * EHR_TILE_H];  // backward: the tile's loss gradient
+    };
+    unsigned ht[VB_TILE_HITS];      // per hit: triangle id of its covered pixel; after the analysis the blend weight
+    unsigned short hq[VB_TILE_HITS];  // per hit: q (region index of pixel 0) | d << 9 | pixel 0 is the covered one << 10 | group slot << 11
+    VbItem items[VB_TILE_ITEMS];    // blended pairs of all links of the tile (link in bits 15-19 of `packed`)
+    u64 covs[VB_TILE_GROUP][VB_RH]; // coverage rows of the group's links
+    int hstart[VB_TILE_GROUP + 1];  // first hit of every link of the group
 };
+static_assert(VB_TILE_HITS >= 2 * VB_RN, "one link's hits must fit");
 
 template <bool TAIL>
 __global__ void __launch_bounds__(256, VB_TILE_WAVES)
 vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, const float* __restrict__ verts,
                const int4* __restrict__ tri4, const int4* __restrict__ opp4, int* __restrict__ lbox,
                const unsigned* __restrict__ jid, const u64* __restrict__ jcov, const int* __restrict__ jdesc,
-               const int* __restrict__ jbase, int jcap, const float* __restrict__ ref, float* __restrict__ mask,
-               long long* __restrict__ facc, int nls, int want_grad, int vec_ok, VbItem* __restrict__ spill, int spill_cap,
-               int* __restrict__ meta, int dbg, const long long* __restrict__ tsum, const long long* __restrict__ vtot,
-               const int* __restrict__ ref_flag, VbViewRects vr, float* __restrict__ loss, float* __restrict__ grad_mvp,
-               StepTail tail) {
+               const int* __restrict__ jbase, const unsigned* __restrict__ jutile, int jcap, const float* __restrict__ ref,
+               float* __restrict__ mask, long long* __restrict__ facc, int nls, int want_grad, int vec_ok,
+               VbItem* __restrict__ spill, int spill_cap, int* __restrict__ meta, int dbg,
+               const long long* __restrict__ tsum, const long long* __restrict__ vtot, const int* __restrict__ ref_flag,
+               float* __restrict__ loss, float* __restrict__ grad_mvp, StepTail tail) {
     __shared__ VbTileLds lds_all[4];
-    extern __shared__ int s_dyn[];  // [B + 1] vpre | [B] vrect (bound reference only)
-    int* const s_vpre = s_dyn;
-    unsigned* const s_vrect = reinterpret_cast<unsigned*>(s_dyn + B + 1);
+    extern __shared__ int s_dyn[];  // [U + 1] first job of every (view, link) | [U] its tile range
+    const int L = g.L, U = B * L;
+    int* const s_jbase = s_dyn;
+    unsigned* const s_utile = reinterpret_cast<unsigned*>(s_dyn + U + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbTileLds& S = lds_all[wave];
-    float* const gpix = S.pairA;  // (the blend weights are dead once the last link's values are gathered)
-#define KT(i) (S.ids[i])
-    const int W = g.W, H = g.H, L = g.L;
+    const int W = g.W, H = g.H;
     const bool sparse = tsum != nullptr;
-    int nitems_all = B * g.nt;
-    if (sparse) {
-        for (int i = tid; i <= B; i += 256) s_vpre[i] = vr.vpre[i];
-        for (int i = tid; i < B; i += 256) s_vrect[i] = vr.vrect[i];
-        __syncthreads();
-        nitems_all = s_vpre[B];
-    }
+    for (int i = tid; i <= U; i += 256) s_jbase[i] = jbase[i];
+    for (int i = tid; i < U; i += 256) s_utile[i] = jutile[i];
+    __syncthreads();
+    // work items: every tile of every view, or (bound reference) the JOBS -- a job stands for its tile if no link before
+    // its own has a job there, so that every tile with a job comes up exactly once and the others never
+    const int nitems_all = sparse ? min(s_jbase[U], jcap) : B * g.nt;
     // XCD-aware order (locality only): every XCD takes a contiguous run of tiles
     const int nwg = gridDim.x;
     const int per_xcd = (nitems_all + 7) >> 3, xcd = blockIdx.x & 7;
@@ -1440,19 +1413,29 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
     for (int item = ibeg + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += istep) {
         int b, tx, ty;
         if (sparse) {
-            int lo = 0, hi = B - 1;
+            int lo = 0, hi = U - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (s_vpre[mid] <= item)
+                if (s_jbase[mid] <= item)
                     lo = mid;
                 else
                     hi = mid - 1;
             }
-            b = lo;
-            const unsigned vrc = s_vrect[b];
-            const int nx = (int)(vrc >> 22), k = item - s_vpre[b];
-            ty = (int)((vrc >> 10) & 4095u) + k / nx;
-            tx = (int)(vrc & 1023u) + k - (k / nx) * nx;
+            b = lo / L;
+            const unsigned ut = s_utile[lo];
+            const int nx = (int)(ut >> 22), k = item - s_jbase[lo];
+            ty = (int)((ut >> 10) & 4095u) + k / nx;
+            tx = (int)(ut & 1023u) + k - (k / nx) * nx;
+            // owner of the tile = the job of the first link that has one there
+            bool prior = false;
+            if (lane < lo - b * L) {
+                const int u2 = b * L + lane;
+                const unsigned u2t = s_utile[u2];
+                const int n2 = s_jbase[u2 + 1] - s_jbase[u2];
+                const int ax0 = u2t & 1023u, ay0 = (u2t >> 10) & 4095u, anx = u2t >> 22;
+                prior = n2 > 0 && tx >= ax0 && tx < ax0 + anx && ty >= ay0 && ty < ay0 + n2 / anx;
+            }
+            if (__ballot(prior)) continue;
         } else {
             b = item / g.nt;
             const int tile = item - b * g.nt;
@@ -1463,23 +1446,22 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
         long long* const vacc = facc + (size_t)b * acc_stride;
         long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
-        // links whose screen box touches the tile + halo region (lane l tests link l) and whose job drew something
-        int myslot = -1;
-        {
-            const int gx0 = max(rx0, 0), gy0 = max(ry0, 0), gx1 = min(rx0 + VB_RW - 1, W - 1), gy1 = min(ry0 + VB_RH - 1, H - 1);
-            if (lane < L) {
-                const int* bx = lbox + VB_LBOX_STRIDE * ((size_t)b * L + lane);
-                const bool hit = bx[0] <= gx1 && bx[2] >= gx0 && bx[1] <= gy1 && bx[3] >= gy0;
-                if (hit && !(dbg & 1)) {
-                    int tx0, ty0, nx, ny;
-                    vb_unit_tiles(bx, W, H, tx0, ty0, nx, ny);
-                    const int sl = jbase[b * L + lane] + (ty - ty0) * nx + (tx - tx0);
-                    if (sl < jcap && jdesc[sl] >= 0) myslot = sl;
+        // links whose tile range (the tiles + halo their screen box touches: the jobs stage 2 ran) contains this tile
+        // (lane l tests link l, from the tables in LDS), and whether the job drew anything (its descriptor)
+        int myslot = -1, myde = -1;
+        if (lane < L && !(dbg & 1)) {
+            const int u = b * L + lane;
+            const unsigned ut = s_utile[u];
+            const int j0 = s_jbase[u], n = s_jbase[u + 1] - j0;
+            const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
+            if (n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && ty < ty0 + n / nx) {
+                const int sl = j0 + (ty - ty0) * nx + (tx - tx0);
+                if (sl < jcap) {
+                    myslot = sl;
+                    myde = jdesc[sl];
                 }
             }
         }
-        unsigned todo = (unsigned)__ballot(myslot >= 0);
-        if (sparse && todo == 0) continue;  // nothing drawn here: the tile's cached sum(ref^2) is part of vtot already
         const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
         const bool row_in = iy < H;
         const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
@@ -1487,6 +1469,8 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
         bool pin[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) pin[j] = row_in && (ix + j) < W;
+        unsigned todo = (unsigned)__ballot(myde >= 0);  // links that drew something here
+        if (sparse && todo == 0) continue;
         if (vec_ok) {
             if (pin[0]) {
                 const float4 r4 = *reinterpret_cast<const float4*>(ref + im);
@@ -1502,6 +1486,7 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
         int nit = 0;          // wave-uniform: blended pairs of the tile so far
         int spill_base = -1;  // wave-uniform: this tile's block of the spill pool, once one was needed
         int room = VB_TILE_ITEMS;
+        unsigned bmask = 0;   // links with blended pairs to back-propagate
         // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
         u64 Vh[VB_WORDS], Vv[VB_WORDS];
         if (todo) {
@@ -1526,190 +1511,224 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
                 Vv[k] = Iw[k] & s34[k] & KV[k];
             }
         }
-        unsigned bmask = 0;  // links with blended pairs to back-propagate
-        while (todo) {  // links in link order
-            const int l = __ffs(todo) - 1;
-            todo &= todo - 1;
-            const size_t slot = (size_t)vb_readlane(myslot, l);
+        while (todo) {  // groups of links (normally one): as many as fit the hit list
+            // ---- (1) collect: per link the pairs with exactly one covered pixel.  Only those can change the result:
+            //      with constant colour inside a link a blend between two covered pixels is alpha * (1 - 1) = 0 in value
+            //      and in gradient.  The next link's ids and coverage rows are requested before this one's are used.
+            unsigned grp = 0;      // links of this group
+            int ng = 0, nhit = 0;  // wave-uniform
             unsigned idw[VB_WORDS];
-            {
+            u64 myrow = 0;
+            auto fetch = [&](int l) {
+                const size_t slot = (size_t)vb_readlane(myslot, l);
                 const unsigned* const src = jid + slot * VB_RN;
 #pragma unroll
                 for (int k = 0; k < VB_WORDS; k++) {
                     const unsigned i = 64u * k + lane;
                     idw[k] = (i < (unsigned)VB_RN) ? src[i] : 0xffffffffu;
                 }
-            }
-            const u64 myrow = (lane < VB_RH) ? jcov[slot * VB_RH + lane] : 0ull;  // coverage rows of the region
-            // coverage in region-linear order (bit i = region pixel i), assembled from the rows: wave-uniform shifts
-            u64 C[VB_WORDS];
-            {
-                u64 crow[VB_RH];
-#pragma unroll
-                for (int rr = 0; rr < VB_RH; rr++) {
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myrow, rr);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myrow >> 32), rr);
-                    crow[rr] = (((u64)hi << 32) | lo) & VB_ROW_MASK;
-                }
-#pragma unroll
-                for (int k = 0; k < VB_WORDS; k++) {
-                    u64 w = 0;
+                myrow = (lane < VB_RH) ? jcov[slot * VB_RH + lane] : 0ull;
+            };
+            fetch(__ffs(todo) - 1);
+            while (todo && ng < VB_TILE_GROUP) {
+                const int l = __ffs(todo) - 1;
+                // coverage in region-linear order (bit i = region pixel i), assembled from the rows: wave-uniform shifts
+                u64 C[VB_WORDS];
+                {
+                    u64 crow[VB_RH];
 #pragma unroll
                     for (int rr = 0; rr < VB_RH; rr++) {
-                        const int sh = VB_RW * rr - 64 * k;  // compile-time
-                        if (sh >= 0 && sh < 64) w |= crow[rr] << sh;
-                        if (sh < 0 && -sh < VB_RW) w |= crow[rr] >> (-sh);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myrow, rr);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myrow >> 32), rr);
+                        crow[rr] = (((u64)hi << 32) | lo) & VB_ROW_MASK;
                     }
-                    C[k] = w;
-                }
-            }
-            VB_WAVE_SYNC();  // the previous link's reads of S are complete
 #pragma unroll
-            for (int k = 0; k < VB_WORDS; k++) {
-                const unsigned i = 64u * k + lane;
-                // covered pixels whose triangle was never asked for (no uncovered neighbour) carry a marker instead of an id
-                if (i < (unsigned)VB_RN)
-                    S.ids[i] = (idw[k] != 0xffffffffu) ? idw[k] : (((C[k] >> lane) & 1ull) ? VB_ID_COVERED : 0xffffffffu);
-            }
-            for (int i = lane; i < 2 * VB_RN; i += 64) S.pairA[i] = 0.f;
-            // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
-            //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
-            u64 Hw[2 * VB_WORDS];
-            int nh = 0;
-            {
-                u64 s1[VB_WORDS], s34[VB_WORDS];
-                vb_shr<1>(C, s1);
-                vb_shr<VB_RW>(C, s34);
+                    for (int k = 0; k < VB_WORDS; k++) {
+                        u64 w = 0;
+#pragma unroll
+                        for (int rr = 0; rr < VB_RH; rr++) {
+                            const int sh = VB_RW * rr - 64 * k;  // compile-time
+                            if (sh >= 0 && sh < 64) w |= crow[rr] << sh;
+                            if (sh < 0 && -sh < VB_RW) w |= crow[rr] >> (-sh);
+                        }
+                        C[k] = w;
+                    }
+                }
+                u64 Hw[2 * VB_WORDS];
+                int nh = 0;
+                {
+                    u64 s1[VB_WORDS], s34[VB_WORDS];
+                    vb_shr<1>(C, s1);
+                    vb_shr<VB_RW>(C, s34);
+#pragma unroll
+                    for (int k = 0; k < VB_WORDS; k++) {
+                        Hw[k] = (C[k] ^ s1[k]) & Vh[k];
+                        Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
+                        nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
+                    }
+                }
+                if (dbg & 2) nh = 0;
+                if (nhit + nh > VB_TILE_HITS) break;  // the list is full: analyse this group, the link opens the next one
+                VB_WAVE_SYNC();  // the previous link's reads of S.ids are complete
+                if (lane < VB_RH) S.covs[ng][lane] = myrow & VB_ROW_MASK;
 #pragma unroll
                 for (int k = 0; k < VB_WORDS; k++) {
-                    Hw[k] = (C[k] ^ s1[k]) & Vh[k];
-                    Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
-                    nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
+                    const unsigned i = 64u * k + lane;
+                    if (i < (unsigned)VB_RN) S.ids[i] = idw[k];
                 }
-            }
-            VB_WAVE_SYNC();
-            float val[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) val[j] = (KT(myq + j) != 0xffffffffu) ? 1.f : 0.f;
-            if (dbg & 2) nh = 0;
-            const int nit0 = nit;
-            if (nh != 0) {
-                // ---- dense hit list, ordered by (direction, region index)
-                {
-                    int base = 0;
+                todo &= todo - 1;
+                if (todo) fetch(__ffs(todo) - 1);  // (a link that opens the next group is fetched again there)
+                VB_WAVE_SYNC();
+                if (nh != 0) {  // dense hit list, ordered by (direction, region index)
+                    int base = nhit;
 #pragma unroll
                     for (int s = 0; s < 2 * VB_WORDS; s++) {
                         const u64 w = Hw[s];
                         if (w) {
-                            if ((w >> lane) & 1)
-                                S.hits[base + vb_mbcnt(w)] = (unsigned short)(((s % VB_WORDS) * 64 + lane) | ((s / VB_WORDS) << 15));
+                            if ((w >> lane) & 1) {
+                                const int q = (s % VB_WORDS) * 64 + lane, d = s / VB_WORDS;
+                                const bool c0 = (C[s % VB_WORDS] >> lane) & 1ull;  // pixel 0 is the covered one of the two
+                                const int at = base + vb_mbcnt(w);
+                                S.hq[at] = (unsigned short)(q | (d << 9) | ((c0 ? 1 : 0) << 10) | (ng << 11));
+                                S.ht[at] = S.ids[c0 ? q : q + (d ? VB_RW : 1)];
+                            }
                             base += __popcll(w);
                         }
                     }
                 }
-                VB_WAVE_SYNC();
-                // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
-                for (int hbase = 0; hbase < nh; hbase += 64) {
-                    const int h = hbase + lane;
-                    VbItem it;
-                    it.packed = 0;
-                    it.v1 = 0;
-                    it.v2 = 0;
-                    it.alpha = 0.f;
-                    bool keep = false;
-                    if (h < nh) {
-                        const int hq = S.hits[h];
-                        const int d = hq >> 15, q = hq & 0x7fff;
-                        const int qy = q / VB_RW, qx = q - qy * VB_RW;
-                        const int nq = q + (d ? VB_RW : 1);
-                        const unsigned k0 = KT(q), k1 = KT(nq);
-                        const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
-                        const int t = min((int)(chose0 ? k0 : k1) & 0x7fffffff, T - 1);  // (always a triangle id: the pixel has an uncovered neighbour)
-                        int px = rx0 + qx, py = ry0 + qy;
-                        if (!chose0) {
-                            px += 1 - d;
-                            py += d;
-                        }
-                        float4 p[3], o[3];
-                        const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
-                        const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
-#pragma unroll
-                        for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
-#pragma unroll
-                        for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
-                        const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
-                        if (a.found) {
-                            S.pairA[d * VB_RN + q] = a.alpha;
-                            // keep for the backward pass if the destination pixel is interior to this tile
-                            const int oq = (a.alpha > 0.f) ? q : nq;
-                            const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
-                            const bool oin = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
-                            if (oin && a.alpha != 0.f) {
-                                it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
-                                it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
-                                it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
-                                it.alpha = a.alpha;
-                                keep = want_grad != 0;
-                            }
-                        }
+                if (lane == 0) S.hstart[ng] = nhit;
+                nhit += nh;
+                grp |= 1u << l;
+                ng++;
+            }
+            if (lane == 0) S.hstart[ng] = nhit;
+            VB_WAVE_SYNC();
+            // ---- (2) silhouette analysis of all the group's hits (restates nvdiffrast's antialias mesh kernel), 64 per round
+            for (int hbase = 0; hbase < nhit; hbase += 64) {
+                const int h = hbase + lane;
+                VbItem it;
+                it.packed = 0;
+                it.v1 = 0;
+                it.v2 = 0;
+                it.alpha = 0.f;
+                bool keep = false;
+                if (h < nhit) {
+                    const int hq = S.hq[h];
+                    const int q = hq & 511, d = (hq >> 9) & 1, gk = hq >> 11;
+                    const bool chose0 = (hq >> 10) & 1;
+                    const int qy = q / VB_RW, qx = q - qy * VB_RW;
+                    const int nq = q + (d ? VB_RW : 1);
+                    const int t = min((int)(S.ht[h] & 0x7fffffffu), T - 1);  // (always a triangle id: the pixel has an uncovered neighbour)
+                    int px = rx0 + qx, py = ry0 + qy;
+                    if (!chose0) {
+                        px += 1 - d;
+                        py += d;
                     }
-                    const u64 km = __ballot(keep);
-                    if (km) {
-                        const int at = nit + vb_mbcnt(km);
-                        const int nnew = nit + __popcll(km);
-                        if (nnew > VB_TILE_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this tile
-                            int base = 0;
-                            if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
-                            spill_base = __builtin_amdgcn_readfirstlane(base);
-                            // items this tile can keep: LDS, then its block of the spill pool as far as the pool reaches
-                            if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
+                    float4 p[3], o[3];
+                    const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
+                    const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
+                    const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
+                    S.ht[h] = a.found ? __float_as_uint(a.alpha) : 0u;
+                    if (a.found) {
+                        // keep for the backward pass if the destination pixel is interior to this tile
+                        const int oq = (a.alpha > 0.f) ? q : nq;
+                        const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+                        const bool oin = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
+                        if (oin && a.alpha != 0.f) {
+                            // the link: the gk-th set bit of grp
+                            unsigned gm = grp;
+                            for (int k = 0; k < gk; k++) gm &= gm - 1;
+                            const int l = __ffs(gm) - 1;
+                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14) | (l << 15);
+                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
+                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
+                            it.alpha = a.alpha;
+                            keep = want_grad != 0;
                         }
-                        if (keep) {
-                            if (at < VB_TILE_ITEMS)
-                                S.items[at] = it;
-                            else if (at < room)
-                                spill[spill_base + (at - VB_TILE_ITEMS)] = it;
-                            else
-                                atomicOr(&meta[EHR_META_OVERFLOW], 1);  // reported through loss = NaN, never silent
-                        }
-                        nit = min(nnew, room);  // never more than were stored
                     }
                 }
-                VB_WAVE_SYNC();
-                // ---- gather the antialiased value of this link at my pixels (fixed order: down, left, right, up pair)
-                {
+                const u64 km = __ballot(keep);
+                if (km) {
+                    const int at = nit + vb_mbcnt(km);
+                    const int nnew = nit + __popcll(km);
+                    if (nnew > VB_TILE_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this tile
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
+                        spill_base = __builtin_amdgcn_readfirstlane(base);
+                        // items this tile can keep: LDS, then its block of the spill pool as far as the pool reaches
+                        if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
+                    }
+                    if (keep) {
+                        if (at < VB_TILE_ITEMS)
+                            S.items[at] = it;
+                        else if (at < room)
+                            spill[spill_base + (at - VB_TILE_ITEMS)] = it;
+                        else
+                            atomicOr(&meta[EHR_META_OVERFLOW], 1);  // reported through loss = NaN, never silent
+                    }
+                    nit = min(nnew, room);  // never more than were stored
+                }
+            }
+            VB_WAVE_SYNC();
+            // ---- (3) per link: scatter its blend weights, gather the antialiased value at my pixels (fixed order: down,
+            //      left, right, up pair), sum in link order
+            for (int i = lane; i < 2 * VB_RN; i += 64) S.pairA[i] = 0.f;
+            {
+                unsigned gm = grp;
+#pragma unroll 1
+                for (int gk = 0; gk < ng; gk++) {
+                    const int l = __ffs(gm) - 1;
+                    gm &= gm - 1;
+                    VB_WAVE_SYNC();
+                    const int hb = S.hstart[gk], he = S.hstart[gk + 1];
+                    for (int h = hb + lane; h < he; h += 64) {
+                        const int hq = S.hq[h];
+                        S.pairA[((hq >> 9) & 1) * VB_RN + (hq & 511)] = __uint_as_float(S.ht[h]);
+                    }
+                    VB_WAVE_SYNC();
+                    const u64 r0 = S.covs[gk][r], r1 = S.covs[gk][r + 1], r2 = S.covs[gk][r + 2];
                     float cn[6], cd[4], cu[4];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) cn[j] = (KT(myq - 1 + j) != 0xffffffffu) ? 1.f : 0.f;
+                    for (int j = 0; j < 6; j++) cn[j] = ((r1 >> (c4 + j)) & 1ull) ? 1.f : 0.f;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        cd[j] = (KT(myq - VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
-                        cu[j] = (KT(myq + VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                        cd[j] = ((r0 >> (c4 + 1 + j)) & 1ull) ? 1.f : 0.f;
+                        cu[j] = ((r2 >> (c4 + 1 + j)) & 1ull) ? 1.f : 0.f;
                     }
+                    float val[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const float c = cn[j + 1];
                         float v = c;
-                        float a;
-                        a = S.pairA[VB_RN + myq + j - VB_RW];
-                        if (a < 0.f) v += a * (c - cd[j]);
-                        a = S.pairA[myq + j - 1];
-                        if (a < 0.f) v += a * (c - cn[j]);
-                        a = S.pairA[myq + j];
-                        if (a > 0.f) v += a * (cn[j + 2] - c);
-                        a = S.pairA[VB_RN + myq + j];
-                        if (a > 0.f) v += a * (cu[j] - c);
+                        if (he > hb) {
+                            float a;
+                            a = S.pairA[VB_RN + myq + j - VB_RW];
+                            if (a < 0.f) v += a * (c - cd[j]);
+                            a = S.pairA[myq + j - 1];
+                            if (a < 0.f) v += a * (c - cn[j]);
+                            a = S.pairA[myq + j];
+                            if (a > 0.f) v += a * (cn[j + 2] - c);
+                            a = S.pairA[VB_RN + myq + j];
+                            if (a > 0.f) v += a * (cu[j] - c);
+                        }
                         val[j] = v;
                     }
+                    VB_WAVE_SYNC();
+                    for (int h = hb + lane; h < he; h += 64) {  // (leave the table zero for the next link)
+                        const int hq = S.hq[h];
+                        S.pairA[((hq >> 9) & 1) * VB_RN + (hq & 511)] = 0.f;
+                    }
+                    // the link's blended pairs count only if it has a value inside the tile (as when the stages were kernels)
+                    const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
+                    if (nz) bmask |= 1u << l;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] += val[j];
                 }
             }
-            // the link's blended pairs count only if it has a value inside the tile (as when the stages were kernels)
-            const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
-            if (!nz) nit = nit0;
-            if (lane == 0) S.istart[l] = nit0 | ((nit - nit0) << 16);
-            if (nit > nit0) bmask |= 1u << l;
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[j] += val[j];
         }
         // ---- composite, loss, mask write (image convention: row 0 = top)
         float e2 = 0.f, gv[4];
@@ -1744,32 +1763,38 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
                     fix_add(lacc, s, meta);
             }
         }
-        if (!want_grad || bmask == 0 || (dbg & 4)) continue;
+        if (!want_grad || nit == 0 || bmask == 0 || (dbg & 4)) continue;
 
-        // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
-        VB_WAVE_SYNC();  // the last link's reads of pairA are complete
+        // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link (the pairs carry their link)
+        VB_WAVE_SYNC();  // the reads of pairA are complete
 #pragma unroll
-        for (int j = 0; j < 4; j++) gpix[r * EHR_TILE_W + c4 + j] = gv[j];
+        for (int j = 0; j < 4; j++) S.gpix[r * EHR_TILE_W + c4 + j] = gv[j];
         VB_WAVE_SYNC();
-        unsigned links = bmask;
+        // which links have pairs at all (wave-uniform), restricted to those with a value in the tile
+        unsigned links = 0;
+        for (int i = lane; i < nit; i += 64) {
+            const VbItem itm = (i < VB_TILE_ITEMS) ? S.items[i] : spill[spill_base + (i - VB_TILE_ITEMS)];
+            links |= 1u << ((itm.packed >> 15) & 31);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) links |= (unsigned)__shfl_xor((int)links, o, 64);
+        links &= bmask;
         while (links) {
             const int l = __ffs(links) - 1;
             links &= links - 1;
-            const int is = S.istart[l];
-            const int i0 = is & 0xffff, n = is >> 16;
             float G[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) G[k] = 0.f;
-            for (int i = lane; i < n; i += 64) {
-                const int ii = i0 + i;
-                const VbItem itm = (ii < VB_TILE_ITEMS) ? S.items[ii] : spill[spill_base + (ii - VB_TILE_ITEMS)];
+            for (int i = lane; i < nit; i += 64) {
+                const VbItem itm = (i < VB_TILE_ITEMS) ? S.items[i] : spill[spill_base + (i - VB_TILE_ITEMS)];
+                if (((itm.packed >> 15) & 31) != l) continue;
                 const int q = itm.packed & 1023, d = (itm.packed >> 10) & 1;
                 const int tri1 = (itm.packed >> 13) & 1;
                 const float dc = ((itm.packed >> 14) & 1) ? 1.f : -1.f;
                 const int nq = q + (d ? VB_RW : 1);
                 const int oq = (itm.alpha > 0.f) ? q : nq;
                 const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
-                const float gi = gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
+                const float gi = S.gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
                 const float dd = gi * dc;
                 if (gi == 0.f || dd == 0.f) continue;
                 const int qy = q / VB_RW, qx = q - qy * VB_RW;
@@ -1797,7 +1822,6 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
             if (lane < 12) fix_add(&vacc[12 * l + lane], mine, meta);
         }
     }
-#undef KT
     // ---- the workgroup whose atomics are performed last runs the finish stage.  Every wave first waits until its own
     //      atomics have been performed (vmcnt covers them), then one lane takes a ticket on the XCD's counter and the
     //      last of an XCD one on the top counter: two levels, because a few thousand arrivals on ONE address serialise
@@ -1988,8 +2012,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         // (the -DVB_TIMELINE profiling build parks its per-wave records here: keep room for them)
         if ((rc = ctx->vb_spill.reserve(std::max((size_t)ctx->vb_spill_cap * sizeof(VbItem), (size_t)1 << 20)))) return rc;
     }
-    // link boxes (one 64-byte line each) | per-view tile rectangles: vpre [B + 1] | vrect [B]
-    if ((rc = ctx->vb_units.reserve(((size_t)VB_LBOX_STRIDE * B * L + 2 * (size_t)B + 1) * sizeof(int)))) return rc;
+    if ((rc = ctx->vb_units.reserve((size_t)VB_LBOX_STRIDE * B * L * sizeof(int)))) return rc;  // link boxes (one 64-byte line each)
     {  // a bound reference mask's cached sums: tsum [B][nt] | vtot [B] | flag
         BinGeom g0 = make_geom(H, W, L);
         if ((rc = ctx->vb_refsum.reserve(((size_t)B * g0.nt + B + 1) * sizeof(long long)))) return rc;
@@ -2004,7 +2027,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         ctx->vb_jcap = (int)want;
         const size_t nslot = (size_t)ctx->vb_jcap;
         if ((rc = ctx->vb_jobs.reserve(nslot * (VB_RN * sizeof(unsigned) + VB_RH * sizeof(u64) + sizeof(int) + sizeof(int4)) +
-                                       (size_t)B * L * sizeof(int) + 32))) return rc;
+                                       (2 * (size_t)B * L + 1) * sizeof(int) + 32))) return rc;
     }
     {  // heavy-job hint: generation + two counts | two lists | stamp table
         BinGeom g = make_geom(H, W, L);
@@ -2197,14 +2220,12 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     u64* jcov = (u64*)ctx->vb_jobs.ptr;
     unsigned* jid = (unsigned*)(jcov + nslot * VB_RH);
     int* jdesc = (int*)(jid + nslot * VB_RN);
-    int* jbase = jdesc + nslot;
-    int4* slow_list = (int4*)(((uintptr_t)(jbase + (size_t)B * L) + 15) & ~(uintptr_t)15);  // [nslot] jobs for vb_slow_kernel
+    int* jbase = jdesc + nslot;                               // [B * L + 1] first job of every (view, link)
+    unsigned* jutile = (unsigned*)(jbase + (size_t)B * L + 1);  // [B * L] its tile range
+    int4* slow_list = (int4*)(((uintptr_t)(jutile + (size_t)B * L) + 15) & ~(uintptr_t)15);  // [nslot] jobs for vb_slow_kernel
     const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
-    VbViewRects vr;
-    vr.vpre = lbox + (size_t)VB_LBOX_STRIDE * B * L;
-    vr.vrect = (unsigned*)(vr.vpre + B + 1);
-    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jid, jdesc, jbase, ctx->vb_jcap, meta, dbg, hv,
-                                                (long long*)ctx->vb_spill.ptr, vr, posc, V, si, jcov, slow_list, heavy_t);
+    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg, hv,
+                                                (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t);
     EHR_LAUNCH_CHECK();
     // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
     vb_slow_kernel<<<ctx->num_cus, 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, slow_list, meta);
@@ -2226,18 +2247,18 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     const long long* tsum = sparse ? (const long long*)ctx->vb_refsum.ptr : nullptr;
     const long long* vtot = sparse ? tsum + (size_t)B * g.nt : nullptr;
     const int* ref_flag = sparse ? (const int*)(vtot + B) : nullptr;
-    const size_t dyn = sparse ? (2 * (size_t)B + 1) * sizeof(int) : 0;
+    const size_t dyn = (2 * (size_t)B * L + 1) * sizeof(int);  // link tables
     const int4* tri4 = (const int4*)ctx->vb_idx.ptr;
     if (tail) {
         vb_tile_kernel<true><<<nwg, 256, dyn, stream>>>(g, B, posc, V, T, verts, tri4, tri4 + T, lbox, jid, jcov, jdesc, jbase,
-                                                      ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok,
-                                                      spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, vr, loss,
+                                                      jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok,
+                                                      spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss,
                                                       grad_mvp, *tail);
     } else {
         StepTail none = {};
         vb_tile_kernel<false><<<nwg, 256, dyn, stream>>>(g, B, posc, V, T, verts, tri4, tri4 + T, lbox, jid, jcov, jdesc, jbase,
-                                                       ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok,
-                                                       spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, vr, loss,
+                                                       jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok,
+                                                       spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss,
                                                        grad_mvp, none);
     }
     EHR_LAUNCH_CHECK();
