@@ -48,7 +48,7 @@ constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min 
                                       // heavy: next step a whole workgroup takes it.  Units, not triangles: a tile of 130 long
                                       // thin triangles (7000 units) keeps a wave busy for 60 us, one of 380 small ones for 25
 constexpr int VB_HEAVY_CAP = 4096;    // heavy jobs remembered per step
-
+constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
 constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
 constexpr u64 VB_EMPTY = ~0ull;
 #define VB_SMALL_BOX 16                // pixel boxes up to this size are walked by the triangle's own lane
@@ -834,6 +834,11 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
     return n;
 }
 
+struct alignas(16) VbResolveLds {  // per wave of the resolve kernel
+    unsigned ids[VB_RN];         // triangle id of each region pixel (all-ones = uncovered), copied from the job's slot
+    float pairA[2 * VB_RN];      // blend weight of pair (q, d) at [d * RN + q]
+    unsigned short hits[2 * VB_RN];
+};
 
 // tiles (+ 1-pixel halo) a link's pixel box touches: the jobs of that (view, link)
 __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W, int H, int& tx0, int& ty0, int& nx, int& ny) {
@@ -853,8 +858,9 @@ struct VbJobArgs {
     const int4* cvidx;    // [NC * 64] {v0, v1, v2, triangle} of every cluster slot
     const int* lcoff;     // LDS: first cluster of every link
     unsigned* jid;        // job slots: triangle ids of the region's pixels
-    u64* jcov;            //            coverage rows
+    u64* jcov;            //            coverage bitmap (region-linear, VB_WORDS words)
     int* jdesc;
+    int* jn;
     int NC, V, W, H, L;
 };
 
@@ -965,7 +971,14 @@ __device__ __forceinline__ void vb_publish(const VbJobArgs& A, const u64* key_, 
         const unsigned i = 64u * k + lane;
         if (i < (unsigned)VB_RN) dst[i] = (unsigned)key_[i];  // low word = triangle id; all-ones stays all-ones
     }
-    if (lane < VB_RH) A.jcov[(size_t)job * VB_RH + lane] = cov_[lane];
+    // coverage in region-linear order (bit i = region pixel i), what the resolve kernel's bit arithmetic works on
+#pragma unroll
+    for (int k = 0; k < VB_WORDS; k++) {
+        const unsigned i = 64u * k + lane;
+        const unsigned row = i / VB_RW, col = i - row * VB_RW;
+        const u64 w = __ballot(i < (unsigned)VB_RN && ((cov_[row < (unsigned)VB_RH ? row : 0] >> col) & 1ull));
+        if (lane == 0) A.jcov[(size_t)job * VB_WORDS + k] = w;
+    }
     if (lane == 0) A.jdesc[job] = u | (tx << 9) | (ty << 19);
 }
 
@@ -996,6 +1009,7 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
     if (drawn > 0) {
         vb_publish(A, S.key, S.cov, job, u, tx, ty);
     } else if (lane == 0) {
+        A.jn[job] = -1;
         A.jdesc[job] = -1;
     }
 }
@@ -1011,8 +1025,8 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
 #define VB_JOB_WAVES 4
 #endif
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
-vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, unsigned* __restrict__ jid,
-              int* __restrict__ jdesc, int* __restrict__ jbase, unsigned* __restrict__ jutile, int jcap,
+vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
+              unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, unsigned* __restrict__ jutile, int jcap,
               int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline,
               const float4* __restrict__ posc, int V, VbSlotIdx si, u64* __restrict__ jcov,
               int4* __restrict__ slow_list, int heavy_t) {
@@ -1079,6 +1093,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     A.jid = jid;
     A.jcov = jcov;
     A.jdesc = jdesc;
+    A.jn = jn;
     A.NC = cl.NC;
     A.V = V;
     A.W = W;
@@ -1142,6 +1157,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             } else if (any_drawn) {
                 vb_publish(A, S0.key, S0.cov, job, u, tx, ty);
             } else if (lane == 0) {
+                jn[job] = -1;
                 jdesc[job] = -1;
             }
             if (lane == 0) {
@@ -1233,6 +1249,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         if (nsurv >= heavy_t && lane == 0) remember_heavy(dense_id);
         if (drawn == 0) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
+                jn[slot] = -1;
                 jdesc[slot] = -1;
             }
             continue;
@@ -1263,7 +1280,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 // Stage 2a (normally empty): the jobs the lean code put aside, one wave each, with the general triangle path.
 __global__ void __launch_bounds__(256)
 vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ posc, int V, VbSlotIdx si,
-               unsigned* __restrict__ jid, u64* __restrict__ jcov, int* __restrict__ jdesc,
+               unsigned* __restrict__ jid, u64* __restrict__ jcov, int* __restrict__ jdesc, int* __restrict__ jn,
                const int4* __restrict__ slow_list, const int* __restrict__ meta) {
     const int n = *vb_line(const_cast<int*>(meta), 17);
     if (n == 0) return;
@@ -1277,6 +1294,7 @@ vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ p
     A.jid = jid;
     A.jcov = jcov;
     A.jdesc = jdesc;
+    A.jn = jn;
     A.NC = cl.NC;
     A.V = V;
     A.W = g.W;
@@ -1287,6 +1305,238 @@ vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ p
         const int4 e = slow_list[i];
         vb_job_slow(A, lds_all[wave], e.x, e.y, e.z, e.w);
     }
+}
+
+// Stage 2b: one WAVE per DRAWN job, persistent waves over the per-XCD lists the job kernel appended to.  From the
+// triangle ids of the job's region (tile + 1-pixel halo): covered/uncovered pixel pairs by wave-uniform bit arithmetic on
+// the coverage bitmap, silhouette analysis of the compacted hits (restates nvdiffrast's antialias mesh kernel), gather of
+// the link's antialiased value per pixel in the oracle's order.  Leaves in the job's slot the 256 values (jval), the
+// blended pairs the backward pass needs (jitems) and their number (jn; -1 = the link contributes nothing here).
+// A kernel of its own because its registers (36 wave-uniform 64-bit bitmaps, 24 floats of vertex positions per hit)
+// and the rasterizer's do not fit 128 VGPRs together: fused, the job kernel kept 350 bytes per lane in scratch and its
+// 4096 waves' 91 MB of scratch evicted each other from the 4 MB L2s.
+__global__ void __launch_bounds__(256)
+vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, const int4* __restrict__ tri4,
+                  const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const u64* __restrict__ jcov,
+                  const int* __restrict__ jdesc,
+                  int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems,
+                  int* __restrict__ jspill, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
+                  int* __restrict__ meta, int dbg) {
+    __shared__ VbResolveLds lds_all[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    VbResolveLds& S = lds_all[wave];
+#define KT(i) (S.ids[i])
+    const int W = g.W, H = g.H, L = g.L;
+    (void)B;
+    // XCD-aware like the job kernel (workgroup w runs on XCD w % 8; the slots of an eighth of the job list were written
+    // through that XCD's L2), one job per wave and turn
+    const int total = min(meta[5], jcap), per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
+    const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
+    const int step = (int)(gridDim.x >> 3) * 4;
+    for (int job = jbeg + (int)(blockIdx.x >> 3) * 4 + wave; job < jend; job += step) {
+        const size_t slot = (size_t)job;
+        // the ids are requested together with the descriptor (one round trip; an undrawn slot holds stale ids, unused)
+        unsigned idw[VB_WORDS];
+        {
+            const unsigned* const src = jid + slot * VB_RN;
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                const unsigned i = 64u * k + lane;
+                idw[k] = (i < (unsigned)VB_RN) ? src[i] : 0xffffffffu;
+            }
+        }
+        const u64 mycw = (lane < VB_WORDS) ? jcov[slot * VB_WORDS + lane] : 0ull;  // coverage bitmap of the region
+        const int de = jdesc[job];
+        if (de < 0) continue;  // nothing drawn: the job kernel has already marked the slot
+        const int u = de & 511, tx = (de >> 9) & 1023, ty = (de >> 19) & 4095;
+        const int b = u / L;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        u64 C[VB_WORDS];  // bit i = region pixel i is covered
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mycw, k);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mycw >> 32), k);
+            C[k] = ((u64)hi << 32) | lo;
+        }
+        VB_WAVE_SYNC();  // the previous job's reads of S are complete
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            // covered pixels whose triangle was never asked for (no uncovered neighbour) carry a marker instead of an id
+            if (i < (unsigned)VB_RN)
+                S.ids[i] = (idw[k] != 0xffffffffu) ? idw[k] : (((C[k] >> lane) & 1ull) ? VB_ID_COVERED : 0xffffffffu);
+        }
+        const int r = lane >> 3, c4 = (lane & 7) * 4;
+        const int myq = (r + 1) * VB_RW + (c4 + 1);
+        const float4* const pv = posc + (size_t)b * V;
+        int nitems = 0;       // wave-uniform
+        int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
+        VB_WAVE_SYNC();
+        for (int i = lane; i < 2 * VB_RN; i += 64) S.pairA[i] = 0.f;
+        // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
+        u64 Iw[VB_WORDS];
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            const unsigned i = 64u * k + lane;
+            const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
+            const int x = rx0 + qx, y = ry0 + qy;
+            Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
+        }
+        u64 Vh[VB_WORDS], Vv[VB_WORDS];
+        {
+            // compile-time bitmaps (forced: a constexpr call with a loop index is otherwise evaluated at run time)
+            constexpr u64 KH[VB_WORDS] = {vb_word_h(0), vb_word_h(1), vb_word_h(2), vb_word_h(3), vb_word_h(4), vb_word_h(5)};
+            constexpr u64 KV[VB_WORDS] = {vb_word_v(0), vb_word_v(1), vb_word_v(2), vb_word_v(3), vb_word_v(4), vb_word_v(5)};
+            static_assert(VB_WORDS == 6, "tables above");
+            u64 s1[VB_WORDS], s34[VB_WORDS];
+            vb_shr<1>(Iw, s1);
+            vb_shr<VB_RW>(Iw, s34);
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                Vh[k] = Iw[k] & s1[k] & KH[k];
+                Vv[k] = Iw[k] & s34[k] & KV[k];
+            }
+        }
+        // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
+        //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
+        u64 Hw[2 * VB_WORDS];
+        int nh = 0;
+        {
+            u64 s1[VB_WORDS], s34[VB_WORDS];
+            vb_shr<1>(C, s1);
+            vb_shr<VB_RW>(C, s34);
+#pragma unroll
+            for (int k = 0; k < VB_WORDS; k++) {
+                Hw[k] = (C[k] ^ s1[k]) & Vh[k];
+                Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
+                nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
+            }
+        }
+        VB_WAVE_SYNC();
+        float val[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) val[j] = (KT(myq + j) != 0xffffffffu) ? 1.f : 0.f;
+        if (dbg & 2) nh = 0;
+        if (nh != 0) {
+            // ---- dense hit list, ordered by (direction, region index)
+            {
+                int base = 0;
+#pragma unroll
+                for (int s = 0; s < 2 * VB_WORDS; s++) {
+                    const u64 w = Hw[s];
+                    if (w) {
+                        if ((w >> lane) & 1)
+                            S.hits[base + vb_mbcnt(w)] = (unsigned short)(((s % VB_WORDS) * 64 + lane) | ((s / VB_WORDS) << 15));
+                        base += __popcll(w);
+                    }
+                }
+            }
+            VB_WAVE_SYNC();
+            // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
+            for (int hbase = 0; hbase < nh; hbase += 64) {
+                const int h = hbase + lane;
+                VbItem it;
+                it.packed = 0;
+                it.v1 = 0;
+                it.v2 = 0;
+                it.alpha = 0.f;
+                bool keep = false;
+                if (h < nh) {
+                    const int hq = S.hits[h];
+                    const int d = hq >> 15, q = hq & 0x7fff;
+                    const int qy = q / VB_RW, qx = q - qy * VB_RW;
+                    const int nq = q + (d ? VB_RW : 1);
+                    const unsigned k0 = KT(q), k1 = KT(nq);
+                    const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
+                    const int t = min((int)(chose0 ? k0 : k1) & 0x7fffffff, T - 1);  // (always a triangle id: the pixel has an uncovered neighbour)
+                    int px = rx0 + qx, py = ry0 + qy;
+                    if (!chose0) {
+                        px += 1 - d;
+                        py += d;
+                    }
+                    float4 p[3], o[3];
+                    const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
+                    const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
+#pragma unroll
+                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
+                    const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
+                    if (a.found) {
+                        S.pairA[d * VB_RN + q] = a.alpha;
+                        // keep for the backward pass if the destination pixel is interior to this tile
+                        const int oq = (a.alpha > 0.f) ? q : nq;
+                        const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+                        const bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
+                        if (oi && a.alpha != 0.f) {
+                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
+                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
+                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
+                            it.alpha = a.alpha;
+                            keep = want_grad != 0;
+                        }
+                    }
+                }
+                const u64 km = __ballot(keep);
+                if (km) {
+                    const int at = nitems + vb_mbcnt(km);
+                    const int nnew = nitems + __popcll(km);
+                    if (nnew > VB_JOB_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this job
+                        int base = 0;
+                        if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
+                        spill_base = __builtin_amdgcn_readfirstlane(base);
+                    }
+                    // items this job can keep: its slot, then its block of the spill pool as far as the pool reaches
+                    int room = VB_JOB_ITEMS;
+                    if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
+                    if (keep) {
+                        if (at < VB_JOB_ITEMS)
+                            jitems[slot * VB_JOB_ITEMS + at] = it;
+                        else if (at < room)
+                            spill[spill_base + (at - VB_JOB_ITEMS)] = it;
+                        else
+                            meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
+                    }
+                    nitems = min(nnew, room);  // never more than were stored: the composite kernel reads exactly these
+                }
+            }
+            VB_WAVE_SYNC();
+            // ---- gather the antialiased value of this link at my pixels (fixed order: down, left, right, up pair)
+            {
+                float cn[6], cd[4], cu[4];
+#pragma unroll
+                for (int j = 0; j < 6; j++) cn[j] = (KT(myq - 1 + j) != 0xffffffffu) ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    cd[j] = (KT(myq - VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                    cu[j] = (KT(myq + VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float c = cn[j + 1];
+                    float v = c;
+                    float a;
+                    a = S.pairA[VB_RN + myq + j - VB_RW];
+                    if (a < 0.f) v += a * (c - cd[j]);
+                    a = S.pairA[myq + j - 1];
+                    if (a < 0.f) v += a * (c - cn[j]);
+                    a = S.pairA[myq + j];
+                    if (a > 0.f) v += a * (cn[j + 2] - c);
+                    a = S.pairA[VB_RN + myq + j];
+                    if (a > 0.f) v += a * (cu[j] - c);
+                    val[j] = v;
+                }
+            }
+        }
+        // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
+        const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
+        if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
+        if (lane == 0) {
+            jn[slot] = nz ? nitems : -1;
+            if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
+        }
+    }
+#undef KT
 }
 
 // Per (view, tile) of a BOUND reference mask: the fixed-point value the composite kernel would add to the view's frame
@@ -1341,486 +1591,221 @@ vb_refsum_kernel(BinGeom g, int B, const float* __restrict__ ref, int vec_ok, lo
     }
 }
 
-// Stage 3: one WAVE per 32x8 tile, all the links whose job drew something there TOGETHER: from every such job's coverage
-// rows the covered / uncovered pixel pairs (wave-uniform bit arithmetic) go into one hit list with the covered pixel's
-// triangle id; the silhouette analysis (restates nvdiffrast's antialias mesh kernel) runs over that list 64 hits at a
-// time; then per link the antialiased value of every pixel is gathered in the oracle's order, the links' values summed
-// in link order, clamp, frame loss, mask, and the blended pairs back-propagated to 12 numbers per link which go to the
-// view's fixed-point accumulators.  Round 2 ran this as two kernels (per-job resolve -> per-tile composite) with the
-// per-link value tiles and pair lists passing through HBM.  What bounds the stage is its chain of dependent memory round
-// trips (~1 us each: the data was written by the previous kernel through another XCD's L2), so the tile is organised
-// around the shortest chain: link tables in LDS -> {descriptors, coverage rows, ids} of all links at once -> triangle
-// indices -> vertices -> [composite] -> the pairs' vertices -> atomics, whatever the number of links.
-// 4 pixels per lane, float4 image accesses, no workgroup barriers in the tile loop.  Persistent waves over
-//   tsum == NULL: every tile of every view (tiles no link draws into just stream: mask = 0, loss += ref^2);
+// Stage 3: one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers): sums the links'
+// values in link order, clamps, accumulates the frame loss, writes the mask, and back-propagates the tile's blended
+// pairs to 12 numbers per link which go to the view's fixed-point accumulators.  Persistent waves over
+//   tsum == NULL: every tile of every view (tiles no link box touches just stream: mask = 0, loss += ref^2);
 //   tsum != NULL (bound reference mask, no mask output): the tiles of the views' link rectangles only; a tile that no
-//                 link draws into is skipped without touching the image -- its cached sum is already in vtot.
+//                 link contributes to is skipped without touching the image -- its cached sum is already in vtot.
 // The workgroup that finishes LAST (a ticket per XCD, then one over the XCDs) runs the finish stage: accumulators ->
 // loss / grad_mvp [-> pose backward -> Adam], re-arms the link boxes.  vec_ok: W % 4 == 0 and 16-byte aligned images.
-#ifndef VB_TILE_WAVES
-#define VB_TILE_WAVES 4
-#endif
-constexpr int VB_TILE_ITEMS = 96;   // blended pairs of a tile (all links) kept in LDS; the rest spills to a global pool
-constexpr int VB_TILE_HITS = 704;   // hits analysed together (>= 2 * VB_RN: one link's worst case)
-constexpr int VB_TILE_GROUP = 8;    // links analysed together
-struct alignas(16) VbTileLds {      // per wave of the tile kernel
-    union {
-        unsigned ids[VB_RN];        // collecting hits: triangle id of each region pixel of the current link
-        float pairA[2 * VB_RN];     // gathering values: blend weight of pair (q, d) at [d * RN + q]
-        float gpix[EHR_TILE_W * EHR_TILE_H];  // backward: the tile's loss gradient
-    };
-    unsigned ht[VB_TILE_HITS];      // per hit: triangle id of its covered pixel; after the analysis the blend weight
-    unsigned short hq[VB_TILE_HITS];  // per hit: q (region index of pixel 0) | d << 9 | pixel 0 is the covered one << 10 | group slot << 11
-    VbItem items[VB_TILE_ITEMS];    // blended pairs of all links of the tile (link in bits 15-19 of `packed`)
-    u64 covs[VB_TILE_GROUP][VB_RH]; // coverage rows of the group's links
-    int hstart[VB_TILE_GROUP + 1];  // first hit of every link of the group
-};
-static_assert(VB_TILE_HITS >= 2 * VB_RN, "one link's hits must fit");
-
 template <bool TAIL>
-__global__ void __launch_bounds__(256, VB_TILE_WAVES)
-vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, const float* __restrict__ verts,
-               const int4* __restrict__ tri4, const int4* __restrict__ opp4, int* __restrict__ lbox,
-               const unsigned* __restrict__ jid, const u64* __restrict__ jcov, const int* __restrict__ jdesc,
-               const int* __restrict__ jbase, const unsigned* __restrict__ jutile, int jcap, const float* __restrict__ ref,
-               float* __restrict__ mask, long long* __restrict__ facc, int nls, int want_grad, int vec_ok,
-               VbItem* __restrict__ spill, int spill_cap, int* __restrict__ meta, int dbg,
-               const long long* __restrict__ tsum, const long long* __restrict__ vtot, const int* __restrict__ ref_flag,
-               float* __restrict__ loss, float* __restrict__ grad_mvp, StepTail tail) {
-    __shared__ VbTileLds lds_all[4];
+__global__ void __launch_bounds__(256, 6)
+vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const float* __restrict__ verts,
+                    int* __restrict__ lbox, const int* __restrict__ jn, const float* __restrict__ jval,
+                    const VbItem* __restrict__ jitems, const int* __restrict__ jspill, const int* __restrict__ jbase,
+                    const unsigned* __restrict__ jutile, int jcap, const float* __restrict__ ref,
+                    float* __restrict__ mask, long long* __restrict__ facc, int nls, int want_grad, int vec_ok,
+                    const VbItem* __restrict__ spill, int spill_cap, int* __restrict__ meta, int dbg,
+                    const long long* __restrict__ tsum, const long long* __restrict__ vtot,
+                    const int* __restrict__ ref_flag, float* __restrict__ loss,
+                    float* __restrict__ grad_mvp, StepTail tail) {
+    __shared__ float gpix_all[4][EHR_TILE_W * EHR_TILE_H];
     extern __shared__ int s_dyn[];  // [U + 1] first job of every (view, link) | [U] its tile range
-    const int L = g.L, U = B * L;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const gpix = gpix_all[wave];
+    const int W = g.W, H = g.H, L = g.L, U = B * L;
     int* const s_jbase = s_dyn;
     unsigned* const s_utile = reinterpret_cast<unsigned*>(s_dyn + U + 1);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    VbTileLds& S = lds_all[wave];
-    const int W = g.W, H = g.H;
     const bool sparse = tsum != nullptr;
     for (int i = tid; i <= U; i += 256) s_jbase[i] = jbase[i];
     for (int i = tid; i < U; i += 256) s_utile[i] = jutile[i];
     __syncthreads();
     // work items: every tile of every view, or (bound reference) the JOBS -- a job stands for its tile if no link before
     // its own has a job there, so that every tile with a job comes up exactly once and the others never
-    const int nitems_all = sparse ? min(s_jbase[U], jcap) : B * g.nt;
-    // XCD-aware order (locality only): every XCD takes a contiguous run of tiles
+    const int nitems = sparse ? min(s_jbase[U], jcap) : B * g.nt;
+    // XCD-aware order (locality only): every XCD takes a contiguous run of items
     const int nwg = gridDim.x;
-    const int per_xcd = (nitems_all + 7) >> 3, xcd = blockIdx.x & 7;
-    const int ibeg = xcd * per_xcd, iend = min(ibeg + per_xcd, nitems_all);
+    const int per_xcd = (nitems + 7) >> 3, xcd = blockIdx.x & 7;
+    const int ibeg = xcd * per_xcd, iend = min(ibeg + per_xcd, nitems);
     const int istep = (nwg >> 3) * 4;
     const int acc_stride = 12 * L + nls * VB_LOSS_STRIDE;
     const int r = lane >> 3, c4 = (lane & 7) * 4;
-    const int myq = (r + 1) * VB_RW + (c4 + 1);
     for (int item = ibeg + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += istep) {
-        int b, tx, ty;
-        if (sparse) {
-            int lo = 0, hi = U - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_jbase[mid] <= item)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-            b = lo / L;
-            const unsigned ut = s_utile[lo];
-            const int nx = (int)(ut >> 22), k = item - s_jbase[lo];
-            ty = (int)((ut >> 10) & 4095u) + k / nx;
-            tx = (int)(ut & 1023u) + k - (k / nx) * nx;
-            // owner of the tile = the job of the first link that has one there
-            bool prior = false;
-            if (lane < lo - b * L) {
-                const int u2 = b * L + lane;
-                const unsigned u2t = s_utile[u2];
-                const int n2 = s_jbase[u2 + 1] - s_jbase[u2];
-                const int ax0 = u2t & 1023u, ay0 = (u2t >> 10) & 4095u, anx = u2t >> 22;
-                prior = n2 > 0 && tx >= ax0 && tx < ax0 + anx && ty >= ay0 && ty < ay0 + n2 / anx;
-            }
-            if (__ballot(prior)) continue;
-        } else {
-            b = item / g.nt;
-            const int tile = item - b * g.nt;
-            tx = tile % g.ntx;
-            ty = tile / g.ntx;
+    int b, tx, ty;
+    if (sparse) {
+        int lo = 0, hi = U - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_jbase[mid] <= item)
+                lo = mid;
+            else
+                hi = mid - 1;
         }
-        const int tile = ty * g.ntx + tx;
-        long long* const vacc = facc + (size_t)b * acc_stride;
-        long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
-        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
-        // links whose tile range (the tiles + halo their screen box touches: the jobs stage 2 ran) contains this tile
-        // (lane l tests link l, from the tables in LDS), and whether the job drew anything (its descriptor)
-        int myslot = -1, myde = -1;
+        b = lo / L;
+        const unsigned ut = s_utile[lo];
+        const int nx = (int)(ut >> 22), k = item - s_jbase[lo];
+        ty = (int)((ut >> 10) & 4095u) + k / nx;
+        tx = (int)(ut & 1023u) + k - (k / nx) * nx;
+        // owner of the tile = the job of the first link that has one there
+        bool prior = false;
+        if (lane < lo - b * L) {
+            const int u2 = b * L + lane;
+            const unsigned u2t = s_utile[u2];
+            const int n2 = s_jbase[u2 + 1] - s_jbase[u2];
+            const int ax0 = u2t & 1023u, ay0 = (u2t >> 10) & 4095u, anx = u2t >> 22;
+            prior = n2 > 0 && tx >= ax0 && tx < ax0 + anx && ty >= ay0 && ty < ay0 + n2 / anx;
+        }
+        if (__ballot(prior)) continue;
+    } else {
+        b = item / g.nt;
+        const int tile = item - b * g.nt;
+        tx = tile % g.ntx;
+        ty = tile / g.ntx;
+    }
+    const int tile = ty * g.ntx + tx;
+    long long* const vacc = facc + (size_t)b * acc_stride;
+    long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
+    const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+    // links whose tile range (the tiles + halo their screen box touches: the jobs stage 2 ran) contains this tile (lane l
+    // tests link l, from the tables in LDS)
+    unsigned tmask;
+    int myn = -1, myslot = 0;
+    {
         if (lane < L && !(dbg & 1)) {
             const int u = b * L + lane;
             const unsigned ut = s_utile[u];
             const int j0 = s_jbase[u], n = s_jbase[u + 1] - j0;
             const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
             if (n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && ty < ty0 + n / nx) {
-                const int sl = j0 + (ty - ty0) * nx + (tx - tx0);
-                if (sl < jcap) {
-                    myslot = sl;
-                    myde = jdesc[sl];
-                }
+                myslot = j0 + (ty - ty0) * nx + (tx - tx0);
+                if (myslot < jcap) myn = jn[myslot];
             }
         }
-        const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
-        const bool row_in = iy < H;
-        const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
-        float rf[4] = {0.f, 0.f, 0.f, 0.f};
-        bool pin[4];
+        tmask = (unsigned)__ballot(myn >= 0);  // links that contribute a value here
+    }
+    if (sparse && tmask == 0) continue;  // nothing drawn here: the tile's cached sum(ref^2) is part of vtot already
+    const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
+    const bool row_in = iy < H;
+    const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
+    float rf[4] = {0.f, 0.f, 0.f, 0.f};
+    bool pin[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) pin[j] = row_in && (ix + j) < W;
-        unsigned todo = (unsigned)__ballot(myde >= 0);  // links that drew something here
-        if (sparse && todo == 0) continue;
+    for (int j = 0; j < 4; j++) pin[j] = row_in && (ix + j) < W;
+    if (vec_ok) {
+        if (pin[0]) {
+            const float4 r4 = *reinterpret_cast<const float4*>(ref + im);
+            rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (pin[j]) rf[j] = ref[im + j];
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned todo = tmask;
+    while (todo) {  // sum in link order
+        const int l = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const size_t slot = (size_t)vb_readlane(myslot, l);
+        const float4 v4 = *reinterpret_cast<const float4*>(jval + slot * 256 + r * EHR_TILE_W + c4);
+        acc[0] += v4.x;
+        acc[1] += v4.y;
+        acc[2] += v4.z;
+        acc[3] += v4.w;
+    }
+    // ---- composite, loss, mask write (image convention: row 0 = top)
+    float e2 = 0.f, gv[4];
+    float mv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        gv[j] = 0.f;
+        mv[j] = 0.f;
+        if (pin[j]) {
+            const float m = acc[j] > 1.f ? 1.f : acc[j];
+            const float e = m - rf[j];
+            e2 += e * e;
+            gv[j] = (acc[j] <= 1.f) ? 2.f * e : 0.f;
+            mv[j] = m;
+        }
+    }
+    if (mask) {
         if (vec_ok) {
-            if (pin[0]) {
-                const float4 r4 = *reinterpret_cast<const float4*>(ref + im);
-                rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
-            }
+            if (pin[0]) *reinterpret_cast<float4*>(mask + im) = make_float4(mv[0], mv[1], mv[2], mv[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (pin[j]) rf[j] = ref[im + j];
+                if (pin[j]) mask[im + j] = mv[j];
         }
-        const float4* const pv = posc + (size_t)b * V;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int nit = 0;          // wave-uniform: blended pairs of the tile so far
-        int spill_base = -1;  // wave-uniform: this tile's block of the spill pool, once one was needed
-        int room = VB_TILE_ITEMS;
-        unsigned bmask = 0;   // links with blended pairs to back-propagate
-        // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
-        u64 Vh[VB_WORDS], Vv[VB_WORDS];
-        if (todo) {
-            u64 Iw[VB_WORDS];
-#pragma unroll
-            for (int k = 0; k < VB_WORDS; k++) {
-                const unsigned i = 64u * k + lane;
-                const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
-                const int x = rx0 + qx, y = ry0 + qy;
-                Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
-            }
-            // compile-time bitmaps (forced: a constexpr call with a loop index is otherwise evaluated at run time)
-            constexpr u64 KH[VB_WORDS] = {vb_word_h(0), vb_word_h(1), vb_word_h(2), vb_word_h(3), vb_word_h(4), vb_word_h(5)};
-            constexpr u64 KV[VB_WORDS] = {vb_word_v(0), vb_word_v(1), vb_word_v(2), vb_word_v(3), vb_word_v(4), vb_word_v(5)};
-            static_assert(VB_WORDS == 6, "tables above");
-            u64 s1[VB_WORDS], s34[VB_WORDS];
-            vb_shr<1>(Iw, s1);
-            vb_shr<VB_RW>(Iw, s34);
-#pragma unroll
-            for (int k = 0; k < VB_WORDS; k++) {
-                Vh[k] = Iw[k] & s1[k] & KH[k];
-                Vv[k] = Iw[k] & s34[k] & KV[k];
-            }
+    }
+    {
+        const float s = wave_sum(e2);
+        if (lane == 0) {
+            if (sparse)
+                fix_add_delta(lacc, s, tsum[(size_t)b * g.nt + tile], meta);
+            else
+                fix_add(lacc, s, meta);
         }
-        while (todo) {  // groups of links (normally one): as many as fit the hit list
-            // ---- (1) collect: per link the pairs with exactly one covered pixel.  Only those can change the result:
-            //      with constant colour inside a link a blend between two covered pixels is alpha * (1 - 1) = 0 in value
-            //      and in gradient.  The next link's ids and coverage rows are requested before this one's are used.
-            unsigned grp = 0;      // links of this group
-            int ng = 0, nhit = 0;  // wave-uniform
-            unsigned idw[VB_WORDS];
-            u64 myrow = 0;
-            auto fetch = [&](int l) {
-                const size_t slot = (size_t)vb_readlane(myslot, l);
-                const unsigned* const src = jid + slot * VB_RN;
-#pragma unroll
-                for (int k = 0; k < VB_WORDS; k++) {
-                    const unsigned i = 64u * k + lane;
-                    idw[k] = (i < (unsigned)VB_RN) ? src[i] : 0xffffffffu;
-                }
-                myrow = (lane < VB_RH) ? jcov[slot * VB_RH + lane] : 0ull;
-            };
-            fetch(__ffs(todo) - 1);
-            while (todo && ng < VB_TILE_GROUP) {
-                const int l = __ffs(todo) - 1;
-                // coverage in region-linear order (bit i = region pixel i), assembled from the rows: wave-uniform shifts
-                u64 C[VB_WORDS];
-                {
-                    u64 crow[VB_RH];
-#pragma unroll
-                    for (int rr = 0; rr < VB_RH; rr++) {
-                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)myrow, rr);
-                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(myrow >> 32), rr);
-                        crow[rr] = (((u64)hi << 32) | lo) & VB_ROW_MASK;
-                    }
-#pragma unroll
-                    for (int k = 0; k < VB_WORDS; k++) {
-                        u64 w = 0;
-#pragma unroll
-                        for (int rr = 0; rr < VB_RH; rr++) {
-                            const int sh = VB_RW * rr - 64 * k;  // compile-time
-                            if (sh >= 0 && sh < 64) w |= crow[rr] << sh;
-                            if (sh < 0 && -sh < VB_RW) w |= crow[rr] >> (-sh);
-                        }
-                        C[k] = w;
-                    }
-                }
-                u64 Hw[2 * VB_WORDS];
-                int nh = 0;
-                {
-                    u64 s1[VB_WORDS], s34[VB_WORDS];
-                    vb_shr<1>(C, s1);
-                    vb_shr<VB_RW>(C, s34);
-#pragma unroll
-                    for (int k = 0; k < VB_WORDS; k++) {
-                        Hw[k] = (C[k] ^ s1[k]) & Vh[k];
-                        Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
-                        nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
-                    }
-                }
-                if (dbg & 2) nh = 0;
-                if (nhit + nh > VB_TILE_HITS) break;  // the list is full: analyse this group, the link opens the next one
-                VB_WAVE_SYNC();  // the previous link's reads of S.ids are complete
-                if (lane < VB_RH) S.covs[ng][lane] = myrow & VB_ROW_MASK;
-#pragma unroll
-                for (int k = 0; k < VB_WORDS; k++) {
-                    const unsigned i = 64u * k + lane;
-                    if (i < (unsigned)VB_RN) S.ids[i] = idw[k];
-                }
-                todo &= todo - 1;
-                if (todo) fetch(__ffs(todo) - 1);  // (a link that opens the next group is fetched again there)
-                VB_WAVE_SYNC();
-                if (nh != 0) {  // dense hit list, ordered by (direction, region index)
-                    int base = nhit;
-#pragma unroll
-                    for (int s = 0; s < 2 * VB_WORDS; s++) {
-                        const u64 w = Hw[s];
-                        if (w) {
-                            if ((w >> lane) & 1) {
-                                const int q = (s % VB_WORDS) * 64 + lane, d = s / VB_WORDS;
-                                const bool c0 = (C[s % VB_WORDS] >> lane) & 1ull;  // pixel 0 is the covered one of the two
-                                const int at = base + vb_mbcnt(w);
-                                S.hq[at] = (unsigned short)(q | (d << 9) | ((c0 ? 1 : 0) << 10) | (ng << 11));
-                                S.ht[at] = S.ids[c0 ? q : q + (d ? VB_RW : 1)];
-                            }
-                            base += __popcll(w);
-                        }
-                    }
-                }
-                if (lane == 0) S.hstart[ng] = nhit;
-                nhit += nh;
-                grp |= 1u << l;
-                ng++;
-            }
-            if (lane == 0) S.hstart[ng] = nhit;
-            VB_WAVE_SYNC();
-            // ---- (2) silhouette analysis of all the group's hits (restates nvdiffrast's antialias mesh kernel), 64 per round
-            for (int hbase = 0; hbase < nhit; hbase += 64) {
-                const int h = hbase + lane;
-                VbItem it;
-                it.packed = 0;
-                it.v1 = 0;
-                it.v2 = 0;
-                it.alpha = 0.f;
-                bool keep = false;
-                if (h < nhit) {
-                    const int hq = S.hq[h];
-                    const int q = hq & 511, d = (hq >> 9) & 1, gk = hq >> 11;
-                    const bool chose0 = (hq >> 10) & 1;
-                    const int qy = q / VB_RW, qx = q - qy * VB_RW;
-                    const int nq = q + (d ? VB_RW : 1);
-                    const int t = min((int)(S.ht[h] & 0x7fffffffu), T - 1);  // (always a triangle id: the pixel has an uncovered neighbour)
-                    int px = rx0 + qx, py = ry0 + qy;
-                    if (!chose0) {
-                        px += 1 - d;
-                        py += d;
-                    }
-                    float4 p[3], o[3];
-                    const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
-                    const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
-#pragma unroll
-                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
-#pragma unroll
-                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
-                    const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
-                    S.ht[h] = a.found ? __float_as_uint(a.alpha) : 0u;
-                    if (a.found) {
-                        // keep for the backward pass if the destination pixel is interior to this tile
-                        const int oq = (a.alpha > 0.f) ? q : nq;
-                        const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
-                        const bool oin = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
-                        if (oin && a.alpha != 0.f) {
-                            // the link: the gk-th set bit of grp
-                            unsigned gm = grp;
-                            for (int k = 0; k < gk; k++) gm &= gm - 1;
-                            const int l = __ffs(gm) - 1;
-                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14) | (l << 15);
-                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
-                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
-                            it.alpha = a.alpha;
-                            keep = want_grad != 0;
-                        }
-                    }
-                }
-                const u64 km = __ballot(keep);
-                if (km) {
-                    const int at = nit + vb_mbcnt(km);
-                    const int nnew = nit + __popcll(km);
-                    if (nnew > VB_TILE_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this tile
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
-                        spill_base = __builtin_amdgcn_readfirstlane(base);
-                        // items this tile can keep: LDS, then its block of the spill pool as far as the pool reaches
-                        if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
-                    }
-                    if (keep) {
-                        if (at < VB_TILE_ITEMS)
-                            S.items[at] = it;
-                        else if (at < room)
-                            spill[spill_base + (at - VB_TILE_ITEMS)] = it;
-                        else
-                            atomicOr(&meta[EHR_META_OVERFLOW], 1);  // reported through loss = NaN, never silent
-                    }
-                    nit = min(nnew, room);  // never more than were stored
-                }
-            }
-            VB_WAVE_SYNC();
-            // ---- (3) per link: scatter its blend weights, gather the antialiased value at my pixels (fixed order: down,
-            //      left, right, up pair), sum in link order
-            for (int i = lane; i < 2 * VB_RN; i += 64) S.pairA[i] = 0.f;
-            {
-                unsigned gm = grp;
-#pragma unroll 1
-                for (int gk = 0; gk < ng; gk++) {
-                    const int l = __ffs(gm) - 1;
-                    gm &= gm - 1;
-                    VB_WAVE_SYNC();
-                    const int hb = S.hstart[gk], he = S.hstart[gk + 1];
-                    for (int h = hb + lane; h < he; h += 64) {
-                        const int hq = S.hq[h];
-                        S.pairA[((hq >> 9) & 1) * VB_RN + (hq & 511)] = __uint_as_float(S.ht[h]);
-                    }
-                    VB_WAVE_SYNC();
-                    const u64 r0 = S.covs[gk][r], r1 = S.covs[gk][r + 1], r2 = S.covs[gk][r + 2];
-                    float cn[6], cd[4], cu[4];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) cn[j] = ((r1 >> (c4 + j)) & 1ull) ? 1.f : 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        cd[j] = ((r0 >> (c4 + 1 + j)) & 1ull) ? 1.f : 0.f;
-                        cu[j] = ((r2 >> (c4 + 1 + j)) & 1ull) ? 1.f : 0.f;
-                    }
-                    float val[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const float c = cn[j + 1];
-                        float v = c;
-                        if (he > hb) {
-                            float a;
-                            a = S.pairA[VB_RN + myq + j - VB_RW];
-                            if (a < 0.f) v += a * (c - cd[j]);
-                            a = S.pairA[myq + j - 1];
-                            if (a < 0.f) v += a * (c - cn[j]);
-                            a = S.pairA[myq + j];
-                            if (a > 0.f) v += a * (cn[j + 2] - c);
-                            a = S.pairA[VB_RN + myq + j];
-                            if (a > 0.f) v += a * (cu[j] - c);
-                        }
-                        val[j] = v;
-                    }
-                    VB_WAVE_SYNC();
-                    for (int h = hb + lane; h < he; h += 64) {  // (leave the table zero for the next link)
-                        const int hq = S.hq[h];
-                        S.pairA[((hq >> 9) & 1) * VB_RN + (hq & 511)] = 0.f;
-                    }
-                    // the link's blended pairs count only if it has a value inside the tile (as when the stages were kernels)
-                    const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
-                    if (nz) bmask |= 1u << l;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[j] += val[j];
-                }
-            }
-        }
-        // ---- composite, loss, mask write (image convention: row 0 = top)
-        float e2 = 0.f, gv[4];
-        float mv[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            gv[j] = 0.f;
-            mv[j] = 0.f;
-            if (pin[j]) {
-                const float m = acc[j] > 1.f ? 1.f : acc[j];
-                const float e = m - rf[j];
-                e2 += e * e;
-                gv[j] = (acc[j] <= 1.f) ? 2.f * e : 0.f;
-                mv[j] = m;
-            }
-        }
-        if (mask) {
-            if (vec_ok) {
-                if (pin[0]) *reinterpret_cast<float4*>(mask + im) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (pin[j]) mask[im + j] = mv[j];
-            }
-        }
-        {
-            const float s = wave_sum(e2);
-            if (lane == 0) {
-                if (sparse)
-                    fix_add_delta(lacc, s, tsum[(size_t)b * g.nt + tile], meta);
-                else
-                    fix_add(lacc, s, meta);
-            }
-        }
-        if (!want_grad || nit == 0 || bmask == 0 || (dbg & 4)) continue;
+    }
+    const unsigned bmask = (unsigned)__ballot(myn > 0);  // links with blended pairs to back-propagate
+    if (!want_grad || bmask == 0 || (dbg & 4)) continue;
 
-        // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link (the pairs carry their link)
-        VB_WAVE_SYNC();  // the reads of pairA are complete
+    // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
+    const float4* const pv = posc + (size_t)b * V;
+    VB_WAVE_SYNC();  // the previous tile's reads of gpix are complete
 #pragma unroll
-        for (int j = 0; j < 4; j++) S.gpix[r * EHR_TILE_W + c4 + j] = gv[j];
-        VB_WAVE_SYNC();
-        // which links have pairs at all (wave-uniform), restricted to those with a value in the tile
-        unsigned links = 0;
-        for (int i = lane; i < nit; i += 64) {
-            const VbItem itm = (i < VB_TILE_ITEMS) ? S.items[i] : spill[spill_base + (i - VB_TILE_ITEMS)];
-            links |= 1u << ((itm.packed >> 15) & 31);
+    for (int j = 0; j < 4; j++) gpix[r * EHR_TILE_W + c4 + j] = gv[j];
+    VB_WAVE_SYNC();
+    unsigned links = bmask;
+    while (links) {
+        const int l = __ffs(links) - 1;
+        links &= links - 1;
+        const size_t slot = (size_t)vb_readlane(myslot, l);
+        int n = vb_readlane(myn, l);
+        int sbase = 0;
+        if (n > VB_JOB_ITEMS) {  // the rest of the list lives in the spill pool; never read outside it
+            sbase = jspill[slot];
+            if (sbase < 0 || sbase >= spill_cap) n = VB_JOB_ITEMS;
+            else n = min(n, VB_JOB_ITEMS + (spill_cap - sbase));
         }
+        float G[12];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) links |= (unsigned)__shfl_xor((int)links, o, 64);
-        links &= bmask;
-        while (links) {
-            const int l = __ffs(links) - 1;
-            links &= links - 1;
-            float G[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) G[k] = 0.f;
-            for (int i = lane; i < nit; i += 64) {
-                const VbItem itm = (i < VB_TILE_ITEMS) ? S.items[i] : spill[spill_base + (i - VB_TILE_ITEMS)];
-                if (((itm.packed >> 15) & 31) != l) continue;
-                const int q = itm.packed & 1023, d = (itm.packed >> 10) & 1;
-                const int tri1 = (itm.packed >> 13) & 1;
-                const float dc = ((itm.packed >> 14) & 1) ? 1.f : -1.f;
-                const int nq = q + (d ? VB_RW : 1);
-                const int oq = (itm.alpha > 0.f) ? q : nq;
-                const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
-                const float gi = S.gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
-                const float dd = gi * dc;
-                if (gi == 0.f || dd == 0.f) continue;
-                const int qy = q / VB_RW, qx = q - qy * VB_RW;
-                int px = rx0 + qx, py = ry0 + qy;
-                if (tri1) {
-                    px += 1 - d;
-                    py += d;
-                }
-                float g1[3], g2[3];
-                aa_pos_grad(pv[itm.v1], pv[itm.v2], px, py, d, itm.alpha, dd, W, H, g1, g2);
-                const float* a1 = verts + 3 * (size_t)itm.v1;
-                const float* a2 = verts + 3 * (size_t)itm.v2;
-                const float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) G[4 * rr + c] += g1[rr] * h1[c] + g2[rr] * h2[c];
+        for (int k = 0; k < 12; k++) G[k] = 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const VbItem itm = (i < VB_JOB_ITEMS) ? jitems[slot * VB_JOB_ITEMS + i] : spill[sbase + (i - VB_JOB_ITEMS)];
+            const int q = itm.packed & 1023, d = (itm.packed >> 10) & 1;
+            const int tri1 = (itm.packed >> 13) & 1;
+            const float dc = ((itm.packed >> 14) & 1) ? 1.f : -1.f;
+            const int nq = q + (d ? VB_RW : 1);
+            const int oq = (itm.alpha > 0.f) ? q : nq;
+            const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+            const float gi = gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
+            const float dd = gi * dc;
+            if (gi == 0.f || dd == 0.f) continue;
+            const int qy = q / VB_RW, qx = q - qy * VB_RW;
+            int px = rx0 + qx, py = ry0 + qy;
+            if (tri1) {
+                px += 1 - d;
+                py += d;
             }
-            float mine = 0.f;
+            float g1[3], g2[3];
+            aa_pos_grad(pv[itm.v1], pv[itm.v2], px, py, d, itm.alpha, dd, W, H, g1, g2);
+            const float* a1 = verts + 3 * (size_t)itm.v1;
+            const float* a2 = verts + 3 * (size_t)itm.v2;
+            const float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
 #pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const float s = wave_sum(G[k]);
-                if (lane == k) mine = s;
-            }
-            if (lane < 12) fix_add(&vacc[12 * l + lane], mine, meta);
+            for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) G[4 * rr + c] += g1[rr] * h1[c] + g2[rr] * h2[c];
         }
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const float s = wave_sum(G[k]);
+            if (lane == k) mine = s;
+        }
+        if (lane < 12) fix_add(&vacc[12 * l + lane], mine, meta);
+    }
     }
     // ---- the workgroup whose atomics are performed last runs the finish stage.  Every wave first waits until its own
     //      atomics have been performed (vmcnt covers them), then one lane takes a ticket on the XCD's counter and the
@@ -1840,10 +1825,12 @@ vb_tile_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, 
     if (!s_last) return;
     if (ref_flag && tid == 0 && ref_flag[0]) atomicOr(&meta[EHR_META_OVERFLOW], 1);  // the bound reference's own sums overflowed
     __syncthreads();
-    __shared__ double Sred[4][17];
+    __shared__ double S[4][17];
     __shared__ float red_lds[8];
+#ifndef VB_NO_FINISH
     finish_body<TAIL>(g, B, facc, sparse ? vtot : nullptr, loss, grad_mvp, meta, tail, nls, lbox, VB_LOSS_STRIDE,
-                      lds_all[0].pairA, Sred, red_lds);
+                      gpix_all[0], S, red_lds);
+#endif
 }
 
 // [T][3] int32 -> [T] int4 (one aligned 16-byte gather per triangle in the silhouette analysis)
@@ -2018,15 +2005,18 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         if ((rc = ctx->vb_refsum.reserve(((size_t)B * g0.nt + B + 1) * sizeof(long long)))) return rc;
         ctx->vb_ref = nullptr;  // a new plan forgets the binding
     }
-    {  // job slots, compact (numbered like the jobs): triangle ids of the region 1.36 KB | coverage rows 80 B | descriptor |
-       // an entry of the list for vb_slow_kernel; then the links' first jobs
+    {  // job slots, compact (numbered like the jobs): value tile 1 KB | items 1 KB | count | spill base | region ids 1.36 KB;
+       // descriptor; then the links' first jobs
         BinGeom g = make_geom(H, W, L);
+        // a job = a (link, tile) pair whose boxes touch: `slack` tiles-worth of links per view (default 4 = every pixel
+        // under four link boxes), never more than all of them
         (void)slack;  // every (view, link, tile) can have its slot: nothing to overflow
         const double want = (double)L * (double)B * g.nt;
         if (want > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles exceeds 2e9");
         ctx->vb_jcap = (int)want;
         const size_t nslot = (size_t)ctx->vb_jcap;
-        if ((rc = ctx->vb_jobs.reserve(nslot * (VB_RN * sizeof(unsigned) + VB_RH * sizeof(u64) + sizeof(int) + sizeof(int4)) +
+        if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + VB_WORDS * sizeof(u64) +
+                                                2 * sizeof(int) + VB_RN * sizeof(unsigned) + sizeof(int) + sizeof(int4)) +
                                        (2 * (size_t)B * L + 1) * sizeof(int) + 32))) return rc;
     }
     {  // heavy-job hint: generation + two counts | two lists | stamp table
@@ -2217,49 +2207,58 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     static const int job_grid = getenv("EHR_VB_JOB_GRID") ? atoi(getenv("EHR_VB_JOB_GRID")) : 4;   // tuning knob
     static const int heavy_t = getenv("EHR_VB_HEAVY_T") ? atoi(getenv("EHR_VB_HEAVY_T")) : VB_HEAVY_T_DEFAULT;  // tuning knob
     const size_t nslot = (size_t)ctx->vb_jcap;
-    u64* jcov = (u64*)ctx->vb_jobs.ptr;
-    unsigned* jid = (unsigned*)(jcov + nslot * VB_RH);
+    float* jval = (float*)ctx->vb_jobs.ptr;
+    VbItem* jitems = (VbItem*)(jval + nslot * 256);
+    u64* jcov = (u64*)(jitems + nslot * VB_JOB_ITEMS);
+    int* jn = (int*)(jcov + nslot * VB_WORDS);
+    int* jspill = jn + nslot;
+    unsigned* jid = (unsigned*)(jspill + nslot);
     int* jdesc = (int*)(jid + nslot * VB_RN);
     int* jbase = jdesc + nslot;                               // [B * L + 1] first job of every (view, link)
     unsigned* jutile = (unsigned*)(jbase + (size_t)B * L + 1);  // [B * L] its tile range
     int4* slow_list = (int4*)(((uintptr_t)(jutile + (size_t)B * L) + 15) & ~(uintptr_t)15);  // [nslot] jobs for vb_slow_kernel
     const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
-    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg, hv,
+    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg, hv,
                                                 (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t);
     EHR_LAUNCH_CHECK();
     // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
-    vb_slow_kernel<<<ctx->num_cus, 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, slow_list, meta);
+    vb_slow_kernel<<<ctx->num_cus, 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
     EHR_LAUNCH_CHECK();
     if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
+    // stage 1b: drawn jobs -> per-link values and blended pairs
+    static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
+    const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
+    vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, T, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
+                                                   jid, jcov, jdesc, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
+                                                   ctx->vb_spill_cap, meta, dbg);
+    EHR_LAUNCH_CHECK();
     if (ev) {
         for (int k = 3; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
     }
-    // stage 2: per tile, the drawn links' silhouette analysis and values, composite, loss, mask, backward; its
-    // last-arriving workgroup runs the finish stage (accumulators -> loss / grad_mvp, + pose backward and Adam in the
-    // solver-step form; re-arms the link boxes).  With a bound reference mask and no mask output only the tiles inside the
-    // views' link rectangles are visited.
+    // stage 2: composite, loss, mask, backward; its last-arriving workgroup runs the finish stage (accumulators -> loss /
+    // grad_mvp, + pose backward and Adam in the solver-step form; re-arms the link boxes).  With a bound reference mask
+    // and no mask output only the tiles inside the views' link rectangles are visited.
     static const int no_sparse = getenv("EHR_VB_NO_SPARSE") ? atoi(getenv("EHR_VB_NO_SPARSE")) : 0;  // A/B aid
     const bool sparse = !no_sparse && !mask && ctx->vb_ref != nullptr && ctx->vb_ref == ref;
-    static const int tile_grid = getenv("EHR_VB_TILE_GRID") ? atoi(getenv("EHR_VB_TILE_GRID")) : VB_TILE_WAVES;  // tuning knob
-    int nwg = ctx->num_cus * std::max(1, tile_grid);
+    static const int comp_grid = getenv("EHR_VB_COMPOSITE_GRID") ? atoi(getenv("EHR_VB_COMPOSITE_GRID")) : 6;  // tuning knob (6 resident per CU)
+    int nwg = ctx->num_cus * std::max(1, comp_grid);
     if (!sparse) nwg = std::min(nwg, (ntiles + 3) / 4);
     nwg = std::max(8, (nwg + 7) & ~7);  // a multiple of 8: the XCD split and the two-level arrival ticket rely on it
     const long long* tsum = sparse ? (const long long*)ctx->vb_refsum.ptr : nullptr;
     const long long* vtot = sparse ? tsum + (size_t)B * g.nt : nullptr;
     const int* ref_flag = sparse ? (const int*)(vtot + B) : nullptr;
-    const size_t dyn = (2 * (size_t)B * L + 1) * sizeof(int);  // link tables
-    const int4* tri4 = (const int4*)ctx->vb_idx.ptr;
+    const size_t dyn = (2 * (size_t)B * L + 1) * sizeof(int);  // link tables in LDS
     if (tail) {
-        vb_tile_kernel<true><<<nwg, 256, dyn, stream>>>(g, B, posc, V, T, verts, tri4, tri4 + T, lbox, jid, jcov, jdesc, jbase,
-                                                      jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok,
-                                                      spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss,
-                                                      grad_mvp, *tail);
+        vb_composite_kernel<true><<<nwg, 256, dyn, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase,
+                                                         jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0,
+                                                         vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag,
+                                                         loss, grad_mvp, *tail);
     } else {
         StepTail none = {};
-        vb_tile_kernel<false><<<nwg, 256, dyn, stream>>>(g, B, posc, V, T, verts, tri4, tri4 + T, lbox, jid, jcov, jdesc, jbase,
-                                                       jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok,
-                                                       spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss,
-                                                       grad_mvp, none);
+        vb_composite_kernel<false><<<nwg, 256, dyn, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase,
+                                                          jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0,
+                                                          vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot,
+                                                          ref_flag, loss, grad_mvp, none);
     }
     EHR_LAUNCH_CHECK();
     if (ev) {

@@ -131,10 +131,9 @@ def mvp_matrices(K, H, W, Tc_c2b, link_poses, n=0.001, f=10.0):
     return proj @ (o2b @ Tc_c2l)                      # nvdiffrast_renderer.py:35,37 (same association)
 
 
-# kernels bracketed by ehr_fused_timing's hipEvents, in ms[] order (include/ehr.h): vertex + records, jobs (+ the
-# normally empty general-path pass), tiles (silhouette analysis, composite, backward, + the finish stage in its last
-# workgroup); slots 2, 3, 5, 6 are unused.
-STAGES = ("vertex", "job", "unused2", "unused3", "tile", "unused5", "unused6")
+# kernels bracketed by ehr_fused_timing's hipEvents, in ms[] order (include/ehr.h): vertex + records, jobs, resolve,
+# composite (+ the finish stage in its last workgroup); slots 3, 5, 6 are unused.
+STAGES = ("vertex", "job", "resolve", "unused3", "composite", "unused5", "unused6")
 DOMINANT_STAGE, DOMINANT_KERNEL = "job", "vb_job_kernel"
 
 
