@@ -48,6 +48,10 @@ SIGNATURES = {
     "ehr_solver_step": (c_int, [c_void_p] * 9 + [c_int] * 6 + [c_float] * 2 + [c_void_p] * 5 + [c_int, c_void_p] +
                         [c_float] * 5 + [c_void_p] * 8 + [c_int, c_void_p]),
     "ehr_mask_variance": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "ehr_comm_unique_id": (c_int, [c_void_p]),
+    "ehr_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "ehr_comm_allreduce": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "ehr_comm_destroy": (c_int, [c_void_p]),
     "ehr_graph_begin": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "ehr_graph_end": (c_int, [c_void_p]),
     "ehr_graph_launch": (c_int, [c_void_p, c_void_p]),

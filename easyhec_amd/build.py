@@ -11,7 +11,7 @@ LIB = os.path.join(_HERE, "libehr_hip.so")
 ARCH = "gfx950"
 # -amdgpu-use-amdgpu-trackers: the target's own register-pressure trackers during scheduling; the job kernel sits at the
 # 128-VGPR limit and every spilled register shows in its duration (7 instead of 10 spilled VGPRs, +1 % frames/s)
-FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-mllvm", "-amdgpu-use-amdgpu-trackers=1", "-ldl"]
 
 
 def sources():

@@ -89,6 +89,9 @@ struct ehr_ctx {
     // space-explorer scoring (ehr_mask_variance) keeps its own scratch so that it never disturbs a solver plan
     ehr::Scratch sc_counts, sc_offsets, sc_entries, sc_posc;
     size_t sc_entries_cap = 0;
+    // RCCL communicator of the data-parallel exchange (ehr_comm_*; an ncclComm_t), created by the library itself
+    void* comm = nullptr;
+    int comm_ranks = 0;
     // natively captured launch chain (ehr_graph_*): capture stream and the instantiated graph
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;

@@ -218,6 +218,7 @@ int ehr_ctx_create(int device, ehr_ctx** out) {
 
 int ehr_ctx_destroy(ehr_ctx* c) {
     if (!c) return EHR_OK;
+    (void)ehr_comm_destroy(c);
     int cur = 0;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(c->device);

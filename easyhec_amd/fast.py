@@ -21,7 +21,7 @@ def _f(x):
 
 class FusedPoseStep:
     def __init__(self, model, batch, lr=0.003, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0005, near=0.001, far=10.0,
-                 process_group=None):
+                 process_group=None, rccl=None):
         self.model = model
         self.renderer = model._ensure_renderer()
         self.scene = model._ensure_scene()
@@ -38,6 +38,13 @@ class FusedPoseStep:
         self.near, self.far = near, far
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
+        # How the ranks exchange the 8-float vector: "rccl" = ncclAllReduce on the library's own communicator, enqueued on
+        # the chain's stream between the solver step and Adam (default for the nccl backend, i.e. one process per GPU);
+        # otherwise torch.distributed.all_reduce (gloo: the CPU tests, two ranks sharing one GPU).  rccl=True without a
+        # process group makes a single-rank communicator (the same launch sequence on one GPU).
+        self.rccl = bool(rccl) if rccl is not None else (self.distributed and dist.get_backend(self.pg) == "nccl")
+        if self.rccl:
+            self._init_comm()
         # optimiser state (torch.optim.Adam names): a fresh Adam (step 0, zero moments) unless load_state_dict restores
         # one -- like the reference's load_model path.  The row of ``history_ops`` the next step records its pose in is a
         # counter of its own (the reference's first all-zero row, rb_solver.py:50-51): it starts at the model's history
@@ -61,6 +68,23 @@ class FusedPoseStep:
         fused.bind_ref(self.glctx, self.scene, self.ref)
         self._graph = None
 
+    def _init_comm(self):
+        """ncclCommInitRank through the C ABI (``ehr_comm_*``): rank 0's ncclUniqueId travels over the process group that
+        is already up (the only use torch.distributed has on this path)."""
+        lib = _lib.lib()
+        world = dist.get_world_size(self.pg) if self.distributed else 1
+        rank = dist.get_rank(self.pg) if self.distributed else 0
+        idbuf = (ctypes.c_ubyte * 128)()
+        if rank == 0:
+            _lib.check(lib.ehr_comm_unique_id(idbuf), "ehr_comm_unique_id")
+        if world > 1:
+            on_dev = dist.get_backend(self.pg) == "nccl"
+            t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.dev if on_dev else "cpu")
+            dist.broadcast(t, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            idbuf = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+        with torch.cuda.device(self.dev):
+            _lib.check(lib.ehr_comm_init(self.glctx.handle, idbuf, world, rank), "ehr_comm_init")
+
     # -- one step -------------------------------------------------------------------------------------------------
     def _enqueue(self, want_mask, stream=None):
         lib = _lib.lib()
@@ -79,9 +103,13 @@ class FusedPoseStep:
             _lib.ptr(self.hist_row), _f(self.lr), _f(self.betas[0]), _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.mvp),
             _lib.ptr(self.tc_jac), _lib.ptr(self.mask if want_mask else None), _lib.ptr(self.loss_b),
             _lib.ptr(self.grad_mvp), _lib.ptr(self.red), _lib.ptr(self.loss), _lib.ptr(self.grad),
-            int(self.distributed), stream), "ehr_solver_step")
-        if self.distributed:
-            dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.pg)  # the ONE collective of a step (32 bytes)
+            int(self.distributed or self.rccl), stream), "ehr_solver_step")
+        if self.distributed or self.rccl:
+            # the ONE collective of a step (32 bytes), between the chain and Adam
+            if self.rccl:
+                _lib.check(lib.ehr_comm_allreduce(self.glctx.handle, _lib.ptr(self.red), 8, stream), "ehr_comm_allreduce")
+            else:
+                dist.all_reduce(self.red, op=dist.ReduceOp.SUM, group=self.pg)
             _lib.check(lib.ehr_pose_adam(_lib.ptr(dof), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
                                          _lib.ptr(self.step_t), _lib.ptr(self.red), _f(self.lr), _f(self.betas[0]),
                                          _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.loss),
@@ -102,12 +130,13 @@ class FusedPoseStep:
     def capture(self):
         """Record the step's launch chain (4 kernels on one stream) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
         with one host call.  Iteration state lives on the device, so replays are ordinary optimisation steps.  The
-        chain is GPU-bound, so this saves host time, not step time.  Single-process only: the data-parallel step has a
-        collective between the chain and Adam."""
+        chain is GPU-bound, so this saves host time, not step time.  The data-parallel step is captured too when its
+        exchange is the library's own ncclAllReduce (``rccl``: [solver step, all-reduce, Adam] on one stream); with the
+        torch.distributed exchange (gloo) it cannot be."""
         if self._graph:
             return
-        if self.distributed:
-            raise RuntimeError("capture(): not available with data parallelism")
+        if self.distributed and not self.rccl:
+            raise RuntimeError("capture(): not available with the torch.distributed exchange (use the RCCL one)")
         lib = _lib.lib()
         with torch.cuda.device(self.dev):
             torch.cuda.synchronize()

@@ -42,7 +42,7 @@ def shard_views(n_views, rank, world_size):
 
 
 class RBSolverTrainer:
-    def __init__(self, cfg, model, batch, process_group=None, fast=False, graph=False):
+    def __init__(self, cfg, model, batch, process_group=None, fast=False, graph=False, rccl=None):
         """batch: dict of this rank's device tensors (mask, link_poses, K, Tc_c2b) -- the single batch the reference
         builds with batch_size=100 >= #frames (configs/xarm7/example.yaml:45).
         fast: run the step as the fixed HIP launch chain of :class:`easyhec_amd.fast.FusedPoseStep` (same arithmetic,
@@ -62,8 +62,8 @@ class RBSolverTrainer:
             if cfg.solver.do_grad_clip or cfg.solver.optimizer != "Adam":
                 raise ValueError("fast path implements the reference's default solver only (Adam, no gradient clipping)")
             self.fast = FusedPoseStep(model, self.batch, lr=cfg.solver.max_lr, weight_decay=cfg.solver.weight_decay,
-                                      process_group=process_group)
-            if graph and not self.distributed:
+                                      process_group=process_group, rccl=rccl)
+            if graph and (not self.distributed or self.fast.rccl):
                 self.fast.capture()
         if "Tc_c2b" in self.batch and "gt_dof6" not in self.batch:
             gt = self.batch["Tc_c2b"][0]

@@ -36,7 +36,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 3 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref) */
+int ehr_version(void);                 /* ABI version, currently 3 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
@@ -171,6 +171,23 @@ int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                     int32_t* history_row, float lr, float beta1, float beta2, float eps, float weight_decay, float* mvp,
                     float* tc_jac, float* mask, float* loss_b, float* grad_mvp, float* red, float* loss_out,
                     float* grad_out, int defer_adam, void* stream);
+
+/* The data-parallel exchange (replaces the DDP gradient all-reduce of trainer/base.py:349-352 under the
+ * one-process-per-GPU launch of tools/run_easyhec.py:41-50).  Views shard over the ranks; per step every rank runs
+ * ehr_solver_step(defer_adam = 1) on its views, the ranks sum the 8-float vector red = [d sum(loss)/d dof (6), sum(loss),
+ * n_views] and then run ehr_pose_adam, bit-identically.  The library owns an RCCL communicator per context and issues
+ * ncclAllReduce on the stream it is given -- the chain's own stream -- so the step is [solver step, all-reduce, Adam] on ONE
+ * stream with no host round trip, and the three calls can be captured together in a hipGraph (ehr_graph_*).
+ *   ehr_comm_unique_id : rank 0 obtains the 128-byte ncclUniqueId; the caller ships it to every rank (any transport);
+ *   ehr_comm_init      : every rank, with the same id: ncclCommInitRank on the context's device (blocks until all ranks
+ *                        have joined); nranks == 1 is legal (a single-GPU communicator);
+ *   ehr_comm_allreduce : in-place sum of red[0..count) (device, fp32) over the ranks, enqueued on `stream`;
+ *   ehr_comm_destroy   : releases the communicator (ehr_ctx_destroy does it too).
+ * RCCL is resolved with dlopen at the first call (the librccl a host process already holds is reused). */
+int ehr_comm_unique_id(void* id128_host);
+int ehr_comm_init(ehr_ctx* ctx, const void* id128_host, int nranks, int rank);
+int ehr_comm_allreduce(ehr_ctx* ctx, float* red, int count, void* stream);
+int ehr_comm_destroy(ehr_ctx* ctx);
 
 /* hipGraph capture of launch chains.  ehr_graph_begin opens a capture on a stream the context owns and returns it; every
  * library call made with THAT stream until ehr_graph_end (e.g. one ehr_solver_step, or ehr_solver_step with defer_adam

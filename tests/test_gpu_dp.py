@@ -60,3 +60,29 @@ def test_two_ranks_match_single_process(xarm7, tmp_path):
     # sum over ranks of (sum over local views) == sum over all views, up to float reassociation of 2 partial sums
     assert np.allclose(dp["losses"], single, rtol=1e-5)
     assert (dp["dof"] - model.dof.detach().cpu()).abs().max() <= 2e-5
+
+
+def test_rccl_exchange_on_one_rank_is_the_plain_step(xarm7):
+    """The data-parallel launch sequence -- ehr_solver_step(defer_adam) -> ncclAllReduce on the library's own RCCL
+    communicator (ehr_comm_*, created with ncclCommInitRank, one rank) on the chain's stream -> ehr_pose_adam -- equals
+    the single-process step bit for bit, eager and captured as a hipGraph (the collective is part of the capture)."""
+    from easyhec_amd.fast import FusedPoseStep
+    from test_gpu_fast import problem
+    cfg, make, batch = problem(xarm7, 3, 240, 320, 0.25)
+    ma, mb, mc = make(), make(), make()
+    fa = FusedPoseStep(ma, batch)                 # plain
+    fb = FusedPoseStep(mb, batch, rccl=True)      # RCCL exchange, eager
+    fc = FusedPoseStep(mc, batch, rccl=True)      # RCCL exchange, hipGraph replay
+    assert fb.rccl and fc.rccl and not fa.rccl
+    fc.capture()
+    for _ in range(12):
+        fa.step()
+        fb.step()
+        fc.step()
+    torch.cuda.synchronize()
+    for name in ["mvp", "loss_b", "grad_mvp", "red", "loss", "grad", "exp_avg", "exp_avg_sq", "step_t", "hist_row"]:
+        assert torch.equal(getattr(fa, name), getattr(fb, name)), name
+        assert torch.equal(getattr(fa, name), getattr(fc, name)), name
+    assert torch.equal(ma.dof.data, mb.dof.data) and torch.equal(ma.dof.data, mc.dof.data)
+    assert torch.equal(ma.history_ops[:12], mc.history_ops[:12])
+    assert float(fa.red[7]) == 3.0
