@@ -64,7 +64,11 @@ struct ehr_ctx {
     ehr::Scratch offsets;   // int32 [nkeys]
     ehr::Scratch entries;   // int32 [entries_cap]
     size_t entries_cap = 0; // in entries
-    int* host_pinned = nullptr;  // 4 ints, pinned, for the synchronous size read-back of the drop-in rasterize
+    int* host_pinned = nullptr;  // 8 ints, pinned: size read-backs of the scoring op ([0..5]) and the drop-in rasterize ([6..7])
+    hipEvent_t ev_size[2] = {nullptr, nullptr};  // drop-in rasterize: "the size in host_pinned[k] has arrived"
+    bool size_valid[2] = {false, false};
+    long long size_key[2] = {0, 0};              // (B, T, H, W) of the call that produced it
+    int size_slot = 0;
     // fused path plan
     int pB = 0, pL = 0, pV = 0, pT = 0, pH = 0, pW = 0;
     int num_cus = 256;
@@ -76,7 +80,8 @@ struct ehr_ctx {
     const void* vb_plan_opp = nullptr;
     const void* vb_plan_verts = nullptr;
     int vb_nc = 0;           // number of clusters
-    int vb_jcap = 0;         // job slots
+    int vb_jcap = 0;         // job slots (of one chunk of views)
+    int vb_chunk = 0;        // views per pass of the chain (plan time: LDS tables of the job kernel, scratch budget)
     ehr::Scratch vb_boxes;   // uint2 pixel boxes of the current step: tbox [B][NC][64] | cbox [B][NC]
     ehr::Scratch vb_units;   // i32 [B][L][4] pixel boxes of the links (re-armed by the finish kernel)
     ehr::Scratch vb_acc;     // i64 [B][12 L + VB_LOSS_SLOTS * VB_LOSS_STRIDE] fixed-point sums, then the meta words

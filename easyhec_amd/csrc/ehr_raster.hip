@@ -55,13 +55,27 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
                                                                       const int* __restrict__ offsets,
                                                                       const int4* __restrict__ entries, int entries_cap,
                                                                       float4* __restrict__ rast,
-                                                                      float4* __restrict__ rast_db) {
+                                                                      float4* __restrict__ rast_db,
+                                                                      const int* __restrict__ meta) {
     __shared__ u64 key[EHR_TILE_W * EHR_TILE_H];
     __shared__ BlockRaster wscratch;
     const int tile = blockIdx.x, b = blockIdx.y;
     const int tx = tile % g.ntx, ty = tile / g.ntx;
     const int rx0 = tx * EHR_TILE_W, ry0 = ty * EHR_TILE_H;
     const int tid = threadIdx.x;
+    if (meta[EHR_META_TOTAL] > entries_cap) {
+        // the queues did not fit (the host skipped its size read-back because the previous frames needed far less): the
+        // image is NaN, never a silently incomplete one; the next call sees the size and grows the storage
+        const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
+        const int ix = rx0 + lx, iy = ry0 + ly;
+        if (ix < g.W && iy < g.H) {
+            const float nanv = __int_as_float(0x7fc00000);
+            const size_t pix = ((size_t)b * g.H + iy) * g.W + ix;
+            rast[pix] = make_float4(nanv, nanv, nanv, nanv);
+            if (WITH_DB) rast_db[pix] = make_float4(nanv, nanv, nanv, nanv);
+        }
+        return;
+    }
     key[tid] = ~0ull;
     const int kidx = b * g.nt + tile;
     int n = counts[kidx];
@@ -241,6 +255,8 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->vb_refsum.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; k++)
+        if (c->ev_size[k]) (void)hipEventDestroy(c->ev_size[k]);
     if (c->gexec) (void)hipGraphExecDestroy(c->gexec);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     (void)hipSetDevice(cur);
@@ -302,14 +318,37 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     }
     bin_alloc_kernel<<<(nkeys + 255) / 256, 256, 0, stream>>>(counts, offsets, nullptr, nullptr, nullptr, nkeys, 1, meta);
     EHR_LAUNCH_CHECK();
-    // size read-back (the one synchronisation of this op): grow the queue storage if this frame needs more
-    EHR_HIP(hipMemcpyAsync(ctx->host_pinned, meta, sizeof(int), hipMemcpyDeviceToHost, stream));
-    EHR_HIP(hipStreamSynchronize(stream));
-    size_t total = (size_t)ctx->host_pinned[0];
-    if (total > ctx->entries_cap) {
-        size_t want = total + total / 2;
-        if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
-        ctx->entries_cap = want;
+    // Size read-back.  The queue storage must hold `total` entries, known only on the device.  Steady state (a solve
+    // renders the same meshes again and again): the total travels to pinned host memory asynchronously and the NEXT call
+    // looks at it -- if the last completed call of this shape needed at most half of the storage, this call does not
+    // wait (a frame that suddenly needs more than twice as much comes out as NaN, see raster_tile_kernel, and the call
+    // after it grows the storage).  Otherwise (first calls, new shape, tight storage) synchronise once and grow, like
+    // nvdiffrast's own rasterizer.
+    const int slot = ctx->size_slot ^= 1;
+    if (!ctx->ev_size[0]) {
+        EHR_HIP(hipEventCreateWithFlags(&ctx->ev_size[0], hipEventDisableTiming));
+        EHR_HIP(hipEventCreateWithFlags(&ctx->ev_size[1], hipEventDisableTiming));
+    }
+    const long long shape_key = ((long long)B << 48) ^ ((long long)T << 24) ^ ((long long)H << 12) ^ W;
+    bool wait = true;
+    {
+        const int prev = slot ^ 1;
+        if (ctx->size_valid[prev] && ctx->size_key[prev] == shape_key && hipEventQuery(ctx->ev_size[prev]) == hipSuccess &&
+            2 * (size_t)ctx->host_pinned[6 + prev] + 1024 <= ctx->entries_cap)
+            wait = false;
+    }
+    EHR_HIP(hipMemcpyAsync(ctx->host_pinned + 6 + slot, meta, sizeof(int), hipMemcpyDeviceToHost, stream));
+    EHR_HIP(hipEventRecord(ctx->ev_size[slot], stream));
+    ctx->size_valid[slot] = true;
+    ctx->size_key[slot] = shape_key;
+    if (wait) {
+        EHR_HIP(hipStreamSynchronize(stream));
+        size_t total = (size_t)ctx->host_pinned[6 + slot];
+        if (2 * total + 1024 > ctx->entries_cap) {
+            size_t want = 2 * total + total / 2 + 4096;
+            if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
+            ctx->entries_cap = want;
+        }
     }
     int4* entries = (int4*)ctx->entries.ptr;
     if (tmax > 0) {
@@ -321,10 +360,10 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     int ecap = (int)std::min(ctx->entries_cap, (size_t)0x7fffffff);
     if (rast_db)
         raster_tile_kernel<true><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, counts, offsets, entries, ecap,
-                                                                        (float4*)rast, (float4*)rast_db);
+                                                                        (float4*)rast, (float4*)rast_db, meta);
     else
         raster_tile_kernel<false><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, counts, offsets, entries, ecap,
-                                                                         (float4*)rast, nullptr);
+                                                                         (float4*)rast, nullptr, meta);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(256)
 vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vert_link,
                  const int32_t* __restrict__ tris, VbClusters cl, StepHead head, float* __restrict__ mvp, int V, int nvb,
                  BinGeom g, float4* __restrict__ posc, VbRecs rc, int* __restrict__ lbox, int* __restrict__ zacc,
-                 int nzacc, int* __restrict__ meta, int B, int gx, int xcd_views, VbHeavy hv) {
+                 int nzacc, int* __restrict__ meta, int B, int gx, int xcd_views, VbHeavy hv, int chunk_role) {
     __shared__ float Tc[16];
     __shared__ float M[32][16];
     // 1-D grid of B * gx workgroups.  xcd_views > 0 (B a multiple of 8): workgroup w runs on XCD w % 8 (observed, used
@@ -237,7 +237,11 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         bx = blockIdx.x - b * gx;
     }
     const int tid = threadIdx.x, L = g.L, H = g.H, W = g.W;
-    const bool first = bx == 0 && b == 0;
+    // chunk_role: the views of a step go through the chain in chunks (one, unless views x links exceeds what a job
+    // kernel handles): 1 = first chunk (the per-step housekeeping happens here), 2 = a later one (only the per-chunk
+    // counters are re-armed)
+    const bool first = bx == 0 && b == 0 && chunk_role == 1;
+    const bool rearm = bx == 0 && b == 0 && chunk_role == 2;
     // A view's work items: [0, nvb) blocks of 256 vertices (-> posc), then groups of four clusters (one wave per cluster,
     // one lane per triangle).  The workgroup takes items bx, bx + gx, ...: the pose head above every item (exponential,
     // matrices: ~3 us of dependent arithmetic) is paid once per workgroup, not once per 256 vertices -- with one item per
@@ -311,7 +315,11 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             for (int i = tid; i < n; i += 256) hv.stamp[hv.list[cur * VB_HEAVY_CAP + i]] = gen;
         }
         if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
-        if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors of the 8 XCDs
+        if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors of the 8 XCDs, tickets, slow-job count
+    }
+    if (rearm) {  // a later chunk of the same step: cursors and tickets again, the overflow flag stays
+        if (tid < 8 && tid != EHR_META_OVERFLOW) meta[tid] = 0;
+        if (tid < VB_LINES) *vb_line(meta, tid) = 0;
     }
     if (bx == 0) {  // fixed-point accumulators of this view (a few KB)
         const int nzv = nzacc / B;
@@ -1609,7 +1617,9 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
                     const VbItem* __restrict__ spill, int spill_cap, int* __restrict__ meta, int dbg,
                     const long long* __restrict__ tsum, const long long* __restrict__ vtot,
                     const int* __restrict__ ref_flag, float* __restrict__ loss,
-                    float* __restrict__ grad_mvp, StepTail tail) {
+                    float* __restrict__ grad_mvp, StepTail tail, int do_finish, int B_all,
+                    const long long* __restrict__ facc_all, const long long* __restrict__ vtot_all,
+                    int* __restrict__ lbox_all) {
     __shared__ float gpix_all[4][EHR_TILE_W * EHR_TILE_H];
     extern __shared__ int s_dyn[];  // [U + 1] first job of every (view, link) | [U] its tile range
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1812,6 +1822,7 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     //      last of an XCD one on the top counter: two levels, because a few thousand arrivals on ONE address serialise
     //      at ~12 ns each.  The accumulators are only ever touched by agent-scope atomics and read back with agent-scope
     //      loads (acc_load), so no cache maintenance is needed between the two.
+    if (!do_finish) return;  // (not the last chunk of views: the kernel boundary orders its sums before the last chunk's finish)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int s_last;
@@ -1828,7 +1839,7 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     __shared__ double S[4][17];
     __shared__ float red_lds[8];
 #ifndef VB_NO_FINISH
-    finish_body<TAIL>(g, B, facc, sparse ? vtot : nullptr, loss, grad_mvp, meta, tail, nls, lbox, VB_LOSS_STRIDE,
+    finish_body<TAIL>(g, B_all, facc_all, sparse ? vtot_all : nullptr, loss, grad_mvp, meta, tail, nls, lbox_all, VB_LOSS_STRIDE,
                       gpix_all[0], S, red_lds);
 #endif
 }
@@ -1980,48 +1991,52 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
                    const int32_t* tris, const int32_t* tri_link, const int32_t* opp) {
     if (H > 32760 || W > 32736)  // tile counts are packed into 10 (columns) and 12 (rows) bits
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: resolution above 32736 x 32760 (W x H) is unsupported");
-    if ((long long)B * L > VB_MAX_UNITS)  // the job kernel keeps 8 bytes per (view, link) in LDS
-        return fail(EHR_ERR_INVALID,
-                    "ehr_fused_plan: %d views x %d links exceeds the %d (view, link) units one context handles; split the "
-                    "views over several contexts / calls", B, L, VB_MAX_UNITS);
     if ((V > 0 && !verts) || (T > 0 && (!tris || !tri_link || !opp)))
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: the scene arrays (verts, tris, tri_link, opp) are required");
     int rc;
     if ((rc = vb_build_clusters(ctx, L, V, T, verts, tris, tri_link))) return rc;
     const int NC = std::max(ctx->vb_nc, 1);
+    // The views of a call go through the chain in CHUNKS of Bc views (one chunk in the common case): the job kernel
+    // keeps its (view, link) tables in LDS (VB_MAX_UNITS entries), and the per-chunk scratch -- clip-space vertices,
+    // raster records, job slots (3.5 KB each) -- is bounded to ~2 GB however many views a call brings (the reference
+    // batches all frames of a data set in one step, configs/xarm7/example.yaml: batch_size 100).  A job = a (link, tile)
+    // pair whose boxes touch; by default one slot per (link, tile) is provided, so nothing can overflow; `slack` >= 1
+    // provides `slack` jobs per view tile instead (less scratch, larger chunks); a view that needs more (every pixel
+    // under more than `slack` link boxes on average) is reported (loss = NaN, ehr_fused_status).
+    BinGeom gp = make_geom(H, W, L);
+    const size_t slot_bytes = 256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + VB_WORDS * sizeof(u64) + 2 * sizeof(int) +
+                              VB_RN * sizeof(unsigned) + sizeof(int) + sizeof(int4);
+    const double jobs_per_view = ((slack >= 1.f) ? std::min((double)L, (double)slack) : (double)L) * gp.nt;
+    const double view_bytes = jobs_per_view * slot_bytes + (double)NC * (64 * 40 + 8) + (double)std::max(V, 1) * 16 +
+                              (double)L * gp.nt * 4;
+    static const double budget = getenv("EHR_VB_SCRATCH_MB") ? atof(getenv("EHR_VB_SCRATCH_MB")) * 1048576.0 : 2048.0 * 1048576.0;
+    int Bc = std::min(B, std::max(1, VB_MAX_UNITS / L));
+    Bc = std::max(1, std::min(Bc, (int)(budget / view_bytes)));
+    if (jobs_per_view * Bc > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles of a chunk exceeds 2e9");
+    ctx->vb_chunk = Bc;
     if ((rc = ctx->vb_acc.reserve(((size_t)B * (12 * (size_t)L + VB_LOSS_SLOTS * VB_LOSS_STRIDE)) * sizeof(long long) + EHR_META_INTS * sizeof(int) + (VB_LINES + 1) * 128))) return rc;
-    if ((rc = ctx->vb_posc.reserve((size_t)B * std::max(V, 1) * sizeof(float4)))) return rc;
+    if ((rc = ctx->vb_posc.reserve((size_t)Bc * std::max(V, 1) * sizeof(float4)))) return rc;
     // per step and (view, cluster slot): trec 32 B | tbox 8 B, then cbox 8 B per (view, cluster)
-    if ((rc = ctx->vb_boxes.reserve((size_t)B * NC * (64 * 40 + 8)))) return rc;
+    if ((rc = ctx->vb_boxes.reserve((size_t)Bc * NC * (64 * 40 + 8)))) return rc;
     {  // pool of blended pairs for jobs that exceed their slot (EHR_VB_SPILL_ITEMS: test hook for the overflow path)
         const char* e = getenv("EHR_VB_SPILL_ITEMS");
         ctx->vb_spill_cap = e ? std::max(0, atoi(e)) : VB_SPILL_ITEMS;
         // (the -DVB_TIMELINE profiling build parks its per-wave records here: keep room for them)
         if ((rc = ctx->vb_spill.reserve(std::max((size_t)ctx->vb_spill_cap * sizeof(VbItem), (size_t)1 << 20)))) return rc;
     }
-    if ((rc = ctx->vb_units.reserve((size_t)VB_LBOX_STRIDE * B * L * sizeof(int)))) return rc;  // link boxes (one 64-byte line each)
+    if ((rc = ctx->vb_units.reserve((size_t)VB_LBOX_STRIDE * B * L * sizeof(int)))) return rc;  // link boxes (one 64-byte line each), all views
     {  // a bound reference mask's cached sums: tsum [B][nt] | vtot [B] | flag
-        BinGeom g0 = make_geom(H, W, L);
-        if ((rc = ctx->vb_refsum.reserve(((size_t)B * g0.nt + B + 1) * sizeof(long long)))) return rc;
+        if ((rc = ctx->vb_refsum.reserve(((size_t)B * gp.nt + B + 1) * sizeof(long long)))) return rc;
         ctx->vb_ref = nullptr;  // a new plan forgets the binding
     }
-    {  // job slots, compact (numbered like the jobs): value tile 1 KB | items 1 KB | count | spill base | region ids 1.36 KB;
-       // descriptor; then the links' first jobs
-        BinGeom g = make_geom(H, W, L);
-        // a job = a (link, tile) pair whose boxes touch: `slack` tiles-worth of links per view (default 4 = every pixel
-        // under four link boxes), never more than all of them
-        (void)slack;  // every (view, link, tile) can have its slot: nothing to overflow
-        const double want = (double)L * (double)B * g.nt;
-        if (want > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles exceeds 2e9");
-        ctx->vb_jcap = (int)want;
+    {  // job slots of a chunk, compact (numbered like the jobs): value tile 1 KB | items 1 KB | coverage words | count | spill
+       // base | region ids 1.36 KB | descriptor | an entry of the slow-job list; then the links' first jobs and tile ranges
+        ctx->vb_jcap = (int)(jobs_per_view * Bc);
         const size_t nslot = (size_t)ctx->vb_jcap;
-        if ((rc = ctx->vb_jobs.reserve(nslot * (256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + VB_WORDS * sizeof(u64) +
-                                                2 * sizeof(int) + VB_RN * sizeof(unsigned) + sizeof(int) + sizeof(int4)) +
-                                       (2 * (size_t)B * L + 1) * sizeof(int) + 32))) return rc;
+        if ((rc = ctx->vb_jobs.reserve(nslot * slot_bytes + (2 * (size_t)Bc * L + 1) * sizeof(int) + 32))) return rc;
     }
-    {  // heavy-job hint: generation + two counts | two lists | stamp table
-        BinGeom g = make_geom(H, W, L);
-        const size_t ints = 4 + 2 * (size_t)VB_HEAVY_CAP + (size_t)B * L * g.nt;
+    {  // heavy-job hint: generation + two counts | two lists | stamp table (dense ids of a chunk)
+        const size_t ints = 4 + 2 * (size_t)VB_HEAVY_CAP + (size_t)Bc * L * gp.nt;
         if ((rc = ctx->vb_heavy.reserve(ints * sizeof(int)))) return rc;
         EHR_HIP(hipMemset(ctx->vb_heavy.ptr, 0, ints * sizeof(int)));
     }
@@ -2141,12 +2156,11 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     if (tris != ctx->vb_plan_tris || opp != ctx->vb_plan_opp || verts != ctx->vb_plan_verts)
         return fail(EHR_ERR_INVALID, "fused op: the scene arrays differ from the planned ones; call ehr_fused_plan again");
     BinGeom g = make_geom(H, W, L);
-    const int ntiles = B * g.nt;
-    long long* facc = (long long*)ctx->vb_acc.ptr;
-    const int acc_stride = 12 * L + VB_LOSS_SLOTS * VB_LOSS_STRIDE, nacc_ints = 2 * B * acc_stride;
-    int* meta = (int*)(facc + (size_t)B * acc_stride);
+    long long* const facc_all = (long long*)ctx->vb_acc.ptr;
+    const int acc_stride = 12 * L + VB_LOSS_SLOTS * VB_LOSS_STRIDE;
+    int* meta = (int*)(facc_all + (size_t)B * acc_stride);
     float4* posc = (float4*)ctx->vb_posc.ptr;
-    int* lbox = (int*)ctx->vb_units.ptr;
+    int* const lbox_all = (int*)ctx->vb_units.ptr;
     VbItem* spill = (VbItem*)ctx->vb_spill.ptr;
     const int NC = ctx->vb_nc, NC1 = std::max(NC, 1);
     VbClusters cl;
@@ -2162,11 +2176,6 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     hv.gen = (int*)ctx->vb_heavy.ptr;
     hv.list = hv.gen + 4;
     hv.stamp = hv.list + 2 * VB_HEAVY_CAP;
-    VbRecs recs;
-    recs.n = (size_t)B * NC1 * 64;
-    recs.trec = (int4*)ctx->vb_boxes.ptr;
-    recs.tbox = (uint2*)(recs.trec + recs.n * 2);
-    recs.cbox = recs.tbox + recs.n;
 
     hipEvent_t* ev = nullptr;
     if (ctx->timing) {
@@ -2181,31 +2190,21 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         EHR_HIP(hipEventRecord(ev[0], stream));
     }
     const int vec_ok = ((W & 3) == 0) && (((uintptr_t)ref & 15) == 0) && (!mask || ((uintptr_t)mask & 15) == 0);
-    // stage 0: [pose forward] + vertices + screen boxes
-    const int nvb = (std::max(V, 1) + 255) / 256;
-    // workgroups per view: as many as stay resident together (5 per CU), every one with the same number of work items
-    const int nitems = nvb + (NC + 3) / 4;
-    static const int vertex_grid = getenv("EHR_VB_VERTEX_GRID") ? atoi(getenv("EHR_VB_VERTEX_GRID")) : 5;  // tuning knob
-    const int per_view_cap = std::max(8, (ctx->num_cus * std::max(1, vertex_grid)) / std::max(B, 1));
-    const int items_per_wg = (nitems + per_view_cap - 1) / per_view_cap;
-    const int gx = std::max(1, (nitems + items_per_wg - 1) / std::max(items_per_wg, 1));
-    static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
-    const int xcd_views = (xcd_align && (B % 8) == 0) ? B / 8 : 0;
-    const dim3 vgrid(gx * B);
-    if (head) {
-        vb_vertex_kernel<true><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, *head, mvp, V, nvb, g, posc, recs,
-                                                         lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views, hv);
-    } else {
-        StepHead none = {};
-        vb_vertex_kernel<false><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, none, mvp, V, nvb, g, posc, recs,
-                                                          lbox, (int*)facc, nacc_ints, meta, B, gx, xcd_views, hv);
-    }
-    EHR_LAUNCH_CHECK();
-    if (ev) EHR_HIP(hipEventRecord(ev[1], stream));
-    // stage 1: jobs = (view, link, tile) -> per-link values and blended pairs
-    static const int dbg = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;  // measurement aid only
+    static const int dbg_env = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;  // measurement aid only
     static const int job_grid = getenv("EHR_VB_JOB_GRID") ? atoi(getenv("EHR_VB_JOB_GRID")) : 4;   // tuning knob
     static const int heavy_t = getenv("EHR_VB_HEAVY_T") ? atoi(getenv("EHR_VB_HEAVY_T")) : VB_HEAVY_T_DEFAULT;  // tuning knob
+    static const int vertex_grid = getenv("EHR_VB_VERTEX_GRID") ? atoi(getenv("EHR_VB_VERTEX_GRID")) : 5;  // tuning knob
+    static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
+    static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
+    static const int no_sparse = getenv("EHR_VB_NO_SPARSE") ? atoi(getenv("EHR_VB_NO_SPARSE")) : 0;  // A/B aid
+    static const int comp_grid = getenv("EHR_VB_COMPOSITE_GRID") ? atoi(getenv("EHR_VB_COMPOSITE_GRID")) : 6;  // tuning knob (6 resident per CU)
+    const bool sparse = !no_sparse && !mask && ctx->vb_ref != nullptr && ctx->vb_ref == ref;
+    const long long* const tsum_all = sparse ? (const long long*)ctx->vb_refsum.ptr : nullptr;
+    const long long* const vtot_all = sparse ? tsum_all + (size_t)B * g.nt : nullptr;
+    const int* const ref_flag = sparse ? (const int*)(vtot_all + B) : nullptr;
+    const int Bc = std::max(1, std::min(ctx->vb_chunk, B));
+    // (the heavy-job hint names jobs by their dense id inside a chunk: with more than one chunk it is switched off)
+    const int dbg = dbg_env | (Bc < B ? 64 : 0);
     const size_t nslot = (size_t)ctx->vb_jcap;
     float* jval = (float*)ctx->vb_jobs.ptr;
     VbItem* jitems = (VbItem*)(jval + nslot * 256);
@@ -2214,53 +2213,87 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     int* jspill = jn + nslot;
     unsigned* jid = (unsigned*)(jspill + nslot);
     int* jdesc = (int*)(jid + nslot * VB_RN);
-    int* jbase = jdesc + nslot;                               // [B * L + 1] first job of every (view, link)
-    unsigned* jutile = (unsigned*)(jbase + (size_t)B * L + 1);  // [B * L] its tile range
-    int4* slow_list = (int4*)(((uintptr_t)(jutile + (size_t)B * L) + 15) & ~(uintptr_t)15);  // [nslot] jobs for vb_slow_kernel
-    const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
-    vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, B, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg, hv,
-                                                (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t);
-    EHR_LAUNCH_CHECK();
-    // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
-    vb_slow_kernel<<<ctx->num_cus, 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
-    EHR_LAUNCH_CHECK();
-    if (ev) EHR_HIP(hipEventRecord(ev[2], stream));
-    // stage 1b: drawn jobs -> per-link values and blended pairs
-    static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
-    const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
-    vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, B, posc, V, T, (const int4*)ctx->vb_idx.ptr, (const int4*)ctx->vb_idx.ptr + T,
-                                                   jid, jcov, jdesc, jn, jval, jitems, jspill, ctx->vb_jcap, grad_mvp ? 1 : 0, spill,
-                                                   ctx->vb_spill_cap, meta, dbg);
-    EHR_LAUNCH_CHECK();
-    if (ev) {
-        for (int k = 3; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
+    int* jbase = jdesc + nslot;                                 // [Bc * L + 1] first job of every (view, link) of the chunk
+    unsigned* jutile = (unsigned*)(jbase + (size_t)Bc * L + 1);  // [Bc * L] its tile range
+    int4* slow_list = (int4*)(((uintptr_t)(jutile + (size_t)Bc * L) + 15) & ~(uintptr_t)15);  // [nslot] jobs for vb_slow_kernel
+    const int nvb = (std::max(V, 1) + 255) / 256;
+    const int nitems = nvb + (NC + 3) / 4;
+    for (int b0 = 0; b0 < B; b0 += Bc) {  // chunks of views (one, unless views x links / scratch say otherwise)
+        const int Bk = std::min(Bc, B - b0);
+        const bool first_chunk = b0 == 0, last_chunk = b0 + Bk == B;
+        const bool time_it = ev && last_chunk;  // (stage times of a multi-chunk call: those of its last chunk)
+        long long* facc = facc_all + (size_t)b0 * acc_stride;
+        int* lbox = lbox_all + (size_t)VB_LBOX_STRIDE * b0 * L;
+        float* mvp_k = mvp + (size_t)b0 * L * 16;
+        const float* ref_k = ref + (size_t)b0 * H * W;
+        float* mask_k = mask ? mask + (size_t)b0 * H * W : nullptr;
+        VbRecs recs;
+        recs.n = (size_t)Bk * NC1 * 64;
+        recs.trec = (int4*)ctx->vb_boxes.ptr;
+        recs.tbox = (uint2*)(recs.trec + recs.n * 2);
+        recs.cbox = recs.tbox + recs.n;
+        // stage 0: [pose forward] + vertices + screen boxes
+        // workgroups per view: as many as stay resident together (5 per CU), every one with the same number of work items
+        const int per_view_cap = std::max(8, (ctx->num_cus * std::max(1, vertex_grid)) / std::max(Bk, 1));
+        const int items_per_wg = (nitems + per_view_cap - 1) / per_view_cap;
+        const int gx = std::max(1, (nitems + items_per_wg - 1) / std::max(items_per_wg, 1));
+        const int xcd_views = (xcd_align && (Bk % 8) == 0) ? Bk / 8 : 0;
+        const dim3 vgrid(gx * Bk);
+        const int nacc_ints = 2 * Bk * acc_stride;
+        const int role = first_chunk ? 1 : 2;
+        if (head) {
+            StepHead hk = *head;
+            hk.link_poses = head->link_poses + (size_t)b0 * L * 16;
+            vb_vertex_kernel<true><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, hk, mvp_k, V, nvb, g, posc, recs, lbox,
+                                                             (int*)facc, nacc_ints, meta, Bk, gx, xcd_views, hv, role);
+        } else {
+            StepHead none = {};
+            vb_vertex_kernel<false><<<vgrid, 256, 0, stream>>>(verts, vert_link, tris, cl, none, mvp_k, V, nvb, g, posc, recs,
+                                                              lbox, (int*)facc, nacc_ints, meta, Bk, gx, xcd_views, hv, role);
+        }
+        EHR_LAUNCH_CHECK();
+        if (time_it) EHR_HIP(hipEventRecord(ev[1], stream));
+        // stage 1: jobs = (view, link, tile) -> coverage and the triangle ids the silhouette analysis will ask for
+        const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
+        vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg,
+                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t);
+        EHR_LAUNCH_CHECK();
+        // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
+        vb_slow_kernel<<<ctx->num_cus, 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
+        EHR_LAUNCH_CHECK();
+        if (time_it) EHR_HIP(hipEventRecord(ev[2], stream));
+        // stage 1b: drawn jobs -> per-link values and blended pairs
+        const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
+        vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, Bk, posc, V, T, (const int4*)ctx->vb_idx.ptr,
+                                                       (const int4*)ctx->vb_idx.ptr + T, jid, jcov, jdesc, jn, jval, jitems, jspill,
+                                                       ctx->vb_jcap, grad_mvp ? 1 : 0, spill, ctx->vb_spill_cap, meta, dbg);
+        EHR_LAUNCH_CHECK();
+        if (time_it) {
+            for (int k = 3; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
+        }
+        // stage 2: composite, loss, mask, backward.  In the call's last chunk its last-arriving workgroup runs the finish
+        // stage over ALL views (accumulators -> loss / grad_mvp, + pose backward and Adam in the solver-step form; re-arms
+        // the link boxes).  With a bound reference mask and no mask output only tiles that hold a job are visited.
+        int nwg = ctx->num_cus * std::max(1, comp_grid);
+        if (!sparse) nwg = std::min(nwg, (Bk * g.nt + 3) / 4);
+        nwg = std::max(8, (nwg + 7) & ~7);  // a multiple of 8: the XCD split and the two-level arrival ticket rely on it
+        const long long* tsum = sparse ? tsum_all + (size_t)b0 * g.nt : nullptr;
+        const long long* vtot = sparse ? vtot_all + b0 : nullptr;
+        const size_t dyn = (2 * (size_t)Bk * L + 1) * sizeof(int);  // link tables in LDS
+        if (tail) {
+            vb_composite_kernel<true><<<nwg, 256, dyn, stream>>>(
+                g, Bk, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, jutile, ctx->vb_jcap, ref_k, mask_k, facc,
+                VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss, grad_mvp,
+                *tail, last_chunk ? 1 : 0, B, facc_all, vtot_all, lbox_all);
+        } else {
+            StepTail none = {};
+            vb_composite_kernel<false><<<nwg, 256, dyn, stream>>>(
+                g, Bk, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, jutile, ctx->vb_jcap, ref_k, mask_k, facc,
+                VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss, grad_mvp,
+                none, last_chunk ? 1 : 0, B, facc_all, vtot_all, lbox_all);
+        }
+        EHR_LAUNCH_CHECK();
     }
-    // stage 2: composite, loss, mask, backward; its last-arriving workgroup runs the finish stage (accumulators -> loss /
-    // grad_mvp, + pose backward and Adam in the solver-step form; re-arms the link boxes).  With a bound reference mask
-    // and no mask output only the tiles inside the views' link rectangles are visited.
-    static const int no_sparse = getenv("EHR_VB_NO_SPARSE") ? atoi(getenv("EHR_VB_NO_SPARSE")) : 0;  // A/B aid
-    const bool sparse = !no_sparse && !mask && ctx->vb_ref != nullptr && ctx->vb_ref == ref;
-    static const int comp_grid = getenv("EHR_VB_COMPOSITE_GRID") ? atoi(getenv("EHR_VB_COMPOSITE_GRID")) : 6;  // tuning knob (6 resident per CU)
-    int nwg = ctx->num_cus * std::max(1, comp_grid);
-    if (!sparse) nwg = std::min(nwg, (ntiles + 3) / 4);
-    nwg = std::max(8, (nwg + 7) & ~7);  // a multiple of 8: the XCD split and the two-level arrival ticket rely on it
-    const long long* tsum = sparse ? (const long long*)ctx->vb_refsum.ptr : nullptr;
-    const long long* vtot = sparse ? tsum + (size_t)B * g.nt : nullptr;
-    const int* ref_flag = sparse ? (const int*)(vtot + B) : nullptr;
-    const size_t dyn = (2 * (size_t)B * L + 1) * sizeof(int);  // link tables in LDS
-    if (tail) {
-        vb_composite_kernel<true><<<nwg, 256, dyn, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase,
-                                                         jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0,
-                                                         vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag,
-                                                         loss, grad_mvp, *tail);
-    } else {
-        StepTail none = {};
-        vb_composite_kernel<false><<<nwg, 256, dyn, stream>>>(g, B, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase,
-                                                          jutile, ctx->vb_jcap, ref, mask, facc, VB_LOSS_SLOTS, grad_mvp ? 1 : 0,
-                                                          vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot,
-                                                          ref_flag, loss, grad_mvp, none);
-    }
-    EHR_LAUNCH_CHECK();
     if (ev) {
         for (int k = 5; k <= 7; k++) EHR_HIP(hipEventRecord(ev[k], stream));
     }

@@ -192,6 +192,9 @@ class TopologyHash:
         self.num_triangles = num_triangles
 
 
+_TOPO_CACHE = {}
+
+
 def antialias_construct_topology_hash(tri):
     """``dr.antialias_construct_topology_hash(tri)``: build once per mesh, pass as ``topology_hash=``."""
     _check_dev("tri", tri, torch.int32)
@@ -260,7 +263,16 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
              (pos.dim() == 2 and pos.shape[1] == 4), "pos must have shape [B, >0, 4] or [>0, 4]")
     tri = tri.contiguous()
     if topology_hash is None:
-        topology_hash = antialias_construct_topology_hash(tri)
+        # nvdiffrast rebuilds the topology on every such call; the result only depends on tri, so the last few are kept
+        # (keyed by the tensor's storage and version counter: an in-place edit of tri invalidates the entry)
+        key = (tri.data_ptr(), tri._version, tri.shape[0], tri.device.index)
+        topology_hash = _TOPO_CACHE.get(key)
+        if topology_hash is None:
+            topology_hash = antialias_construct_topology_hash(tri)
+            if len(_TOPO_CACHE) >= 64:
+                _TOPO_CACHE.clear()
+            _TOPO_CACHE[key] = topology_hash
+            topology_hash._keepalive = tri  # the key's address stays this tensor's while the entry lives
     _require(isinstance(topology_hash, TopologyHash) and topology_hash.num_triangles == tri.shape[0],
              "topology_hash does not belong to tri")
     return _AntialiasFunc.apply(color.contiguous(), rast.contiguous(), pos.contiguous(), tri, topology_hash.opp,

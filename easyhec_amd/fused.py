@@ -46,7 +46,7 @@ class LinkScene:
 class _Plan:
     """Per-context plan for one (B, L, T, H, W) shape: sizes the ctx scratch once so the hot call never allocates."""
 
-    def __init__(self, glctx, scene, B, H, W, slack=4.0):
+    def __init__(self, glctx, scene, B, H, W, slack=0.0):
         self.key = _plan_key(scene, B, H, W)
         with torch.cuda.device(glctx.device):
             _lib.check(_lib.lib().ehr_fused_plan(glctx.handle, B, scene.num_links, scene.num_verts, scene.num_tris, H, W,

@@ -49,7 +49,9 @@ int ehr_ctx_destroy(ehr_ctx* ctx);
  * instance mode (ranges_host == NULL): pos [B,V,4], every image draws all T triangles.
  * range mode: pos [V,4], image b draws triangles ranges_host[2b] .. +ranges_host[2b+1] (HOST int32 [B,2]).
  * rast [B,H,W,4] = (u, v, z/w, triangle_id+1); rast_db [B,H,W,4] = (du/dx, du/dy, dv/dx, dv/dy) or NULL.
- * Synchronises once (reads back the bin-queue size to grow scratch if needed), like nvdiffrast's own rasterizer. */
+ * Synchronises only while it is sizing its queue storage (first calls of a shape): in steady state the size of a frame
+ * reaches the host asynchronously and is looked at by the next call; a frame that needs more than twice what the previous one
+ * did is returned as NaN (never silently incomplete) and the storage grows for the next. */
 int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
                       int T, int H, int W, float* rast, float* rast_db, void* stream);
 
@@ -97,12 +99,15 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  * spatially close triangles per link, padded index tables), so it takes the scene arrays -- the SAME device arrays that
  * are later passed to ehr_render_mask_loss / ehr_solver_step (they are checked by address; call it again when the
  * scene, the shape or the arrays change -- also when only the CONTENTS of verts / tris change: the index holds a copy
- * of every triangle's corners).  Limits of the default chain, checked here: B x L <= 512, L <= 32, W <= 32736, H <= 32760.  The hot calls never synchronise or allocate, so they can be captured in a
- * hipGraph; a new plan invalidates a captured graph.  One slot per (view, link, tile) is reserved, so nothing on this
- * path can overflow except the fixed-point accumulators (|sum| > 2^31) and a 16 MB spill pool for tiles with more than
- * 64 blended pairs per link: then loss[] is NaN (never a silently wrong image), the optimiser state is left untouched
- * and ehr_fused_status() returns EHR_ERR_OVERFLOW after synchronising.  `slack` only matters for the round-1 tile chain
- * (EHR_FUSED_PATH=tile: bin-queue capacity). */
+ * of every triangle's corners).  Limits, checked here: L <= 32, W <= 32736, H <= 32760, <= 262144 triangles per link.
+ * Any number of views: a call's views go through the launch chain in chunks (one chunk up to 512 / L views; fewer per
+ * chunk when the chunk's scratch -- clip-space vertices, raster records, 3.5 KB per (view, link, tile) job slot -- would
+ * exceed ~2 GB, EHR_VB_SCRATCH_MB), all inside the one call.  The hot calls never synchronise or allocate, so they can be
+ * captured in a hipGraph; a new plan invalidates a captured graph.  `slack` < 1 (default): one job slot per (view, link,
+ * tile), nothing can overflow except the fixed-point accumulators (|sum| > 2^31) and a 16 MB spill pool for tiles with
+ * more than 64 blended pairs per link; `slack` >= 1 provides only `slack` job slots per view tile (less scratch, larger
+ * chunks).  An overflow makes loss[] NaN (never a silently wrong image), leaves the optimiser state untouched, and
+ * ehr_fused_status() returns EHR_ERR_OVERFLOW after synchronising. */
 int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
                    const int32_t* tris, const int32_t* tri_link, const int32_t* opp);
 int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,

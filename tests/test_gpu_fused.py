@@ -339,15 +339,83 @@ def test_fused_edge_cases(env, oracle, xarm7):
     assert abs(float(loss[0]) - float((mask.astype(np.float64) ** 2).sum())) <= 1e-6 * float(loss[0])
 
 
-def test_plan_rejects_more_units_than_a_context_handles(env, xarm7):
-    """views x links above 512: an error that says so at plan time, not an out-of-bounds job table."""
-    fused, ctx, scene, dev = env
+def test_many_views_go_through_in_chunks(env, xarm7, oracle):
+    """views x links above the 512 (view, link) units one pass of the chain handles (the reference batches a whole data
+    set per step: batch_size 100 x 7-8 links), and a scratch budget that forces still smaller chunks: the call splits its
+    views into chunks internally.  Every view's loss and gradient must equal, bit for bit, what the same view gives in a
+    small single-chunk call; spot-checked against the oracle; the bound-reference path included."""
+    fused, _, scene, dev = env
     from easyhec_amd import dr
+    B, H, W, scale = 70, 96, 128, 0.1                   # 70 views x 8 links = 560 units -> 2 chunks (64 + 6)
+    K, lp, Tc, mvp = workload(xarm7, H, W, scale, B, seed=11)
+    rng = np.random.default_rng(11)
+    ref = torch.tensor((rng.uniform(size=(B, H, W)) > 0.8).astype(np.float32), device=dev)
+    tm = torch.tensor(mvp, device=dev)
+
+    def call(ctx, sl, bound):
+        n = sl.stop - sl.start
+        r, m = ref[sl].contiguous(), tm[sl].contiguous()
+        fused._ensure_plan(ctx, scene, n, H, W)
+        fused.bind_ref(ctx, scene, r if bound else None)
+        loss, grad = torch.empty((n,), device=dev), torch.empty((n, scene.num_links, 4, 4), device=dev)
+        fused._launch(ctx, scene, m, r, None, loss, grad)
+        torch.cuda.synchronize()
+        fused.check_status(ctx)
+        return loss, grad
+
+    big = dr.RasterizeCudaContext()
+    l_all, g_all = call(big, slice(0, B), False)
+    l_bnd, g_bnd = call(big, slice(0, B), True)
+    assert torch.equal(l_all, l_bnd) and torch.equal(g_all, g_bnd)
+    small = dr.RasterizeCudaContext()
+    for lo in (0, 30, 60):                               # 10-view single-chunk calls, one of them across the chunk border
+        l_s, g_s = call(small, slice(lo, lo + 10), False)
+        assert torch.equal(l_all[lo:lo + 10], l_s) and torch.equal(g_all[lo:lo + 10], g_s)
+    os.environ["EHR_VB_SCRATCH_MB"] = "1"               # (read once per process by the library: only effective if first)
+    verts, tris, toff, voff = helpers.scene_arrays(xarm7)
+    for b in (0, 65):
+        m_ref, l_ref, g_ref = oracle.render_mask_loss(verts, tris, toff, voff, mvp[b:b + 1], ref[b:b + 1].cpu().numpy())
+        assert abs(float(l_all[b]) - l_ref[0]) <= 1e-6 * abs(l_ref[0])
+        assert np.abs(g_all[b].cpu().numpy() - g_ref[0]).max() <= 1e-5 * np.abs(g_ref).max()
+    # the mask-output form in chunks: masks of the chunked call == masks of the small calls
+    mask = torch.empty((B, H, W), device=dev)
+    loss_m = torch.empty((B,), device=dev)
+    fused._ensure_plan(big, scene, B, H, W)
+    fused._launch(big, scene, tm, ref, mask, loss_m, None)
+    torch.cuda.synchronize()
+    assert torch.equal(loss_m, l_all)
+    mref, _, _ = oracle.render_mask_loss(verts, tris, toff, voff, mvp[66:67], ref[66:67].cpu().numpy())
+    assert (mask[66].cpu().numpy() == mref[0]).all()
+
+
+def test_job_slots_limited_by_slack_report_overflow(env, xarm7):
+    """ehr_fused_plan(slack >= 1) provides only `slack` job slots per view tile; a close-up view in which the links' boxes
+    overlap needs more than one: reported (NaN loss, raised status), never a silently incomplete image.  (The default
+    plan has a slot for every (view, link, tile): the same call is fine there.)"""
+    fused, _, scene, dev = env
+    from easyhec_amd import _lib, dr
+    import ctypes
+    H, W, B = 64, 96, 2
+    K, lp, Tc, mvp = workload(xarm7, H, W, 0.075, B, seed=3)
+    mvp[:, :, :2, :] *= 2.5                             # zoom: the robot fills the frame, the links' boxes overlap
+    ctx = dr.RasterizeCudaContext()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ehr_fused_plan(ctx.handle, B, scene.num_links, scene.num_verts, scene.num_tris, H, W,
+                                             ctypes.c_float(1.0), _lib.ptr(scene.verts), _lib.ptr(scene.tris),
+                                             _lib.ptr(scene.tri_link), _lib.ptr(scene.opp)), "plan")
+    ctx._plan = type("P", (), {"key": fused._plan_key(scene, B, H, W)})()
+    loss = torch.empty((B,), device=dev)
+    fused._launch(ctx, scene, torch.tensor(mvp, device=dev), torch.zeros((B, H, W), device=dev), None, loss, None)
+    torch.cuda.synchronize()
+    assert torch.isnan(loss).all()
+    with pytest.raises(RuntimeError, match="overflow"):
+        fused.check_status(ctx)
     ctx2 = dr.RasterizeCudaContext()
-    B, H, W = 65, 16, 32                                # 65 views x 8 links = 520 units
-    with pytest.raises(RuntimeError, match="exceeds the 512"):
-        fused._ensure_plan(ctx2, scene, B, H, W)
-    fused._ensure_plan(ctx2, scene, 64, H, W)           # 512 units exactly: fine
+    fused._ensure_plan(ctx2, scene, B, H, W)
+    fused._launch(ctx2, scene, torch.tensor(mvp, device=dev), torch.zeros((B, H, W), device=dev), None, loss, None)
+    torch.cuda.synchronize()
+    fused.check_status(ctx2)
+    assert torch.isfinite(loss).all() and float(loss.min()) > 100.0   # (SSE against an empty reference = covered area)
 
 
 @pytest.mark.parametrize("H,W,scale,B", [(720, 1280, 1.0, 8), (100, 150, 0.12, 3)])
