@@ -492,7 +492,7 @@ struct alignas(16) VbWaveLds {   // per wave of the job kernel
 #ifdef VB_TIMELINE
     int tl_units, tl_rounds;     // profiling build: 4-pixel units walked / rounds run by this wave
     int tl_flushes, tl_tested, tl_deferred;
-    long long tl_c[4];           // cycles: staging, prefix + search, walk, flush
+    long long tl_c[8];           // cycles: staging, prefix + search, walk, flush, job total, claim + set-up, publish, -
 #endif
 };
 
@@ -1121,6 +1121,12 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     const int nheavy_prev = hv.gen[1 + hcur];
     const int hmax = (dbg >> 8) ? (dbg >> 8) : (int)gridDim.x / 2;  // (EHR_VB_DEBUG bits 8..: experiment with the limit)
     const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > hmax) ? 0 : min(nheavy_prev, VB_HEAVY_CAP);
+    // ... and when there are fewer jobs than waves (one view, small images) most workgroups are idle anyway: jobs count as
+    // heavy from a proportionally lower cost (down to an eighth: a few rounds), so that the longest ones are shared
+    {
+        const float f = fminf(1.f, fmaxf(0.125f, (float)total / (float)(2 * (int)gridDim.x)));
+        heavy_t = (int)((float)heavy_t * f);
+    }
     auto remember_heavy = [&](int id) {
         const int at = atomicAdd(&hv.gen[1 + hnxt], 1);
         if (at < VB_HEAVY_CAP) hv.list[hnxt * VB_HEAVY_CAP + at] = id;
@@ -1172,6 +1178,9 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
                 s_heavy[0] = 0;
                 s_heavy[1] = 0;
                 if (tot_surv >= heavy_t) remember_heavy(id);
+#ifdef VB_TIMELINE
+                S0.tl_flushes = tot_surv;  // (profiling build: wave 0's counters are reset after the heavy phase; parked here)
+#endif
             }
         }
         __syncthreads();
@@ -1187,14 +1196,19 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     int tl_jobs = 0, tl_maxsurv = 0, tl_sumsurv = 0;
 #endif
 #ifdef VB_TIMELINE
+    const int tl_hcost = (wave == 0) ? lds_all[0].tl_flushes : 0;
+    VB_WAVE_SYNC();
     if (lane == 0) {
         S.tl_units = S.tl_rounds = S.tl_flushes = S.tl_tested = S.tl_deferred = 0;
-        S.tl_c[0] = S.tl_c[1] = S.tl_c[2] = S.tl_c[3] = 0;
+        for (int k = 0; k < 8; k++) S.tl_c[k] = 0;
     }
 #endif
     bool first_job = kx >= hk;
     int sjob = jbeg + (kx - hk) * 4 + wave;
     for (;;) {
+#ifdef VB_TIMELINE
+        const long long tl_j0 = __builtin_readcyclecounter();
+#endif
         int job = 0;
         if (first_job || (dbg & 8)) {
             job = sjob;
@@ -1242,6 +1256,9 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         }
         if (lane < VB_RH) S.cov[lane] = 0ull;
         VB_WAVE_SYNC();
+#ifdef VB_TIMELINE
+        const long long tl_j1 = __builtin_readcyclecounter();
+#endif
         int nsurv = 0, dln = 0;
         const int drawn = vb_job_raster<false>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
         if (drawn < 0) {  // a triangle for the general path (near-plane clipping, huge extent): put the job aside
@@ -1262,7 +1279,18 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             }
             continue;
         }
+#ifdef VB_TIMELINE
+        const long long tl_j2 = __builtin_readcyclecounter();
+#endif
         vb_publish(A, S.key, S.cov, job, u, tx, ty);
+#ifdef VB_TIMELINE
+        if (lane == 0) {
+            const long long now = __builtin_readcyclecounter();
+            S.tl_c[4] += now - tl_j0;
+            S.tl_c[5] += tl_j1 - tl_j0;
+            S.tl_c[6] += now - tl_j2;
+        }
+#endif
     }
 #ifdef VB_TIMELINE
     if (lane == 0) {
@@ -1274,11 +1302,13 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         timeline[4 * gw + 2] = tl_heavy;
         timeline[4 * gw + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
                                ((long long)(hwid & 0xffff) << 32) | ((long long)(xccid & 0xf) << 48);
-        long long* const tx = timeline + 4 * (size_t)gridDim.x * 4 + 8 * gw;
+        long long* const tx = timeline + 4 * (size_t)gridDim.x * 4 + 12 * gw;
         tx[0] = S.tl_units;
         tx[1] = S.tl_rounds;
         tx[2] = (long long)S.tl_flushes | ((long long)S.tl_tested << 16) | ((long long)S.tl_deferred << 40);
         for (int k = 0; k < 4; k++) tx[3 + k] = S.tl_c[k];
+        tx[7] = tl_hcost;
+        for (int k = 0; k < 3; k++) tx[8 + k] = S.tl_c[4 + k];
     }
 #else
     (void)timeline;
@@ -1998,7 +2028,8 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     const int NC = std::max(ctx->vb_nc, 1);
     // The views of a call go through the chain in CHUNKS of Bc views (one chunk in the common case): the job kernel
     // keeps its (view, link) tables in LDS (VB_MAX_UNITS entries), and the per-chunk scratch -- clip-space vertices,
-    // raster records, job slots (3.5 KB each) -- is bounded to ~2 GB however many views a call brings (the reference
+    // raster records, job slots (3.5 KB each) -- is bounded to 24 GB of the 288 (EHR_VB_SCRATCH_MB) however many views a
+    // call brings: a chunk costs a pass of the chain with its own tails, so chunks are as large as they may be (the reference
     // batches all frames of a data set in one step, configs/xarm7/example.yaml: batch_size 100).  A job = a (link, tile)
     // pair whose boxes touch; by default one slot per (link, tile) is provided, so nothing can overflow; `slack` >= 1
     // provides `slack` jobs per view tile instead (less scratch, larger chunks); a view that needs more (every pixel
@@ -2009,7 +2040,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     const double jobs_per_view = ((slack >= 1.f) ? std::min((double)L, (double)slack) : (double)L) * gp.nt;
     const double view_bytes = jobs_per_view * slot_bytes + (double)NC * (64 * 40 + 8) + (double)std::max(V, 1) * 16 +
                               (double)L * gp.nt * 4;
-    static const double budget = getenv("EHR_VB_SCRATCH_MB") ? atof(getenv("EHR_VB_SCRATCH_MB")) * 1048576.0 : 2048.0 * 1048576.0;
+    static const double budget = getenv("EHR_VB_SCRATCH_MB") ? atof(getenv("EHR_VB_SCRATCH_MB")) * 1048576.0 : 24576.0 * 1048576.0;
     int Bc = std::min(B, std::max(1, VB_MAX_UNITS / L));
     Bc = std::max(1, std::min(Bc, (int)(budget / view_bytes)));
     if (jobs_per_view * Bc > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles of a chunk exceeds 2e9");
@@ -2076,7 +2107,7 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
             // Timeline of the job kernel's waves (100 MHz clock), written into the (otherwise idle) spill pool: when
             // they started, left the heavy phase and ended; what their single-wave jobs amounted to; where they ran.
             const int nw = 4 * (((ctx->num_cus * 4) + 7) & ~7);
-            std::vector<long long> tl((size_t)12 * nw);
+            std::vector<long long> tl((size_t)16 * nw);
             EHR_HIP(hipMemcpy(tl.data(), ctx->vb_spill.ptr, tl.size() * sizeof(long long), hipMemcpyDeviceToHost));
             long long t0 = tl[0], t1 = tl[1];
             for (int i = 0; i < nw; i++) {
@@ -2110,7 +2141,7 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                 const int i = order[k].second;
                 const long long x = tl[4 * i + 3];
                 const unsigned hw = (unsigned)(x >> 32) & 0xffff;
-                const long long* tx = &tl[4 * (size_t)nw + 8 * i];
+                const long long* tx = &tl[4 * (size_t)nw + 12 * i];
                 fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; %lld units in %lld rounds ; %lld flushes: %lld of %lld units tested ; kcycles stage %.0f search %.0f walk %.0f flush %.0f ; xcc %lld cu %u simd %u\n", i, i / 4,
                         (tl[4 * i] - t0) * 0.01, (tl[4 * i + 2] - t0) * 0.01, (tl[4 * i + 1] - t0) * 0.01, x & 0xff, (x >> 8) & 0xfff,
                         (x >> 20) & 0xfff, tx[0], tx[1], tx[2] & 0xffff, (tx[2] >> 16) & 0xffffff, tx[2] >> 40, tx[3] * 1e-3, tx[4] * 1e-3, tx[5] * 1e-3,
@@ -2127,9 +2158,9 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
             {
                 long long us = 0, rs = 0, umax = 0;
                 long long fl = 0, te = 0, de = 0;
-                double cyc[4] = {0, 0, 0, 0};
+                double cyc[4] = {0, 0, 0, 0}, jc[3] = {0, 0, 0};
                 for (int i = 0; i < nw; i++) {
-                    const long long* tx = &tl[4 * (size_t)nw + 8 * i];
+                    const long long* tx = &tl[4 * (size_t)nw + 12 * i];
                     us += tx[0];
                     rs += tx[1];
                     umax = std::max(umax, tx[0]);
@@ -2137,8 +2168,22 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                     te += (tx[2] >> 16) & 0xffffff;
                     de += tx[2] >> 40;
                     for (int k = 0; k < 4; k++) cyc[k] += (double)tx[3 + k];
+                    for (int k = 0; k < 3; k++) jc[k] += (double)tx[8 + k];
                 }
                 fprintf(stderr, "[ehr timeline] single-wave jobs: %lld units in %lld rounds (%.0f units per round), at most %lld units on one wave\n", us, rs, rs ? (double)us / rs : 0.0, umax);
+                {   // heavy phase: cost of the job a workgroup shared vs the time it took
+                    std::vector<std::pair<long long, long long>> hp;
+                    for (int i = 0; i < nw; i += 4) {
+                        const long long* tx = &tl[4 * (size_t)nw + 12 * i];
+                        if (tx[7] > 0) hp.push_back(std::make_pair(tl[4 * i + 2] - tl[4 * i], tx[7]));
+                    }
+                    std::sort(hp.begin(), hp.end());
+                    fprintf(stderr, "[ehr timeline] heavy phase: %zu workgroups; (us, cost) of every 16th by duration:", hp.size());
+                    for (size_t k = 0; k < hp.size(); k += std::max<size_t>(1, hp.size() / 16)) fprintf(stderr, " (%.1f, %lld)", hp[k].first * 0.01, hp[k].second);
+                    if (!hp.empty()) fprintf(stderr, " (%.1f, %lld)", hp.back().first * 0.01, hp.back().second);
+                    fprintf(stderr, "\n");
+                }
+                fprintf(stderr, "[ehr timeline] single-wave jobs (drawn ones): %.1f wave-Mcycles in total, claim + set-up %.1f, publish %.1f\n", jc[0] * 1e-6, jc[1] * 1e-6, jc[2] * 1e-6);
                 fprintf(stderr, "[ehr timeline] flushes %lld, deferred units %lld, depth-tested units %lld; wave-Mcycles: staging %.1f, prefix+search %.1f, walk %.1f, flush %.1f (of %.1f in total)\n",
                         fl, de, te, cyc[0] * 1e-6, cyc[1] * 1e-6, cyc[2] * 1e-6, cyc[3] * 1e-6, busy * 0.01 * 2100.0 * 1e-6);
             }
@@ -2259,7 +2304,8 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                                                     hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
-        vb_slow_kernel<<<ctx->num_cus, 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
+        static const int slow_grid = getenv("EHR_VB_SLOW_GRID") ? atoi(getenv("EHR_VB_SLOW_GRID")) : 32;  // tuning knob
+        vb_slow_kernel<<<std::max(1, slow_grid), 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
         EHR_LAUNCH_CHECK();
         if (time_it) EHR_HIP(hipEventRecord(ev[2], stream));
         // stage 1b: drawn jobs -> per-link values and blended pairs

@@ -101,8 +101,8 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  * scene, the shape or the arrays change -- also when only the CONTENTS of verts / tris change: the index holds a copy
  * of every triangle's corners).  Limits, checked here: L <= 32, W <= 32736, H <= 32760, <= 262144 triangles per link.
  * Any number of views: a call's views go through the launch chain in chunks (one chunk up to 512 / L views; fewer per
- * chunk when the chunk's scratch -- clip-space vertices, raster records, 3.5 KB per (view, link, tile) job slot -- would
- * exceed ~2 GB, EHR_VB_SCRATCH_MB), all inside the one call.  The hot calls never synchronise or allocate, so they can be
+ * chunk when the chunk's scratch -- clip-space vertices, raster records, 3.5 KB per (view, link, tile) job slot: 0.1 GB per
+ * 1280x720 view of an 8-link robot -- would exceed 24 GB, EHR_VB_SCRATCH_MB), all inside the one call.  The hot calls never synchronise or allocate, so they can be
  * captured in a hipGraph; a new plan invalidates a captured graph.  `slack` < 1 (default): one job slot per (view, link,
  * tile), nothing can overflow except the fixed-point accumulators (|sum| > 2^31) and a 16 MB spill pool for tiles with
  * more than 64 blended pairs per link; `slack` >= 1 provides only `slack` job slots per view tile (less scratch, larger
