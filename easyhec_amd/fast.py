@@ -93,8 +93,8 @@ class FusedPoseStep:
         m, sc = self.model, self.scene
         dof = m.dof.data
         hist = m.history_ops
-        # one C call = 4 launches: [pose fwd + vertices + raster records] -> jobs -> resolve -> composite [+ in its last
-        # workgroup: accumulators + pose bwd (+ Adam)]
+        # one C call = 5 launches: [pose fwd + vertices + raster records] -> jobs -> general-triangle jobs (normally
+        # none) -> resolve -> composite [+ in its last workgroup: accumulators + pose bwd (+ Adam)]
         _lib.check(lib.ehr_solver_step(
             self.glctx.handle, _lib.ptr(sc.verts), _lib.ptr(sc.tris), _lib.ptr(sc.tri_link), _lib.ptr(sc.vert_link),
             _lib.ptr(sc.opp), _lib.ptr(self.K), _lib.ptr(self.link_poses), _lib.ptr(self.ref), self.B, self.L,
@@ -128,7 +128,7 @@ class FusedPoseStep:
         return self.loss
 
     def capture(self):
-        """Record the step's launch chain (4 kernels on one stream) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
+        """Record the step's launch chain (5 kernels on one stream) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
         with one host call.  Iteration state lives on the device, so replays are ordinary optimisation steps.  The
         chain is GPU-bound, so this saves host time, not step time.  The data-parallel step is captured too when its
         exchange is the library's own ncclAllReduce (``rccl``: [solver step, all-reduce, Adam] on one stream); with the

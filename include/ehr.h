@@ -159,7 +159,8 @@ int ehr_pose_backward(const float* grad_mvp, const float* loss, const float* K, 
 int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* red, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
 
-/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 4 launches:
+/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 5 launches (vertex + raster records, jobs, general-triangle jobs -- normally none --, resolve,
+ * composite + finish):
  * ehr_pose_forward is merged into the vertex kernel (which also does the per-step housekeeping) and ehr_pose_backward +
  * ehr_pose_adam into the finish stage of the composite kernel.  Same arithmetic and outputs as calling the pieces one by one:
  * mvp [B,L,16], tc_jac [7,16], loss_b [B], grad_mvp [B,L,16], red [8], loss_out [1], grad_out [6] are all written.
