@@ -167,13 +167,13 @@ int ehr_graph_end(ehr_ctx* ctx) {
         ctx->gexec = nullptr;
         return fail(EHR_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
     }
-    ctx->gexec_reallocs = Scratch::reallocs;
+    ctx->gexec_reallocs = ctx->scratch_moves();
     return EHR_OK;
 }
 
 int ehr_graph_launch(ehr_ctx* ctx, void* stream) {
     if (!ctx || !ctx->gexec) return fail(EHR_ERR_INVALID, "ehr_graph_launch: no instantiated graph");
-    if (ctx->gexec_reallocs != Scratch::reallocs)  // a drop-in op or a re-plan moved scratch the graph points into
+    if (ctx->gexec_reallocs != ctx->scratch_moves())  // a drop-in op or a re-plan moved scratch the graph points into
         return fail(EHR_ERR_INVALID, "ehr_graph_launch: library scratch was reallocated after the capture; capture again");
     EHR_HIP(hipGraphLaunch(ctx->gexec, (hipStream_t)stream));
     return EHR_OK;

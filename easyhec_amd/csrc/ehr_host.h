@@ -36,7 +36,7 @@ struct Scratch {
     size_t cap = 0;
     int reserve(size_t bytes);  // may hipFree + hipMalloc (synchronises); never called on the fused hot path
     void release();
-    static unsigned long long reallocs;  // bumped whenever any Scratch moves: captured graphs hold raw pointers
+    unsigned long long moves = 0;  // bumped whenever this buffer moves: captured graphs hold raw pointers
 };
 
 struct StepHead;
@@ -100,7 +100,15 @@ struct ehr_ctx {
     // natively captured launch chain (ehr_graph_*): capture stream and the instantiated graph
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
-    unsigned long long gexec_reallocs = 0;  // Scratch::reallocs when the graph was instantiated
+    unsigned long long gexec_reallocs = 0;  // scratch_moves() when the graph was instantiated
+    // how often any scratch of THIS context moved (other contexts of the process do not disturb a captured graph)
+    unsigned long long scratch_moves() const {
+        unsigned long long n = 0;
+        for (const ehr::Scratch* s : {&counts, &offsets, &entries, &vb_clus, &vb_heavy, &vb_idx, &vb_boxes, &vb_units, &vb_acc,
+                                      &vb_posc, &vb_jobs, &vb_spill, &vb_refsum, &sc_counts, &sc_offsets, &sc_entries, &sc_posc})
+            n += s->moves;
+        return n;
+    }
     bool capturing = false;
     // measurement hook (ehr_fused_timing): EHR_FUSED_STAGES + 1 events per recorded call
     bool timing = false;

@@ -22,11 +22,9 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-unsigned long long Scratch::reallocs = 0;
-
 int Scratch::reserve(size_t bytes) {
     if (bytes <= cap) return EHR_OK;
-    reallocs++;
+    moves++;
     if (ptr) {
         EHR_HIP(hipDeviceSynchronize());
         EHR_HIP(hipFree(ptr));

@@ -281,6 +281,8 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         }
     };
     if (item < nitems) load_geometry(item);
+    __shared__ int lacc[32][4];  // pixel box of every link as far as this workgroup's clusters go
+    if (tid < 128) lacc[tid >> 2][tid & 3] = (tid & 2) ? -1 : INT_MAX;
     if (HEAD && tid < 6) {
         Dual<1> T6[16];
         se3_exp_dual<1>(head.dof, 1e-4f, T6, tid);
@@ -339,7 +341,6 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         for (int i = tid; i < L * 16; i += 256) M[i >> 4][i & 15] = mvp[(size_t)b * L * 16 + i];
     }
     __syncthreads();
-    __shared__ int wbox[4][5];  // per wave: link, box of its cluster
     for (; item < nitems;) {
     const bool lv = (unsigned)l < (unsigned)L;
     if (item < nvb) {
@@ -384,6 +385,32 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
                     r1.w = 1;
                 } else {
                     const VbEdges ed = vb_edges(cv.X[0], cv.Y[0], cv.X[1], cv.Y[1], cv.X[2], cv.Y[2], x0, y0, W, H);
+                    // A small box (<= 4 x 4 pixel centres: half of all triangles) is tested exactly, once, here: a fifth of
+                    // the triangles with a non-empty box cover no pixel centre at all (70 % of the 1 x 1 boxes), and would
+                    // otherwise be fetched, staged and walked by every job whose region their box touches.  The same
+                    // integer edge functions as the rasterizer's walk, so nothing that could be drawn is dropped.
+                    if (x1 - x0 < 4 && y1 - y0 < 4) {
+                        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+                        bool any = false;
+                        int q0 = ed.e0, q1 = ed.e1, q2 = ed.e2;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            int a0 = q0, a1 = q1, a2 = q2;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                any = any || (i < bw && j < bh && (a0 | a1 | a2) >= 0);
+                                a0 += ed.sx0;
+                                a1 += ed.sx1;
+                                a2 += ed.sx2;
+                            }
+                            q0 += ed.sy0;
+                            q1 += ed.sy1;
+                            q2 += ed.sy2;
+                        }
+                        if (!any) {
+                            x0 = 0xffff; y0 = 0xffff; x1 = 0; y1 = 0;
+                        }
+                    }
                     r0 = make_int4(ed.e0, ed.e1, ed.e2, (int)(((unsigned)(ed.sy0 / 16) & 0xffffu) | ((unsigned)(-ed.sx0 / 16) << 16)));
                     r1.x = (int)(((unsigned)(ed.sy1 / 16) & 0xffffu) | ((unsigned)(-ed.sx1 / 16) << 16));
                     r1.y = (int)(((unsigned)(ed.sy2 / 16) & 0xffffu) | ((unsigned)(-ed.sx2 / 16) << 16));
@@ -407,43 +434,29 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         cc = max(cc, __shfl_xor(cc, off, 64));
         d = max(d, __shfl_xor(d, off, 64));
     }
-    const int wv = tid >> 6;
     if (lane == 0) {
         const bool cne = cvalid && a <= cc;
         if (cvalid) rc.cbox[(size_t)b * cl.NC + c] = cne ? vb_pack_box(a, bq, cc, d) : VB_BOX_EMPTY;
-        wbox[wv][0] = (cne && lv) ? l : -1;
-        wbox[wv][1] = a;
-        wbox[wv][2] = bq;
-        wbox[wv][3] = cc;
-        wbox[wv][4] = d;
-    }
-    __syncthreads();
-    // link box: integer atomics, merged over the workgroup's four clusters (usually one link) and with one 64-byte line
-    // per (view, link): ~5 k atomics per step spread over B * L lines instead of 20 k on a handful
-    if (tid < 4 && wbox[tid][0] >= 0) {
-        const int ll = wbox[tid][0];
-        bool first_of_link = true;
-        for (int k = 0; k < tid; k++) first_of_link = first_of_link && wbox[k][0] != ll;
-        if (first_of_link) {
-            int ma = wbox[tid][1], mb = wbox[tid][2], mc = wbox[tid][3], md = wbox[tid][4];
-            for (int k = tid + 1; k < 4; k++)
-                if (wbox[k][0] == ll) {
-                    ma = min(ma, wbox[k][1]);
-                    mb = min(mb, wbox[k][2]);
-                    mc = max(mc, wbox[k][3]);
-                    md = max(md, wbox[k][4]);
-                }
-            int* const lb = lbox + VB_LBOX_STRIDE * ((size_t)b * L + ll);
-            atomicMin(lb + 0, ma);
-            atomicMin(lb + 1, mb);
-            atomicMax(lb + 2, mc);
-            atomicMax(lb + 3, md);
+        if (cne && lv) {  // link box: merged over everything this workgroup sees (LDS), published once at the end
+            atomicMin(&lacc[l][0], a);
+            atomicMin(&lacc[l][1], bq);
+            atomicMax(&lacc[l][2], cc);
+            atomicMax(&lacc[l][3], d);
         }
     }
-    __syncthreads();  // wbox is rewritten by the next cluster group
     }
     item += gx;
     if (item < nitems) load_geometry(item);
+    }
+    // link boxes: integer atomics, one 64-byte line per (view, link): a workgroup's clusters belong to one or two links,
+    // ~6 k atomics per step spread over B * L lines
+    __syncthreads();
+    if (tid < 4 * L && lacc[tid >> 2][0] != INT_MAX) {
+        int* const lb = lbox + VB_LBOX_STRIDE * ((size_t)b * L + (tid >> 2));
+        if (tid & 2)
+            atomicMax(lb + (tid & 3), lacc[tid >> 2][tid & 3]);
+        else
+            atomicMin(lb + (tid & 3), lacc[tid >> 2][tid & 3]);
     }
 }
 
