@@ -48,6 +48,8 @@ constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min 
                                       // heavy: next step a whole workgroup takes it.  Units, not triangles: a tile of 130 long
                                       // thin triangles (7000 units) keeps a wave busy for 60 us, one of 380 small ones for 25
 constexpr int VB_HEAVY_CAP = 4096;    // heavy jobs remembered per step
+constexpr int VB_MED_CAP = 2048;      // long single-wave jobs remembered per step (they are started first)
+#define VB_MED_T_DEFAULT 1500          // cost from which a single-wave job counts as long
 constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
 constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
 constexpr u64 VB_EMPTY = ~0ull;
@@ -120,9 +122,13 @@ __device__ __forceinline__ int vb_mbcnt(u64 m) {  // set bits of m below this la
 // dense (view, link, tile) id, stamped into a table at the start of the step so that the single-wave enumeration skips
 // them, and processed first, each by a whole workgroup.  Purely a scheduling hint: results do not depend on it.
 struct VbHeavy {
-    int* gen;     // [0] generation (one per call), [1..2] entries in list 0 / 1
+    int* gen;     // [0] generation (one per call), [1..2] entries in list 0 / 1, [4..5] entries in mlist 0 / 1
     int* list;    // [2][VB_HEAVY_CAP] dense ids; list (gen & 1) is being written, the other one is being consumed
-    int* stamp;   // [B * L * nt]  == generation: handled by a heavy workgroup this step
+    int* mlist;   // [2][VB_MED_CAP] likewise: jobs below the heavy threshold that were long all the same
+    int* stamp;   // [B * L * nt]  == generation: handled by a heavy workgroup this step; == -generation: a long job, dealt
+                  // out as some wave's first job
+    int mcap;     // long jobs consumed per step: min(VB_MED_CAP, 2 x workgroups of the job kernel) -- every one of them
+                  // must find a wave with a static first job, and at least half the workgroups have those
 };
 
 struct VbClusters {          // static acceleration index built by ehr_fused_plan (host): triangles grouped into
@@ -309,12 +315,15 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             s_gen = hv.gen[0] + 1;
             hv.gen[0] = s_gen;
             hv.gen[1 + (s_gen & 1)] = 0;
+            hv.gen[4 + (s_gen & 1)] = 0;
         }
         __syncthreads();
         {
             const int gen = s_gen, cur = (gen - 1) & 1;
             const int n = min(hv.gen[1 + cur], VB_HEAVY_CAP);
             for (int i = tid; i < n; i += 256) hv.stamp[hv.list[cur * VB_HEAVY_CAP + i]] = gen;
+            const int n2 = min(hv.gen[4 + cur], hv.mcap);
+            for (int i = tid; i < n2; i += 256) hv.stamp[hv.mlist[cur * VB_MED_CAP + i]] = -gen;
         }
         if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
         if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors of the 8 XCDs, tickets, slow-job count
@@ -1180,7 +1189,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
               unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, unsigned* __restrict__ jutile, int jcap,
               int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline,
               const float4* __restrict__ posc, int V, VbSlotIdx si, u64* __restrict__ jcov,
-              int4* __restrict__ slow_list, int heavy_t) {
+              int4* __restrict__ slow_list, int heavy_t, int med_t0) {
     __shared__ VbWaveLds lds_all[4];
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
@@ -1274,6 +1283,16 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         const int at = atomicAdd(&hv.gen[1 + hnxt], 1);
         if (at < VB_HEAVY_CAP) hv.list[hnxt * VB_HEAVY_CAP + at] = id;
     };
+    // Long jobs below the heavy threshold: a wave that claims one late (after two or three others) is what the kernel
+    // ends on -- 30 us on one wave whenever it starts -- so they are remembered as well and dealt out as static FIRST jobs,
+    // one per wave, in the next step.  Only when the machine is short of jobs (at most 1.5 per wave): with more, claiming
+    // balances the waves anyway and the jobs are better off in their own XCD's eighth of the list (L2).
+    const int med_t = max(med_t0, 1);
+    const int nmed = ((dbg & (64 | 128)) || total > 6 * (int)gridDim.x) ? 0 : min(hv.gen[4 + hcur], hv.mcap);
+    auto remember_long = [&](int id) {
+        const int at = atomicAdd(&hv.gen[4 + hnxt], 1);
+        if (at < VB_MED_CAP) hv.mlist[hnxt * VB_MED_CAP + at] = id;
+    };
     if (tid < 2) s_heavy[tid] = 0;
     __syncthreads();
     for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform
@@ -1320,7 +1339,10 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             if (lane == 0) {
                 s_heavy[0] = 0;
                 s_heavy[1] = 0;
-                if (tot_surv >= heavy_t) remember_heavy(id);
+                if (tot_surv >= heavy_t)
+                    remember_heavy(id);
+                else if (tot_surv >= med_t)
+                    remember_long(id);
 #ifdef VB_TIMELINE
                 S0.tl_flushes = tot_surv;  // (profiling build: wave 0's counters are reset after the heavy phase; parked here)
 #endif
@@ -1347,44 +1369,63 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     }
 #endif
     bool first_job = kx >= hk;
-    int sjob = jbeg + (kx - hk) * 4 + wave;
+    // static first jobs: wave rx of this XCD's static waves (global rank 8 rx + xcd) takes long job number <rank> of the
+    // previous step if there is one, else the (rx - nmx)-th job of the XCD's eighth; the rest of the eighth is claimed
+    const int rx = (kx - hk) * 4 + wave;
+    const int nmx = (nmed > xcd) ? (nmed - xcd + 7) >> 3 : 0;  // long jobs that go to this XCD's waves (<= nsw, see mcap)
+    const int nsn = nsw - nmx;                                 // static jobs of the eighth itself
+    int sjob = jbeg + rx - nmx;
     for (;;) {
 #ifdef VB_TIMELINE
         const long long tl_j0 = __builtin_readcyclecounter();
 #endif
-        int job = 0;
-        if (first_job || (dbg & 8)) {
-            job = sjob;
-            sjob += nsw;
+        int job = 0, u = -1, tx = 0, ty = 0;
+        if (first_job && rx < nmx) {
             first_job = false;
-        } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
-            if (lane == 0) job = jbeg + nsw + atomicAdd(cursor, 1);
-            job = __builtin_amdgcn_readfirstlane(job);
-        }
-        if (job >= jend) break;
-        int u;
-        {
-            int lo = 0, hi = U - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (upre[mid] <= job)
-                    lo = mid;
-                else
-                    hi = mid - 1;
+            const int id = hv.mlist[hcur * VB_MED_CAP + 8 * rx + xcd];
+            u = id / g.nt;
+            const int tile = id - u * g.nt;
+            tx = tile % g.ntx;
+            ty = tile / g.ntx;
+            const unsigned ut = utile[u];
+            const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
+            job = upre[u] + (ty - ty0) * nx + (tx - tx0);
+            if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
+        } else {
+            if (first_job || (dbg & 8)) {
+                job = sjob;
+                sjob += nsn;
+                first_job = false;
+                if (job >= jbeg + nsn && !(dbg & 8)) job = jend;  // (more static waves than jobs)
+            } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
+                if (lane == 0) job = jbeg + nsn + atomicAdd(cursor, 1);
+                job = __builtin_amdgcn_readfirstlane(job);
             }
-            u = lo;
+            if (job >= jend) break;
+            {
+                int lo = 0, hi = U - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (upre[mid] <= job)
+                        lo = mid;
+                    else
+                        hi = mid - 1;
+                }
+                u = lo;
+            }
+            {
+                const unsigned ut = utile[u];
+                const int nx = (int)(ut >> 22), k = job - upre[u];
+                ty = (int)((ut >> 10) & 4095u) + k / nx;
+                tx = (int)(ut & 1023u) + k - (k / nx) * nx;
+            }
+            const int st = (nheavy > 0 || nmed > 0) ? hv.stamp[u * g.nt + ty * g.ntx + tx] : 0;
+            // a workgroup took this one in the heavy phase / it is some wave's first job
+            if ((nheavy > 0 && st == gen) || (nmed > 0 && st == -gen)) continue;
         }
         const int b = u / L, l = u - b * L;
-        int tx, ty;
-        {
-            const unsigned ut = utile[u];
-            const int nx = (int)(ut >> 22), k = job - upre[u];
-            ty = (int)((ut >> 10) & 4095u) + k / nx;
-            tx = (int)(ut & 1023u) + k - (k / nx) * nx;
-        }
         const size_t slot = (size_t)job;
         const int dense_id = u * g.nt + ty * g.ntx + tx;
-        if (nheavy > 0 && hv.stamp[dense_id] == gen) continue;  // a workgroup took this one in the heavy phase
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
         VbRegion rg;  // tile + 1-pixel halo, inside the image
         rg.x0 = max(rx0, 0);
@@ -1414,7 +1455,12 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         tl_maxsurv = max(tl_maxsurv, nsurv);
         tl_sumsurv += nsurv;
 #endif
-        if (nsurv >= heavy_t && lane == 0) remember_heavy(dense_id);
+        if (lane == 0) {
+            if (nsurv >= heavy_t)
+                remember_heavy(dense_id);
+            else if (nsurv >= med_t)
+                remember_long(dense_id);
+        }
         if (drawn == 0) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
                 jn[slot] = -1;
@@ -2210,7 +2256,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         if ((rc = ctx->vb_jobs.reserve(nslot * slot_bytes + (2 * (size_t)Bc * L + 1) * sizeof(int) + 32))) return rc;
     }
     {  // heavy-job hint: generation + two counts | two lists | stamp table (dense ids of a chunk)
-        const size_t ints = 4 + 2 * (size_t)VB_HEAVY_CAP + (size_t)Bc * L * gp.nt;
+        const size_t ints = 8 + 2 * (size_t)VB_HEAVY_CAP + 2 * (size_t)VB_MED_CAP + (size_t)Bc * L * gp.nt;
         if ((rc = ctx->vb_heavy.reserve(ints * sizeof(int)))) return rc;
         EHR_HIP(hipMemset(ctx->vb_heavy.ptr, 0, ints * sizeof(int)));
     }
@@ -2362,8 +2408,9 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     si.cvidx = (const int4*)(cl.cvert + 3 * (size_t)NC1 * 64);
     VbHeavy hv;
     hv.gen = (int*)ctx->vb_heavy.ptr;
-    hv.list = hv.gen + 4;
-    hv.stamp = hv.list + 2 * VB_HEAVY_CAP;
+    hv.list = hv.gen + 8;
+    hv.mlist = hv.list + 2 * VB_HEAVY_CAP;
+    hv.stamp = hv.mlist + 2 * VB_MED_CAP;
 
     hipEvent_t* ev = nullptr;
     if (ctx->timing) {
@@ -2381,6 +2428,8 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     static const int dbg_env = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;  // measurement aid only
     static const int job_grid = getenv("EHR_VB_JOB_GRID") ? atoi(getenv("EHR_VB_JOB_GRID")) : 4;   // tuning knob
     static const int heavy_t = getenv("EHR_VB_HEAVY_T") ? atoi(getenv("EHR_VB_HEAVY_T")) : VB_HEAVY_T_DEFAULT;  // tuning knob
+    static const int med_t = getenv("EHR_VB_MED_T") ? atoi(getenv("EHR_VB_MED_T")) : VB_MED_T_DEFAULT;        // tuning knob
+    hv.mcap = std::min(VB_MED_CAP, 2 * (((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7));
     static const int vertex_grid = getenv("EHR_VB_VERTEX_GRID") ? atoi(getenv("EHR_VB_VERTEX_GRID")) : 5;  // tuning knob
     static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
     static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
@@ -2444,7 +2493,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         // stage 1: jobs = (view, link, tile) -> coverage and the triangle ids the silhouette analysis will ask for
         const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
         vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg,
-                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t);
+                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t, med_t);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
         static const int slow_grid = getenv("EHR_VB_SLOW_GRID") ? atoi(getenv("EHR_VB_SLOW_GRID")) : 32;  // tuning knob
