@@ -628,11 +628,13 @@ __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n
             const int pix = e & 511u, row = pix / VB_RW, col = pix - row * VB_RW;
             const unsigned m = (e >> 9) & 15u;
             const bool flag = (e >> 13) & 1u;
-            unsigned drawn = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (m & (1u << k))
-                    if (vb_depth_test(p, vi.w, rx0 + col + k, ry0 + row, W, H, &key[pix + k])) drawn |= 1u << k;
+            // (one pass per set bit of the fullest mask in the wave: after the filter a unit has one or two pixels left)
+            unsigned drawn = 0, mm = m;
+            while (mm) {
+                const int k = __ffs(mm) - 1;
+                mm &= mm - 1;
+                if (vb_depth_test(p, vi.w, rx0 + col + k, ry0 + row, W, H, &key[pix + k])) drawn |= 1u << k;
+            }
             if (flag && drawn) atomicOr((unsigned long long*)&cov[row], (u64)drawn << col);
         }
     }
@@ -675,6 +677,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
     // will ever ask which triangle is visible there, and coverage cannot change there: a triangle whose box lies inside
     // the interior is skipped, units inside it are not deferred, and a region that is all interior ends the job (the
     // inner tiles of a link seen from close by: a few large triangles cover everything, the other layers add nothing).
+    bool has_in = false;
     {
         u64 in = 0;
         if (lane < VB_RH) {
@@ -688,6 +691,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             full = true;
             return n;
         }
+        has_in = __ballot(lane < VB_RH && in != 0ull) != 0;  // (no interior yet -- most first rounds --: nothing can be hidden)
         VB_WAVE_SYNC();
     }
     if (sv) {
@@ -709,11 +713,13 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             R.box[lane] = (unsigned)(cx0 - rx0) | ((unsigned)(cy0 - ry0) << 8) | ((unsigned)bw << 16) | ((unsigned)bh << 24);
             R.ent[lane] = (srel << 14) | ((r1.w == 2) ? (1u << 13) : 0u);
             const u64 bm = ((1ull << bw) - 1ull) << (cx0 - rx0);
-            bool hidden = true;
+            bool hidden = has_in;
+            if (has_in) {
 #pragma unroll
-            for (int r = 0; r < VB_RH; r++) {
-                const bool mine = (unsigned)(r - (cy0 - ry0)) < (unsigned)bh;
-                hidden = hidden && (!mine || (S.intr[r] & bm) == bm);
+                for (int r = 0; r < VB_RH; r++) {
+                    const bool mine = (unsigned)(r - (cy0 - ry0)) < (unsigned)bh;
+                    hidden = hidden && (!mine || (S.intr[r] & bm) == bm);
+                }
             }
             // a box of VB_SPAN_GW or more units per row goes to the span walker: work = its rows
             if (!hidden) {
