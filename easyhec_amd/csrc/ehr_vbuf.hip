@@ -1135,25 +1135,28 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
 // for (all-ones elsewhere), then its descriptor; the resolve kernel takes it from there (an undrawn job's descriptor is
 // -1).  No list of drawn jobs: appending to one costs every job a returning atomic (~3 us under load), and three
 // quarters of the jobs are drawn anyway.
+// (part / nparts: the words this wave writes -- 0 / 1 for a job of its own; the four waves of a heavy job share them)
 __device__ __forceinline__ void vb_publish(const VbJobArgs& A, const u64* key_, const u64* cov_, int job, int u, int tx,
-                                           int ty) {
+                                           int ty, int part = 0, int nparts = 1) {
     const int lane = lane_id();
     VB_WAVE_SYNC();
     unsigned* const dst = A.jid + (size_t)job * VB_RN;
 #pragma unroll
     for (int k = 0; k < VB_WORDS; k++) {
+        if (nparts > 1 && (k % nparts) != part) continue;
         const unsigned i = 64u * k + lane;
         if (i < (unsigned)VB_RN) dst[i] = (unsigned)key_[i];  // low word = triangle id; all-ones stays all-ones
     }
     // coverage in region-linear order (bit i = region pixel i), what the resolve kernel's bit arithmetic works on
 #pragma unroll
     for (int k = 0; k < VB_WORDS; k++) {
+        if (nparts > 1 && (k % nparts) != part) continue;
         const unsigned i = 64u * k + lane;
         const unsigned row = i / VB_RW, col = i - row * VB_RW;
         const u64 w = __ballot(i < (unsigned)VB_RN && ((cov_[row < (unsigned)VB_RH ? row : 0] >> col) & 1ull));
         if (lane == 0) A.jcov[(size_t)job * VB_WORDS + k] = w;
     }
-    if (lane == 0) A.jdesc[job] = u | (tx << 9) | (ty << 19);
+    if (lane == 0 && part == 0) A.jdesc[job] = u | (tx << 9) | (ty << 19);
 }
 
 // A whole job on one wave with the general triangle path compiled in (near-plane clipping, 64-bit edge functions): what a
@@ -1208,6 +1211,11 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
 #endif
+    // the scheduling hint of the previous step is requested before anything else (two dependent round trips that would
+    // otherwise sit between the prologue and a heavy job)
+    const int gen = hv.gen[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
+    const int nheavy_prev = hv.gen[1 + hcur];
+    const int hid_first = hv.list[hcur * VB_HEAVY_CAP + min((int)blockIdx.x, VB_HEAVY_CAP - 1)];
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
     __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
     __shared__ int lcoff[33];                 // first cluster of every link
@@ -1277,14 +1285,12 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     //      candidate clusters; wave 0 publishes.  A job alone costs up to ~80 us on one wave (a thousand candidate
     //      triangles in one tile), which used to be the duration of this kernel at small batch sizes.
     __shared__ int s_heavy[2];  // drawn flag, survivors
-    const int gen = hv.gen[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
     // Only when the machine is short of jobs (at most ~2 per wave): with many views per GPU the kernel is bound by the
     // sum of the jobs, not by the longest, and four waves on one job are less efficient than four jobs (measured: 64
     // views 8 % slower with the heavy phase, 8 views 10 % faster, 1 view 40 % faster).
     // Likewise when heavy jobs are the rule rather than the exception (more than one per two workgroups: the Franka
     // meshes at 1080p have ~3000 of them in 8100 jobs and run 17 % slower with the heavy phase; the 8-view xArm7
     // workload has ~220 in 5000).
-    const int nheavy_prev = hv.gen[1 + hcur];
     const int hmax = (dbg >> 8) ? (dbg >> 8) : (int)gridDim.x / 2;  // (EHR_VB_DEBUG bits 8..: experiment with the limit)
     const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > hmax) ? 0 : min(nheavy_prev, VB_HEAVY_CAP);
     // ... and when there are fewer jobs than waves (one view, small images) most workgroups are idle anyway: jobs count as
@@ -1313,7 +1319,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     if ((int)blockIdx.x < nheavy) __builtin_amdgcn_s_setprio(VB_PRIO_HEAVY);
 #endif
     for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform
-        const int id = hv.list[hcur * VB_HEAVY_CAP + hj];
+        const int id = (hj == (int)blockIdx.x) ? hid_first : hv.list[hcur * VB_HEAVY_CAP + hj];
         const int u = id / g.nt, tile = id - u * g.nt;
         const int tx = tile % g.ntx, ty = tile / g.ntx;
         const unsigned ut = utile[u];
@@ -1344,11 +1350,11 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         if (!(any_drawn & 2) && dln > 0)
             vb_flush(S, S0.key, S0.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
         __syncthreads();
+        if (any_drawn == 1) vb_publish(A, S0.key, S0.cov, job, u, tx, ty, wave, 4);  // every wave its share of the words
         if (wave == 0) {
             if (any_drawn & 2) {  // put aside for vb_slow_kernel
                 if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
             } else if (any_drawn) {
-                vb_publish(A, S0.key, S0.cov, job, u, tx, ty);
             } else if (lane == 0) {
                 jn[job] = -1;
                 jdesc[job] = -1;
