@@ -50,6 +50,8 @@ int vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slac
               const int32_t* tris, const int32_t* tri_link, const int32_t* opp);
 int vbuf_meta_read(ehr_ctx* ctx, int* meta4);
 int vbuf_bind_ref(ehr_ctx* ctx, const float* ref, hipStream_t stream);
+int vbuf_score(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* vert_link, const float* mvp, int Q, int S,
+               int L, int V, int T, int H, int W, long long* score, unsigned char* count, hipStream_t stream, int* handled);
 int vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link, const int32_t* vert_link,
                const int32_t* opp, float* mvp, const float* ref, int B, int L, int V, int T, int H, int W, float* mask,
                float* loss, float* grad_mvp, const StepHead* head, const StepTail* tail, hipStream_t stream);
@@ -94,6 +96,13 @@ struct ehr_ctx {
     // space-explorer scoring (ehr_mask_variance) keeps its own scratch so that it never disturbs a solver plan
     ehr::Scratch sc_counts, sc_offsets, sc_entries, sc_posc;
     size_t sc_entries_cap = 0;
+    // ... and, for the coverage-only chain of the scoring op (ehr_vbuf.hip: vbuf_score), the static cluster index of its mesh
+    ehr::Scratch sc_clus, sc_misc;
+    int sc_nc = 0;
+    const void* sc_key[3] = {nullptr, nullptr, nullptr};  // (verts, tris, vert_link) the index was built for
+    int sc_key_n[3] = {0, 0, 0};                          // (V, T, L)
+    unsigned long long sc_hash = 0;                       // content hash of those arrays (an in-place edit rebuilds the index)
+    bool sc_mixed = false;                                // that mesh cannot take the chain (links not grouped)
     // RCCL communicator of the data-parallel exchange (ehr_comm_*; an ncclComm_t), created by the library itself
     void* comm = nullptr;
     int comm_ranks = 0;
@@ -105,7 +114,7 @@ struct ehr_ctx {
     unsigned long long scratch_moves() const {
         unsigned long long n = 0;
         for (const ehr::Scratch* s : {&counts, &offsets, &entries, &vb_clus, &vb_heavy, &vb_idx, &vb_boxes, &vb_units, &vb_acc,
-                                      &vb_posc, &vb_jobs, &vb_spill, &vb_refsum, &sc_counts, &sc_offsets, &sc_entries, &sc_posc})
+                                      &vb_posc, &vb_jobs, &vb_spill, &vb_refsum, &sc_counts, &sc_offsets, &sc_entries, &sc_posc, &sc_clus, &sc_misc})
             n += s->moves;
         return n;
     }

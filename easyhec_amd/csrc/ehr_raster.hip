@@ -241,6 +241,8 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->sc_offsets.release();
     c->sc_entries.release();
     c->sc_posc.release();
+    c->sc_clus.release();
+    c->sc_misc.release();
     c->vb_clus.release();
     c->vb_idx.release();
     c->vb_heavy.release();

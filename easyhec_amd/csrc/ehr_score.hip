@@ -172,6 +172,12 @@ extern "C" int ehr_mask_variance(ehr_ctx* ctx, const float* verts, const int32_t
     if (S < 1 || S > SCORE_MAX_S) return fail(EHR_ERR_INVALID, "ehr_mask_variance: S must be in [1, %d]", SCORE_MAX_S);
     if (H > 32768 || W > 32768) return fail(EHR_ERR_INVALID, "ehr_mask_variance: resolution above 32768 is unsupported");
     hipStream_t stream = (hipStream_t)stream_;
+    {   // the coverage-only chain on the solver's cluster / job machinery, where the call allows it (ehr_vbuf.hip)
+        int handled = 0;
+        const int rc2 = vbuf_score(ctx, verts, tris, vert_link, mvp, Q, S, L, V, T, H, W, (long long*)score, count, stream, &handled);
+        if (rc2) return rc2;
+        if (handled) return EHR_OK;
+    }
     BinGeom g;
     g.W = W;
     g.H = H;

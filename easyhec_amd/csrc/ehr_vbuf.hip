@@ -30,6 +30,7 @@
 // per covered pixel; global atomics execute memory-side on this part (4.6 G/s with raster locality: 272 us for the
 // 1.26 M fragments of the 8-view workload), see DESIGN.md section 6.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <utility>
@@ -214,7 +215,9 @@ struct VbRecs {
 // 1e-5 inside the planes; thickness (2 area / longest edge) at least 0.05 sixteenth-pixels; w within a factor 4.
 // Everything else -- NaNs included -- is "unsafe" and gets the exact per-pixel test.  For a robot in front of the
 // camera (z/w = 0.998 at 1 m with near 1 mm, far 10 m; depth range of a triangle ~1e-5) only edge-on slivers fail.
-__device__ __forceinline__ bool vb_depth_safe(const float4& p0, const float4& p1, const float4& p2, int W, int H) {
+// pos: the stricter class of the scoring op (mask = z/w of the nearest fragment > 0): every coverable pixel centre has
+// a depth in (0, 1], so that coverage alone decides the mask.
+__device__ __forceinline__ bool vb_depth_safe(const float4& p0, const float4& p1, const float4& p2, int W, int H, bool pos = false) {
     const float z0 = p0.z / p0.w, z1 = p1.z / p1.w, z2 = p2.z / p2.w;
     const float sx = (float)(8 * W), sy = (float)(8 * H);
     const float x0 = p0.x / p0.w * sx, y0 = p0.y / p0.w * sy;
@@ -227,7 +230,7 @@ __device__ __forceinline__ bool vb_depth_safe(const float4& p0, const float4& p1
     const float zmax = fmaxf(z0, fmaxf(z1, z2)), zmin = fminf(z0, fminf(z1, z2));
     const float wmax = fmaxf(p0.w, fmaxf(p1.w, p2.w)), wmin = fminf(p0.w, fminf(p1.w, p2.w));
     return (A >= 0.05f * (l1 + l2) + 1e-3f) && (wmax <= 4.f * wmin) && (zmax + delta <= 1.f - 1e-5f) &&
-           (zmin - delta >= -1.f + 1e-5f);
+           (zmin - delta >= (pos ? 1e-5f : -1.f + 1e-5f));
 }
 
 template <bool HEAD>
@@ -254,6 +257,8 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     // chunk_role: the views of a step go through the chain in chunks (one, unless views x links exceeds what a job
     // kernel handles): 1 = first chunk (the per-step housekeeping happens here), 2 = a later one (only the per-chunk
     // counters are re-armed)
+    const bool pos_only = (chunk_role & 4) != 0;  // (the scoring op's chain)
+    chunk_role &= 3;
     const bool first = bx == 0 && b == 0 && chunk_role == 1;
     const bool rearm = bx == 0 && b == 0 && chunk_role == 2;
     // A view's work items: [0, nvb) blocks of 256 vertices (-> posc), then groups of four clusters (one wave per cluster,
@@ -431,7 +436,7 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
                     r0 = make_int4(ed.e0, ed.e1, ed.e2, (int)(((unsigned)(ed.sy0 / 16) & 0xffffu) | ((unsigned)(-ed.sx0 / 16) << 16)));
                     r1.x = (int)(((unsigned)(ed.sy1 / 16) & 0xffffu) | ((unsigned)(-ed.sx1 / 16) << 16));
                     r1.y = (int)(((unsigned)(ed.sy2 / 16) & 0xffffu) | ((unsigned)(-ed.sx2 / 16) << 16));
-                    r1.w = vb_depth_safe(p0, p1, p2, W, H) ? 0 : 2;
+                    r1.w = vb_depth_safe(p0, p1, p2, W, H, pos_only) ? 0 : 2;
                 }
             }
         }
@@ -520,6 +525,7 @@ struct alignas(16) VbWaveLds {   // per wave of the job kernel
     VbRaster R;
     unsigned dl[VB_DL];          // deferred units: pixel (9 bits) | 4-bit coverage << 9 | R.ent
     unsigned sq[128];            // survivors of the box culling waiting for a full round: record slots (ring)
+    int bad;                     // scoring op: a flagged unit's pixel was drawn with a depth <= 0 (coverage cannot decide)
 #ifdef VB_TIMELINE
     int tl_units, tl_rounds;     // profiling build: 4-pixel units walked / rounds run by this wave
     int tl_flushes, tl_tested, tl_deferred;
@@ -529,7 +535,9 @@ struct alignas(16) VbWaveLds {   // per wave of the job kernel
 
 // z/w at the centre of pixel (ix, iy) from the triangle's clip-space vertices, the oracle's arithmetic
 // (depth_test_write); true if the pixel is drawn (depth inside [-1, 1]), and then the z-buffer is updated.
-__device__ __forceinline__ bool vb_depth_test(const float4 p[3], int t, int ix, int iy, int W, int H, u64* slot) {
+// (*nonpos, optional: set if a drawn pixel's depth is <= 0 -- the scoring op's mask is "depth of the nearest fragment > 0")
+__device__ __forceinline__ bool vb_depth_test(const float4 p[3], int t, int ix, int iy, int W, int H, u64* slot,
+                                              bool* nonpos = nullptr) {
     const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
     const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
     const float fx = (float)ix * xs + xo;
@@ -538,7 +546,11 @@ __device__ __forceinline__ bool vb_depth_test(const float4 p[3], int t, int ix, 
     eval_pixel(p, fx, fy, a0, a1, a2);
     const float zw = eval_zw(p, a0, a1, a2);
     if (zw >= -1.f && zw <= 1.f) {
-        atomicMin(slot, ((u64)ord_key(zw) << 32) | (unsigned)t);
+        if (nonpos) {
+            if (!(zw > 0.f)) *nonpos = true;
+        } else {
+            atomicMin(slot, ((u64)ord_key(zw) << 32) | (unsigned)t);
+        }
         return true;
     }
     return false;
@@ -587,6 +599,9 @@ __device__ __forceinline__ void vb_raster_wide(float4 pa, float4 pb, float4 pc, 
 // or partial; shared by the four waves of a workgroup in the heavy-job phase) are the covered ones with an uncovered
 // 4-neighbour inside the region; entries that touch none of them are dropped, the others are depth tested at exactly
 // those pixels.  Units of unsafe triangles (flag) are always tested, at all their pixels, and set their coverage bits.
+// COVER (scoring op): the list holds flagged units only; a pixel that passes the depth-range test is covered, and one whose
+// depth is not positive raises *bad (the coverage-only chain cannot decide that pixel: the caller falls back).
+template <bool COVER = false>
 __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n, const float4* __restrict__ pv,
                                       const int4* __restrict__ cvidx_link, int W, int H, int rx0, int ry0) {
     const int lane = lane_id();
@@ -633,7 +648,9 @@ __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n
             while (mm) {
                 const int k = __ffs(mm) - 1;
                 mm &= mm - 1;
-                if (vb_depth_test(p, vi.w, rx0 + col + k, ry0 + row, W, H, &key[pix + k])) drawn |= 1u << k;
+                bool nonpos = false;
+                if (vb_depth_test(p, vi.w, rx0 + col + k, ry0 + row, W, H, &key[pix + k], COVER ? &nonpos : nullptr)) drawn |= 1u << k;
+                if (COVER && nonpos) S.bad = 1;
             }
             if (flag && drawn) atomicOr((unsigned long long*)&cov[row], (u64)drawn << col);
         }
@@ -656,7 +673,10 @@ __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n
 // splits the concatenated unit sequence EVENLY over the 64 lanes (a third of the candidates have boxes above 16
 // pixels, so one lane per triangle would leave most lanes idle) and each lane walks its contiguous run stepping 32-bit
 // edge functions.  Fed by the per-triangle records of the vertex kernel; nothing but LDS is touched inside the walk.
-template <bool WIDE>
+// COVER: the coverage-only form of the scoring op's chain -- no deferred units, no depth anywhere: every triangle must be
+// of the class "coverage decides" (kind 0 under the positive-depth test), anything else aborts the job (-1); what is
+// already covered (not just interior) hides a box.
+template <bool WIDE, bool COVER = false>
 __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned srel, const VbRecs& rc, const VbRegion& rg,
                                                int rx0, int ry0, int W, int H, VbWaveLds& S, u64* key, u64* cov, int n,
                                                const float4* __restrict__ pv, const int4* __restrict__ cvidx_link, bool& full,
@@ -684,7 +704,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             const u64 c = cov[lane];
             const u64 up = (lane + 1 < VB_RH) ? cov[lane + 1] : VB_ROW_MASK;
             const u64 dn = (lane > 0) ? cov[lane - 1] : VB_ROW_MASK;
-            in = c & ((c >> 1) | (1ull << (VB_RW - 1))) & ((c << 1) | 1ull) & up & dn & VB_ROW_MASK;
+            in = COVER ? (c & VB_ROW_MASK) : (c & ((c >> 1) | (1ull << (VB_RW - 1))) & ((c << 1) | 1ull) & up & dn & VB_ROW_MASK);
             S.intr[lane] = in;
         }
         if (__ballot(lane < VB_RH && in != VB_ROW_MASK) == 0) {
@@ -723,14 +743,14 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             }
             // a box of VB_SPAN_GW or more units per row goes to the span walker: work = its rows
             if (!hidden) {
-                if (((bw + 3) >> 2) >= VB_SPAN_GW)
+                if (((bw + 3) >> 2) >= VB_SPAN_GW && !(COVER && r1.w == 2))  // (coverage-only form: flagged boxes stay with the units)
                     srows = bh;
                 else
                     units = ((bw + 3) >> 2) * bh;
             }
         }
     }
-    if (!WIDE && __ballot(wide)) return -1;  // the lean instantiation hands the whole job to vb_job_slow
+    if ((!WIDE || COVER) && __ballot(wide)) return -1;  // the lean instantiation hands the whole job to vb_job_slow
     // one scan for both walkers: units in the low half (<= 64 x 90), span rows in the high half (<= 64 x 10)
     const int packed = units | (srows << 16);
     int incl = packed;
@@ -799,7 +819,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             // the deferred list takes at most 64 entries per step: walk as many steps as it has room for
             const int room = (VB_DL - n) >> 6;
             if (room == 0) {
-                vb_flush(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
+                vb_flush<COVER>(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
                 n = 0;
                 continue;
             }
@@ -819,13 +839,15 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                 }
                 const bool inside = m4 != 0;
                 const u64 m = __ballot(inside);
-                if (m) {
+                if (COVER && !(__ballot(inside && (eb & (1u << 13))))) {
+                    if (inside) atomicOr((unsigned long long*)&cov[crow], (u64)m4 << (ccol0 + 4 * gx));
+                } else if (m) {
                     // deferred for a depth test: the unit's covered pixels outside the interior (as of the round's start)
                     unsigned md = 0;
                     if (inside) {
                         const int ccol = ccol0 + 4 * gx;
                         if (!(eb & (1u << 13))) atomicOr((unsigned long long*)&cov[crow], (u64)m4 << ccol);
-                        md = m4 & ~(unsigned)(S.intr[crow] >> ccol);
+                        md = COVER ? ((eb & (1u << 13)) ? m4 : 0u) : (m4 & ~(unsigned)(S.intr[crow] >> ccol));
                     }
                     const u64 ma = __ballot(md != 0);
                     if (md) S.dl[n + vb_mbcnt(ma)] = eb | (unsigned)(crow * VB_RW + ccol0 + 4 * gx) | (md << 9);
@@ -951,6 +973,24 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                     c0 = ccol0 + lo;
                     rm = ((1ull << (hi - lo + 1)) - 1ull) << c0;
                 }
+                if (COVER) {
+                    if (rm) atomicOr((unsigned long long*)&cov[crow], rm);
+                    if (act && s2 + it + 1 < e2) {
+                        dy++;
+                        crow++;
+                        er0 += sy0;
+                        er1 += sy1;
+                        er2 += sy2;
+                        if (dy == bh) {
+                            do {
+                                j++;
+                            } while ((R.pre[j + 1] >> 16) == (R.pre[j] >> 16));
+                            load_tri(j);
+                        }
+                    }
+                    it++;
+                    continue;
+                }
                 // deferred: the span's units (aligned to the span's first pixel) with a pixel outside the interior
                 const u64 md = rm ? ((rm & ~S.intr[crow]) >> c0) : 0ull;
                 u64 nz = (md | (md >> 1) | (md >> 2) | (md >> 3)) & 0x1111111111111111ull;
@@ -963,7 +1003,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                 }
                 const int T = vb_readlane(inc, 63);
                 if (n + T > VB_DL) {  // no room for this step's entries: flush, then take the step again
-                    vb_flush(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
+                    vb_flush<COVER>(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
                     n = 0;
                     continue;
                 }
@@ -1015,13 +1055,15 @@ struct alignas(16) VbResolveLds {  // per wave of the resolve kernel
 };
 
 // tiles (+ 1-pixel halo) a link's pixel box touches: the jobs of that (view, link)
-__device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W, int H, int& tx0, int& ty0, int& nx, int& ny) {
+// (halo = 0: the scoring op's coverage-only jobs, which look at their tile alone)
+__device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W, int H, int& tx0, int& ty0, int& nx, int& ny,
+                                              int halo = 1) {
     const int x0 = bx[0], y0 = bx[1], x1 = bx[2], y1 = bx[3];
     if (x0 > x1 || y0 > y1) return false;
-    tx0 = max(x0 - 1, 0) / EHR_TILE_W;
-    ty0 = max(y0 - 1, 0) / EHR_TILE_H;
-    nx = min(x1 + 1, W - 1) / EHR_TILE_W - tx0 + 1;
-    ny = min(y1 + 1, H - 1) / EHR_TILE_H - ty0 + 1;
+    tx0 = max(x0 - halo, 0) / EHR_TILE_W;
+    ty0 = max(y0 - halo, 0) / EHR_TILE_H;
+    nx = min(x1 + halo, W - 1) / EHR_TILE_W - tx0 + 1;
+    ny = min(y1 + halo, H - 1) / EHR_TILE_H - ty0 + 1;
     return true;
 }
 
@@ -1044,7 +1086,7 @@ struct VbJobArgs {
 // job.  The survivors' covered units are left in the wave's deferred list (dln entries on return): the caller flushes it
 // once the job's coverage is complete.  Returns 1 if anything survived the culling, 0 if not, and -1 (lean
 // instantiation only) if a survivor needs the general path: the caller then redoes the job with vb_job_slow.
-template <bool WIDE>
+template <bool WIDE, bool COVER = false>
 __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, u64* key_, u64* cov_, int b, int l,
                                              const VbRegion& rg, int rx0, int ry0, int share, int nshare, int& nsurv,
                                              int& dln) {
@@ -1112,7 +1154,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
                 if (qn >= 64) {
                     VB_WAVE_SYNC();
                     const unsigned sl = W_.sq[(qh + lane) & 127];
-                    dln = vb_raster_round<WIDE>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
+                    dln = vb_raster_round<WIDE, COVER>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
                     if (dln < 0) return -1;
                     if (full) return 1;  // every pixel of the region is interior: nothing can change any more
                     qh = (qh + 64) & 127;
@@ -1125,7 +1167,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
         VB_WAVE_SYNC();
         const bool sv = lane < qn;
         const unsigned sl = sv ? W_.sq[(qh + lane) & 127] : srel0;
-        dln = vb_raster_round<WIDE>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
+        dln = vb_raster_round<WIDE, COVER>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
         if (dln < 0) return -1;
     }
     return drawn ? 1 : 0;
@@ -1201,6 +1243,9 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
 #ifndef VB_JOB_WAVES
 #define VB_JOB_WAVES 4
 #endif
+// COVER (the scoring op): jcov = the (view, tile) coverage words [B][nt][4] the jobs OR their tile's interior into, jn = one
+// sticky flag raised by a job that met a triangle whose depth class does not let coverage decide; no slots, no lists.
+template <bool COVER>
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
 vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
               unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, unsigned* __restrict__ jutile, int jcap,
@@ -1226,7 +1271,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     if (tid <= L) lcoff[tid] = cl.coff[tid];
     for (int u = tid; u < U; u += 256) {
         int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
-        const bool ne = vb_unit_tiles(lbox + VB_LBOX_STRIDE * (size_t)u, W, H, tx0, ty0, nx, ny);
+        const bool ne = vb_unit_tiles(lbox + VB_LBOX_STRIDE * (size_t)u, W, H, tx0, ty0, nx, ny, COVER ? 0 : 1);
         upre[u + 1] = ne ? nx * ny : 0;
         utile[u] = (unsigned)tx0 | ((unsigned)ty0 << 10) | ((unsigned)(ne ? nx : 1) << 22);
     }
@@ -1250,14 +1295,16 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     int total = upre[U];
     if (blockIdx.x == 0) {
         // job slots are numbered like the jobs: stage 3 finds a (view, link, tile) slot from the link's first job
-        for (int u = tid; u <= U; u += 256) jbase[u] = upre[u];
-        for (int u = tid; u < U; u += 256) jutile[u] = utile[u];
+        if (!COVER) {
+            for (int u = tid; u <= U; u += 256) jbase[u] = upre[u];
+            for (int u = tid; u < U; u += 256) jutile[u] = utile[u];
+        }
         if (tid == 0) {
             meta[5] = total;  // number of jobs (the resolve kernel's loop bound)
-            if (total > jcap) meta[EHR_META_OVERFLOW] = 1;  // cannot happen with one slot per (view, link, tile)
+            if (!COVER && total > jcap) meta[EHR_META_OVERFLOW] = 1;  // cannot happen with one slot per (view, link, tile)
         }
     }
-    total = min(total, jcap);
+    if (!COVER) total = min(total, jcap);
     // XCD-aware order: workgroup w runs on XCD w % 8 (observed, used for L2 locality only): every XCD takes a contiguous
     // eighth of the job list, so that a view's vertices, boxes and records stay in one L2.  Inside that eighth every wave
     // takes one job statically; the jobs beyond that are claimed (one returning atomic on the XCD's cursor) by whichever
@@ -1459,24 +1506,48 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         const size_t slot = (size_t)job;
         const int dense_id = u * g.nt + ty * g.ntx + tx;
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
-        VbRegion rg;  // tile + 1-pixel halo, inside the image
-        rg.x0 = max(rx0, 0);
-        rg.y0 = max(ry0, 0);
-        rg.x1 = min(rx0 + VB_RW - 1, W - 1);
-        rg.y1 = min(ry0 + VB_RH - 1, H - 1);
+        VbRegion rg;  // tile + 1-pixel halo, inside the image (coverage-only form: the tile alone, same origin)
+        rg.x0 = COVER ? rx0 + 1 : max(rx0, 0);
+        rg.y0 = COVER ? ry0 + 1 : max(ry0, 0);
+        rg.x1 = min(rx0 + VB_RW - 1 - (COVER ? 1 : 0), W - 1);
+        rg.y1 = min(ry0 + VB_RH - 1 - (COVER ? 1 : 0), H - 1);
         VB_WAVE_SYNC();
+        if (!COVER) {
 #pragma unroll
-        for (int k = 0; k < VB_WORDS; k++) {
-            const unsigned i = 64u * k + lane;
-            if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
+            for (int k = 0; k < VB_WORDS; k++) {
+                const unsigned i = 64u * k + lane;
+                if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
+            }
         }
         if (lane < VB_RH) S.cov[lane] = 0ull;
+        if (COVER && lane == 0) S.bad = 0;
         VB_WAVE_SYNC();
 #ifdef VB_TIMELINE
         const long long tl_j1 = __builtin_readcyclecounter();
 #endif
         int nsurv = 0, dln = 0;
-        const int drawn = vb_job_raster<false>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
+        const int drawn = vb_job_raster<false, COVER>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
+        if (COVER) {
+            // flagged units (their depth range must be tested per pixel: edge-on slivers mostly) are the only deferred ones
+            if (drawn >= 0 && dln > 0)
+                vb_flush<true>(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+            VB_WAVE_SYNC();
+            if (drawn < 0 || S.bad) {  // a triangle for the general path, or a drawn pixel with a depth <= 0: coverage cannot
+                if (lane == 0) jn[0] = 1;  // decide here and the caller falls back for the whole call
+                continue;
+            }
+            if (drawn > 0) {
+                // the tile's 32 x 8 interior of the coverage rows, OR-ed into the (view, tile) words (all links of a view)
+                VB_WAVE_SYNC();
+                if (lane < 4) {
+                    const u64 w = ((S.cov[2 * lane + 1] >> 1) & 0xffffffffull) | (((S.cov[2 * lane + 2] >> 1) & 0xffffffffull) << 32);
+                    // (layout [candidate][tile][pose][4]: the count kernel reads a candidate's words of a tile in one piece;
+                    //  jcap carries S, the poses per candidate, in this form)
+                    if (w) atomicOr((unsigned long long*)&jcov[((((size_t)(b / jcap) * g.nt + (size_t)ty * g.ntx + tx) * jcap + (b % jcap)) * 4 + lane)], w);
+                }
+            }
+            continue;
+        }
         if (drawn < 0) {  // a triangle for the general path (near-plane clipping, huge extent): put the job aside
             if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
             continue;
@@ -1514,7 +1585,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 #endif
     }
 #ifdef VB_TIMELINE
-    if (lane == 0) {
+    if (lane == 0 && timeline) {
         const size_t gw = (size_t)blockIdx.x * 4 + wave;
         const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave slot, SIMD, CU, SH, SE
         const unsigned xccid = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
@@ -2095,6 +2166,78 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
 #endif
 }
 
+// Content hash of the scoring op's mesh arrays (position-weighted sum of their 32-bit words): the cluster index holds
+// copies of the vertex positions, so a mesh edited in place under the same pointers must rebuild it.
+__global__ void __launch_bounds__(256)
+vb_hash_kernel(const unsigned* __restrict__ a, size_t na, const unsigned* __restrict__ b, size_t nb, const unsigned* __restrict__ c,
+               size_t nc, unsigned long long* __restrict__ out) {
+    unsigned long long h = 0;
+    const size_t n = na + nb + nc;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned w = i < na ? a[i] : (i < na + nb ? b[i - na] : c[i - na - nb]);
+        h += ((unsigned long long)w + 0x9e3779b97f4a7c15ull) * (2ull * i + 1ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+}
+
+// Scoring op, last stage: one wave per (candidate, tile), four pixels per lane: c = number of the candidate's S views
+// whose coverage word has the pixel's bit, score[q] += sum c (S - c) (space_explorer.py:152-165: the summed unbiased
+// variance of S binary masks is that integer over S (S - 1)); optionally the count image (row 0 = top).  Also re-arms
+// the link boxes for the next chunk of views.
+__global__ void __launch_bounds__(256)
+vb_score_count_kernel(BinGeom g, int nq, int S, const u64* __restrict__ tcov, unsigned long long* __restrict__ sacc,
+                      unsigned char* __restrict__ count_img, int* __restrict__ lbox, int nlbox,
+                      unsigned long long* __restrict__ prev_sacc, long long* __restrict__ prev_score, int prev_nq) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nlbox; i += gridDim.x * 256) lbox[i] = (i & 2) ? INT_MIN : INT_MAX;
+    // The sums of a chunk are collected in scratch, one 128-byte line per candidate (a few hundred atomics per candidate:
+    // on the caller's packed int64 array they would all hit one line and serialise at ~25 ns each), and stored to the
+    // caller's array by the NEXT launch of this kernel (the last one has nq = 0).
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < prev_nq; i += 256) {
+            prev_score[i] = (long long)prev_sacc[16 * i];
+            prev_sacc[16 * i] = 0ull;
+        }
+    const int r = lane >> 3, c4 = (lane & 7) * 4;
+    const int sh = (r & 1) * 32 + c4;
+    // persistent waves (a workgroup per four items would be bound by the rate workgroups are dispatched at)
+    for (int item = blockIdx.x * 4 + wave; item < nq * g.nt; item += gridDim.x * 4) {
+    const int q = item / g.nt, tile = item - q * g.nt;
+    int c[4] = {0, 0, 0, 0};
+    // one round trip per 16 views: lane 4 s + k requests word k of view s, the words then go round by readlane
+    for (int s0 = 0; s0 < S; s0 += 16) {
+        const int ls = s0 + (lane >> 2);
+        const u64 mine = (ls < S) ? tcov[(((size_t)q * g.nt + tile) * S + ls) * 4 + (lane & 3)] : 0ull;
+        if (__ballot(mine != 0ull) == 0) continue;  // (most tiles hold nothing)
+
+        const int ns = min(16, S - s0);
+        for (int k = 0; k < ns; k++) {
+            const int src = 4 * k + (r >> 1);
+            const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, src, 64), hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), src, 64);
+            const unsigned bits = (unsigned)(((((u64)hi) << 32) | lo) >> sh) & 15u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) c[j] += (bits >> j) & 1u;
+        }
+    }
+    int v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v += c[j] * (S - c[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0 && v) atomicAdd(&sacc[16 * q], (unsigned long long)v);
+    if (count_img) {
+        const int tx = tile % g.ntx, ty = tile / g.ntx;
+        const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;
+        if (iy < g.H)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (ix + j < g.W && c[j]) count_img[((size_t)q * g.H + (g.H - 1 - iy)) * g.W + ix + j] = (unsigned char)c[j];
+    }
+    }
+}
+
 // [T][3] int32 -> [T] int4 (one aligned 16-byte gather per triangle in the silhouette analysis)
 __global__ void vb_pad_kernel(const int32_t* __restrict__ a, int T, int4* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2134,14 +2277,36 @@ static void vb_kd_order(const float* cen, int* idx, int n) {
 // Static acceleration index of a scene: per link, the triangles ordered by a median-split tree over their centroids (object
 // space, so it holds for every pose) and cut into clusters of 64.  Triangle ids stay the caller's: depth ties and the
 // antialias topology are unaffected.
-static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* verts, const int32_t* tris,
-                             const int32_t* tri_link) {
+// tri_link == NULL: the links come from vert_link (the scoring op's packed mesh): a triangle belongs to the link of its
+// vertices; *mixed is set if a triangle's vertices disagree or the triangles are not grouped by link (the caller then
+// keeps to the per-triangle path).
+static int vb_build_clusters(Scratch& out, int& nc_out, int L, int V, int T, const float* verts, const int32_t* tris,
+                             const int32_t* tri_link, const int32_t* vert_link = nullptr, bool* mixed = nullptr) {
     std::vector<float> hv((size_t)3 * std::max(V, 1));
     std::vector<int32_t> ht((size_t)3 * std::max(T, 1)), hl((size_t)std::max(T, 1));
     if (V > 0) EHR_HIP(hipMemcpy(hv.data(), verts, (size_t)3 * V * sizeof(float), hipMemcpyDeviceToHost));
     if (T > 0) {
         EHR_HIP(hipMemcpy(ht.data(), tris, (size_t)3 * T * sizeof(int32_t), hipMemcpyDeviceToHost));
-        EHR_HIP(hipMemcpy(hl.data(), tri_link, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (tri_link) {
+            EHR_HIP(hipMemcpy(hl.data(), tri_link, (size_t)T * sizeof(int32_t), hipMemcpyDeviceToHost));
+        } else {
+            std::vector<int32_t> vl((size_t)std::max(V, 1), 0);
+            if (V > 0) EHR_HIP(hipMemcpy(vl.data(), vert_link, (size_t)V * sizeof(int32_t), hipMemcpyDeviceToHost));
+            int prev = 0;
+            for (int t = 0; t < T; t++) {
+                int lk[3];
+                for (int j = 0; j < 3; j++) {
+                    const int v = ht[3 * (size_t)t + j];
+                    lk[j] = ((unsigned)v < (unsigned)V) ? vl[v] : -1;
+                }
+                if (lk[0] != lk[1] || lk[0] != lk[2] || (unsigned)lk[0] >= (unsigned)L || lk[0] < prev) {
+                    *mixed = true;
+                    return EHR_OK;
+                }
+                prev = lk[0];
+                hl[t] = lk[0];
+            }
+        }
     }
     std::vector<int32_t> ctri, clink, coff((size_t)L + 1, 0);
     std::vector<float> aabb((size_t)6 * L);
@@ -2192,7 +2357,7 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
     if (t != T) return fail(EHR_ERR_INVALID, "ehr_fused_plan: tri_link holds a link outside [0, %d) or is not sorted", L);
     coff[L] = (int32_t)clink.size();
     const int NC = (int)clink.size();
-    ctx->vb_nc = NC;
+    nc_out = NC;
     int rc;
     const size_t n_ctri = (size_t)std::max(NC, 1) * 64;
     std::vector<float> cvert(12 * n_ctri, 0.f);  // three float4 planes
@@ -2221,9 +2386,9 @@ static int vb_build_clusters(ehr_ctx* ctx, int L, int V, int T, const float* ver
     for (int l = 0; l < L; l++)  // a deferred unit names its triangle by an 18-bit slot relative to its link's first cluster
         if (coff[l + 1] - coff[l] > 4096)
             return fail(EHR_ERR_INVALID, "ehr_fused_plan: link %d has more than 262144 triangles", l);
-    if ((rc = ctx->vb_clus.reserve((n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) * sizeof(int32_t) + 32 + cvert.size() * sizeof(float) +
-                                   cvidx.size() * sizeof(int32_t)))) return rc;
-    int32_t* d = (int32_t*)ctx->vb_clus.ptr;
+    if ((rc = out.reserve((n_ctri + std::max(NC, 1) + L + 1 + 6 * (size_t)L) * sizeof(int32_t) + 32 + cvert.size() * sizeof(float) +
+                          cvidx.size() * sizeof(int32_t)))) return rc;
+    int32_t* d = (int32_t*)out.ptr;
     if (NC > 0) {
         EHR_HIP(hipMemcpy(d, ctri.data(), (size_t)NC * 64 * sizeof(int32_t), hipMemcpyHostToDevice));
         EHR_HIP(hipMemcpy(d + n_ctri, clink.data(), (size_t)NC * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -2245,7 +2410,7 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     if ((V > 0 && !verts) || (T > 0 && (!tris || !tri_link || !opp)))
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: the scene arrays (verts, tris, tri_link, opp) are required");
     int rc;
-    if ((rc = vb_build_clusters(ctx, L, V, T, verts, tris, tri_link))) return rc;
+    if ((rc = vb_build_clusters(ctx->vb_clus, ctx->vb_nc, L, V, T, verts, tris, tri_link))) return rc;
     const int NC = std::max(ctx->vb_nc, 1);
     // The views of a call go through the chain in CHUNKS of Bc views (one chunk in the common case): the job kernel
     // keeps its (view, link) tables in LDS (VB_MAX_UNITS entries), and the per-chunk scratch -- clip-space vertices,
@@ -2524,7 +2689,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         if (time_it) EHR_HIP(hipEventRecord(ev[1], stream));
         // stage 1: jobs = (view, link, tile) -> coverage and the triangle ids the silhouette analysis will ask for
         const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
-        vb_job_kernel<<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg,
+        vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg,
                                                     hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t, med_t);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
@@ -2573,6 +2738,146 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
 
 // Binds a reference mask to the plan (ehr_fused_bind_ref): one pass stores per (view, tile) the fixed-point sum(ref^2)
 // exactly as the composite kernel would add it for a tile no link touches, and per view the total.  ref == NULL unbinds.
+// The scoring op (ehr_mask_variance, csrc/ehr_score.hip) on the solver's machinery: the static cluster index of the packed
+// mesh, then per chunk of candidates the vertex kernel (records + link boxes; depth class "coverage decides": every
+// coverable pixel of the triangle has z/w in (0, 1]), the job kernel in its coverage-only form (no deferred units, no
+// depth, no slots: a job ORs its tile's coverage into the view's word) and the count kernel.  *handled = 0 if the call
+// cannot take this road (then nothing the caller sees was touched beyond `score` / `count`, which it rewrites): links
+// not grouped, too many views per candidate for one chunk, or -- known only afterwards -- a triangle whose depth class
+// needs the exact z-buffer (geometry within two near-plane distances of the camera, or crossing the far plane).
+int ehr::vbuf_score(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* vert_link, const float* mvp, int Q,
+                    int S, int L, int V, int T, int H, int W, long long* score, unsigned char* count, hipStream_t stream,
+                    int* handled) {
+    *handled = 0;
+    // EHR_SCORE_PATH (tests, A/B): "tile" = always the per-triangle queue path of ehr_score.hip, "chain" = this one or an error
+    const char* const want = getenv("EHR_SCORE_PATH");
+    const bool must = want && !strcmp(want, "chain");
+    if (want && !strcmp(want, "tile")) return EHR_OK;
+    if (!vert_link || L > 32 || S * L > VB_MAX_UNITS || H > 32760 || W > 32736)
+        return must ? fail(EHR_ERR_INVALID, "ehr_mask_variance: EHR_SCORE_PATH=chain, but the call's sizes do not allow it") : EHR_OK;
+    int rc;
+    unsigned long long hash = 0;
+    {
+        if ((rc = ctx->sc_misc.reserve(4096))) return rc;
+        unsigned long long* dh = (unsigned long long*)ctx->sc_misc.ptr;
+        EHR_HIP(hipMemsetAsync(dh, 0, sizeof(unsigned long long), stream));
+        vb_hash_kernel<<<64, 256, 0, stream>>>((const unsigned*)verts, (size_t)3 * V, (const unsigned*)tris, (size_t)3 * T,
+                                                (const unsigned*)vert_link, (size_t)V, dh);
+        EHR_LAUNCH_CHECK();
+        EHR_HIP(hipMemcpyAsync(ctx->host_pinned, dh, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        EHR_HIP(hipStreamSynchronize(stream));
+        hash = *(unsigned long long*)ctx->host_pinned;
+    }
+    if (ctx->sc_key[0] != verts || ctx->sc_key[1] != tris || ctx->sc_key[2] != vert_link || ctx->sc_key_n[0] != V ||
+        ctx->sc_key_n[1] != T || ctx->sc_key_n[2] != L || ctx->sc_hash != hash) {
+        bool mixed = false;
+        ctx->sc_key[0] = nullptr;
+        if ((rc = vb_build_clusters(ctx->sc_clus, ctx->sc_nc, L, V, T, verts, tris, nullptr, vert_link, &mixed))) {
+            if (rc == EHR_ERR_INVALID) return EHR_OK;  // (a link with too many triangles for a slot id: the other path takes it)
+            return rc;
+        }
+        ctx->sc_mixed = mixed;
+        ctx->sc_key[0] = verts;
+        ctx->sc_key[1] = tris;
+        ctx->sc_key[2] = vert_link;
+        ctx->sc_key_n[0] = V;
+        ctx->sc_key_n[1] = T;
+        ctx->sc_key_n[2] = L;
+        ctx->sc_hash = hash;
+    }
+    if (ctx->sc_mixed || ctx->sc_nc <= 0)
+        return must ? fail(EHR_ERR_INVALID, "ehr_mask_variance: EHR_SCORE_PATH=chain, but the mesh's links are not grouped") : EHR_OK;
+    const BinGeom g = make_geom(H, W, L);
+    const int NC = ctx->sc_nc;
+    VbClusters cl;
+    cl.ctri = (const int32_t*)ctx->sc_clus.ptr;
+    cl.clink = cl.ctri + (size_t)NC * 64;
+    cl.coff = cl.clink + NC;
+    cl.laabb = (const float*)(cl.coff + L + 1);
+    cl.cvert = (const float4*)(((uintptr_t)(cl.laabb + 6 * (size_t)L) + 15) & ~(uintptr_t)15);
+    cl.NC = NC;
+    VbSlotIdx si;
+    si.cvidx = (const int4*)(cl.cvert + 3 * (size_t)NC * 64);
+    // candidates per chunk: (view, link) units of a chunk fit the job kernel's LDS tables; scratch bounded like the solver's
+    const double view_bytes = (double)NC * (64 * 40 + 8) + (double)V * 16 + (double)g.nt * 32;
+    int Qc = std::max(1, (VB_MAX_UNITS / L) / S);
+    Qc = std::max(1, std::min(Qc, (int)(8192.0 * 1048576.0 / (view_bytes * S))));
+    Qc = std::min(Qc, Q);
+    const int Bc = Qc * S;
+    const size_t n_hv = 8 + 2 * (size_t)VB_HEAVY_CAP + 2 * (size_t)VB_MED_CAP;
+    const size_t misc_ints = (size_t)VB_LBOX_STRIDE * Bc * L + EHR_META_INTS + (VB_LINES + 2) * 32 + n_hv + 16 + 64 + 2 * 32 * (size_t)Qc;
+    if ((rc = ctx->sc_posc.reserve((size_t)Bc * V * sizeof(float4)))) return rc;
+    if ((rc = ctx->sc_entries.reserve((size_t)Bc * NC * (64 * 40 + 8)))) return rc;
+    if ((rc = ctx->sc_misc.reserve(misc_ints * sizeof(int) + 64 + (size_t)Bc * g.nt * 4 * sizeof(u64)))) return rc;
+    ctx->sc_entries_cap = 0;  // (the per-triangle path sizes its queues again if it runs after this)
+    int* lbox = (int*)ctx->sc_misc.ptr;
+    int* meta = lbox + (size_t)VB_LBOX_STRIDE * Bc * L;
+    int* hvp = meta + EHR_META_INTS + (VB_LINES + 2) * 32;
+    int* sticky = hvp + n_hv;
+    unsigned long long* sacc0 = (unsigned long long*)(((uintptr_t)(sticky + 16) + 127) & ~(uintptr_t)127);  // [2][Qc][16]
+    u64* tcov = (u64*)(sacc0 + 2 * 16 * (size_t)Qc);
+    float4* posc = (float4*)ctx->sc_posc.ptr;
+    VbHeavy hv;
+    hv.gen = hvp;
+    hv.list = hv.gen + 8;
+    hv.mlist = hv.list + 2 * VB_HEAVY_CAP;
+    hv.stamp = hv.gen;  // (never touched: the hint is off)
+    hv.mcap = 0;
+    EHR_HIP(hipMemsetAsync(hvp, 0, (n_hv + 16) * sizeof(int), stream));
+    EHR_HIP(hipMemsetAsync(sacc0, 0, 2 * 16 * (size_t)Qc * sizeof(unsigned long long), stream));
+    EHR_HIP(hipMemsetAsync(score, 0, (size_t)Q * sizeof(long long), stream));
+    if (count) EHR_HIP(hipMemsetAsync(count, 0, (size_t)Q * H * W, stream));
+    static const int vertex_grid = getenv("EHR_VB_VERTEX_GRID") ? atoi(getenv("EHR_VB_VERTEX_GRID")) : 5;
+    static const int job_grid = getenv("EHR_VB_JOB_GRID") ? atoi(getenv("EHR_VB_JOB_GRID")) : 4;
+    const int nvb = (std::max(V, 1) + 255) / 256;
+    const int nitems = nvb + (NC + 3) / 4;
+    const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
+    // link boxes start empty (afterwards the count kernel re-arms them)
+    vb_score_count_kernel<<<64, 256, 0, stream>>>(g, 0, S, tcov, sacc0, nullptr, lbox, VB_LBOX_STRIDE * Bc * L, sacc0, score, 0);
+    EHR_LAUNCH_CHECK();
+    unsigned long long* prev_sacc = sacc0;
+    long long* prev_score = score;
+    int prev_nq = 0, flip = 0;
+    for (int q0 = 0; q0 < Q; q0 += Qc) {
+        const int nq = std::min(Qc, Q - q0), Bk = nq * S;
+        VbRecs recs;
+        recs.n = (size_t)Bk * NC * 64;
+        recs.trec = (int4*)ctx->sc_entries.ptr;
+        recs.tbox = (uint2*)(recs.trec + recs.n * 2);
+        recs.cbox = recs.tbox + recs.n;
+        const int per_view_cap = std::max(8, (ctx->num_cus * std::max(1, vertex_grid)) / std::max(Bk, 1));
+        const int items_per_wg = (nitems + per_view_cap - 1) / per_view_cap;
+        const int gx = std::max(1, (nitems + items_per_wg - 1) / std::max(items_per_wg, 1));
+        const int xcd_views = ((Bk % 8) == 0) ? Bk / 8 : 0;
+        StepHead none = {};
+        vb_vertex_kernel<false><<<dim3(gx * Bk), 256, 0, stream>>>(verts, vert_link, tris, cl, none, const_cast<float*>(mvp) + (size_t)q0 * S * L * 16,
+                                                                V, nvb, g, posc, recs, lbox, (int*)tcov, Bk * g.nt * 8, meta, Bk, gx,
+                                                                xcd_views, hv, 1 | 4);
+        EHR_LAUNCH_CHECK();
+        vb_job_kernel<true><<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, sticky, nullptr, nullptr, nullptr, nullptr, S, meta,
+                                                      64 | 128, hv, nullptr, posc, V, si, tcov, nullptr, 0x7fffffff, 0x7fffffff);
+        EHR_LAUNCH_CHECK();
+        static const int count_grid = getenv("EHR_SCORE_COUNT_GRID") ? atoi(getenv("EHR_SCORE_COUNT_GRID")) : 4;  // tuning knob
+        unsigned long long* const sacc = sacc0 + (size_t)flip * 16 * Qc;
+        vb_score_count_kernel<<<std::min((nq * g.nt + 3) / 4, std::max(1, count_grid) * ctx->num_cus), 256, 0, stream>>>(
+            g, nq, S, tcov, sacc, count ? count + (size_t)q0 * H * W : nullptr, lbox, VB_LBOX_STRIDE * Bc * L, prev_sacc, prev_score, prev_nq);
+        EHR_LAUNCH_CHECK();
+        prev_sacc = sacc;
+        prev_score = score + q0;
+        prev_nq = nq;
+        flip ^= 1;
+    }
+    vb_score_count_kernel<<<1, 256, 0, stream>>>(g, 0, S, tcov, sacc0, nullptr, lbox, 0, prev_sacc, prev_score, prev_nq);
+    EHR_LAUNCH_CHECK();
+    EHR_HIP(hipMemcpyAsync(ctx->host_pinned, sticky, sizeof(int), hipMemcpyDeviceToHost, stream));
+    EHR_HIP(hipMemcpyAsync(ctx->host_pinned + 1, meta + EHR_META_OVERFLOW, sizeof(int), hipMemcpyDeviceToHost, stream));
+    EHR_HIP(hipStreamSynchronize(stream));
+    if (ctx->host_pinned[0] || ctx->host_pinned[1])  // a triangle needs the exact z-buffer: the other path redoes the call
+        return must ? fail(EHR_ERR_INVALID, "ehr_mask_variance: EHR_SCORE_PATH=chain, but a triangle needs the exact z-buffer") : EHR_OK;
+    *handled = 1;
+    return EHR_OK;
+}
+
 int ehr::vbuf_bind_ref(ehr_ctx* ctx, const float* ref, hipStream_t stream) {
     ctx->vb_ref = nullptr;
     if (!ref) return EHR_OK;

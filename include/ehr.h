@@ -216,8 +216,16 @@ int ehr_graph_release(ehr_ctx* ctx);
  *   verts [V,3], tris [T,3] (global vertex ids), vert_link [V] (link of each vertex; NULL = all 0),
  *   mvp [Q,S,L,16] = proj(K) @ opencv2blender @ Tc_c2b[s] @ link_pose[q,l], row-major;
  *   score [Q] int64 (device); count [Q,H,W] uint8 (device, optional; image convention row 0 = top): c per pixel.
- * Candidates are processed in passes of about chunk_views rendered views (<= 0: default 512) to bound the scratch;
- * the call synchronises the stream once per pass (queue sizing) and once at the end (error flag). */
+ * Two implementations, same integers.  Where the mesh's triangles are grouped by link (vert_link given, every triangle's
+ * vertices in one link, links ascending), L <= 32 and S x L <= 512, the call runs on the solver's machinery: the
+ * static cluster index of the mesh (built at the first call, rebuilt when the arrays' contents change: a content hash is
+ * taken every call), then per chunk of candidates the vertex kernel, the job kernel in a coverage-only form (a triangle
+ * all of whose coverable pixels have a depth in (0, 1] needs no depth test at all; the few others are tested per pixel)
+ * and a count kernel; one synchronisation at the start (hash) and one at the end.  If a drawn pixel turns out to have a
+ * depth <= 0, or a triangle crosses the near plane or spans > 512 pixels -- geometry within two near-plane distances of
+ * the camera --, the call is redone by the other implementation: per-triangle tile queues and an exact z-buffer, in
+ * passes of about chunk_views rendered views (<= 0: default 512), one synchronisation per pass.
+ * EHR_SCORE_PATH=tile / =chain (environment) forces one of them (chain: an error where it cannot decide). */
 int ehr_mask_variance(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* vert_link,
                       const float* mvp, int Q, int S, int L, int V, int T, int H, int W, int64_t* score,
                       uint8_t* count, int chunk_views, void* stream);

@@ -221,3 +221,57 @@ def test_mask_variance_edge_cases(env, oracle, xarm7):
     far[..., 3, :] *= -1.0                                               # w < 0 for every vertex
     _, s0, c0 = se.mask_variance(ctx, scene, far, H, W, return_counts=True)
     assert int(s0.abs().sum()) == 0 and int(c0.sum()) == 0
+
+
+def test_mask_variance_chain_equals_tile_path(env, oracle, xarm7, monkeypatch):
+    """The coverage-only chain on the solver's cluster / job machinery (the default where the call allows it) against the
+    per-triangle queue path and the oracle: counts and scores integer-equal, several chunks of candidates, a count image;
+    then the mesh is edited IN PLACE (same device pointers): the cached cluster index must notice and follow."""
+    se, ctx, _, dev = env
+    from easyhec_amd import fused
+    H, W, Q, S = 180, 320, 9, 10
+    mvp = candidate_mvps(xarm7, H, W, 0.25, Q, S, seed=21)
+    scene = fused.LinkScene([v.copy() for v, _ in xarm7.meshes], [f for _, f in xarm7.meshes], dev)
+    verts, tris, _, _ = helpers.scene_arrays(xarm7)
+    mvp_t = torch.tensor(mvp, device=dev)
+
+    def both():
+        monkeypatch.setenv("EHR_SCORE_PATH", "chain")      # an error if the chain cannot take the call
+        _, s1, c1 = se.mask_variance(ctx, scene, mvp_t, H, W, return_counts=True)
+        monkeypatch.setenv("EHR_SCORE_PATH", "tile")
+        _, s2, c2 = se.mask_variance(ctx, scene, mvp_t, H, W, return_counts=True)
+        monkeypatch.delenv("EHR_SCORE_PATH")
+        return s1.cpu().numpy(), c1.cpu().numpy(), s2.cpu().numpy(), c2.cpu().numpy()
+
+    s1, c1, s2, c2 = both()
+    s_ref, c_ref = oracle.mask_variance(verts, tris, vert_link_of(xarm7), mvp, H, W, return_counts=True)
+    assert (s1 == s_ref).all() and (c1 == c_ref).all() and (s2 == s_ref).all() and (c2 == c_ref).all() and s_ref.min() > 0
+    scene.verts.mul_(0.8)                                   # same pointers, other geometry
+    s1b, c1b, s2b, c2b = both()
+    s_refb, c_refb = oracle.mask_variance(verts * np.float32(0.8), tris, vert_link_of(xarm7), mvp, H, W, return_counts=True)
+    assert (s1b == s_refb).all() and (c1b == c_refb).all() and (s2b == s_refb).all() and (c2b == c_refb).all()
+    assert (s_refb != s_ref).any()
+
+
+def test_mask_variance_chain_falls_back_near_the_camera(env, oracle, xarm7, monkeypatch):
+    """Cameras a few centimetres from the robot and a 12x zoom hold triangles that cross the near plane or span hundreds
+    of pixels: coverage alone cannot decide there.  The chain reports that (an error when it is demanded), the default
+    call falls back to the exact path, results as the oracle's."""
+    se, ctx, scene, dev = env
+    from easyhec_amd.config import XARM7_K_1280x720
+    from easyhec_amd.synthetic import camera_Tc_c2b, make_views, scaled_K
+    H, W, Q = 240, 320, 2
+    K = scaled_K(XARM7_K_1280x720, 0.25, W, H, True)
+    Kz = K.copy()
+    Kz[:2, :2] *= 12.0
+    _, lp = make_views(xarm7, Q, seed=4)
+    cams = [(K, camera_Tc_c2b(radius=0.12, lift=0.15)), (Kz, camera_Tc_c2b(radius=0.45, lift=0.2)),
+            (K, camera_Tc_c2b(radius=0.9))]
+    mvp = np.stack([helpers.mvp_numpy(k, H, W, tc, lp) for k, tc in cams], axis=1)
+    verts, tris, _, _ = helpers.scene_arrays(xarm7)
+    s_ref, c_ref = oracle.mask_variance(verts, tris, vert_link_of(xarm7), mvp, H, W, return_counts=True)
+    _, s, c = se.mask_variance(ctx, scene, torch.tensor(mvp, device=dev), H, W, return_counts=True)
+    assert (s.cpu().numpy() == s_ref).all() and (c.cpu().numpy() == c_ref).all()
+    monkeypatch.setenv("EHR_SCORE_PATH", "chain")
+    with pytest.raises(RuntimeError):
+        se.mask_variance(ctx, scene, torch.tensor(mvp, device=dev), H, W, return_counts=True)
