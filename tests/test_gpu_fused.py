@@ -287,6 +287,27 @@ def test_franka_config4_full_size(oracle):
     assert (again[0] == mask).all() and (again[1] == loss).all() and (again[2] == grad).all()
 
 
+def test_franka_64_views_1080p_under_a_2gb_scratch_budget():
+    """Franka at 1920x1080 with 64 views in ONE call -- 576 (view, link) units, ~11 GB of scratch if taken in one piece --
+    with the per-chunk scratch bounded to 1.7 GB (EHR_VB_SCRATCH_MB; a process of its own: the budget is read once): the
+    call splits into chunks of views, the context takes less than 2 GB of device memory all told (chunk scratch, static
+    index, accumulators, spill pool), every view is finite and views 0-2 are bit-equal to a 3-view call."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env2 = dict(os.environ, EHR_VB_SCRATCH_MB="1700")
+    out = subprocess.run([sys.executable, os.path.join(here, "chunk_worker.py")], env=env2, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["views"] == 64 and res["finite"] and res["loss_min"] > 0
+    assert res["same_loss"] and res["same_grad"]
+    # the context's scratch; the torch caching allocator's blocks for mvp.grad / loss (a few MB) are inside the figure
+    assert res["scratch_bytes"] < 2.0e9, res["scratch_bytes"]
+
+
 def test_fused_edge_cases(env, oracle, xarm7):
     """Empty and ragged inputs: nothing in view, a single link / single view, a lone huge triangle that is queued in
     every tile of the image, sizes that are not multiples of the 32x8 tile, and the largest supported square image."""
