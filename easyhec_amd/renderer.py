@@ -23,6 +23,10 @@ class NVDiffrastRenderer:
         blender2opencv = opencv2blender(device=self.device)
         self.opencv2blender = torch.inverse(blender2opencv)
         self._topo = {}  # id(faces) -> (faces, version, TopologyHash); holding `faces` keeps the id valid
+        # per-call constants of the reference's schedule (one render per (frame, link): 64 calls per step at 8 views x 8
+        # links), cached on the identity + version of the tensor they derive from: the projection of K, the homogeneous
+        # vertex array and the all-ones vertex colour -- six small torch ops per call otherwise, a fifth of the step
+        self._const = {}
 
     def _topology(self, faces):
         ent = self._topo.get(id(faces))
@@ -33,27 +37,52 @@ class NVDiffrastRenderer:
             self._topo[id(faces)] = ent
         return ent[2]
 
+    def _cached(self, kind, t, make):
+        if not torch.is_tensor(t) or t.requires_grad:
+            return make()
+        key = (kind, id(t))
+        ent = self._const.get(key)
+        if ent is None or ent[0] is not t or ent[1] != t._version:
+            if len(self._const) > 256:
+                self._const.clear()
+            ent = (t, t._version, make())
+            self._const[key] = ent
+        return ent[2]
+
+    def _projection(self, K, device):
+        return self._cached("proj", K, lambda: K_to_projection(K, self.H, self.W).to(device))
+
+    def _clip_positions(self, mtx, verts):
+        """transform_pos(mtx, verts) with the homogeneous vertex array built once per vertex tensor."""
+        posw = self._cached("posw", verts, lambda: torch.cat(
+            [verts, torch.ones([verts.shape[0], 1], dtype=verts.dtype, device=verts.device)], dim=1))
+        return torch.matmul(posw, mtx.t())[None, ...]
+
     def render_mask(self, verts, faces, K, object_pose, anti_aliasing=True):
         """Silhouette of one mesh.  verts [N,3] float32 and faces [M,3] int32 on the HIP device, K [3,3] pinhole
         intrinsics, object_pose [4,4] camera<-object (OpenCV axes).  Returns the [H,W] float mask in [0,1] (row 0 = top),
         differentiable w.r.t. object_pose; with ``anti_aliasing=False`` a bool mask (``rast z/w > 0``)."""
-        proj = K_to_projection(K, self.H, self.W).to(verts.device)
+        proj = self._projection(K, verts.device)
         pose = self.opencv2blender @ object_pose
-        pos_clip = transform_pos(proj @ pose, verts)
+        pos_clip = self._clip_positions(proj @ pose, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
     def batch_render_mask(self, verts, faces, K, anti_aliasing=True):
         """Vertices already in the camera frame (nvdiffrast_renderer.py:49-72)."""
-        proj = K_to_projection(K, self.H, self.W).to(verts.device)
+        proj = self._projection(K, verts.device)
         pose = self.opencv2blender
-        pos_clip = transform_pos(proj @ pose, verts)
+        pos_clip = self._clip_positions(proj @ pose, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
     def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing):
         rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution)
         if anti_aliasing:
-            vtx_color = torch.ones(verts.shape, dtype=torch.float, device=verts.device)
-            color, _ = dr.interpolate(vtx_color[None, ...], rast_out, faces)
+            vtx_color = self._cached("ones", verts, lambda: torch.ones((1,) + tuple(verts.shape), dtype=torch.float,
+                                                                       device=verts.device))
+            # (the colour is the same at every vertex, so it does not depend on the barycentrics: the gradient that would
+            #  flow back through rast_out into pos_clip is exactly zero -- every term is dy * (1 - 1) -- and detaching saves
+            #  two full-image backward kernels per (frame, link); the silhouette gradient comes from dr.antialias)
+            color, _ = dr.interpolate(vtx_color, rast_out.detach(), faces)
             color = dr.antialias(color, rast_out, pos_clip, faces, topology_hash=self._topology(faces))
             mask = color[0, :, :, 0]
         else:
