@@ -1,34 +1,38 @@
-// ehr_vbuf.hip -- the fused hot path, visibility-buffer form (round 2; the default).  Same arithmetic and outputs as the
-// LDS-tile chain in ehr_fused.hip (kept behind EHR_FUSED_PATH=tile), restating
+// ehr_vbuf.hip -- the fused hot path: the kernels and the launch chain behind ehr_render_mask_loss / ehr_solver_step
+// (host entry points: ehr_fused.hip) and the coverage-only chain of ehr_mask_variance (vbuf_score).  Restates
 //   /root/reference/easyhec/modeling/models/rb_solve/rb_solver.py:60-72   (per-link render, sum, clamp, SSE)
 //   /root/reference/easyhec/structures/nvdiffrast_renderer.py:33-47        (rasterize -> interpolate -> antialias -> flip)
 //   /root/reference/easyhec/utils/nvdiffrast_utils.py:14-18                (transform_pos)
-// but without per-step triangle binning: no (tile, link) queues are built, counted, allocated or filled.  The meshes
-// project to micro-triangles (median bounding box 8 px, a quarter of them cover no pixel centre at all), for which
-// building and draining per-tile queues cost more than the coverage tests themselves.  Instead ehr_fused_plan groups
-// every link's triangles ONCE into clusters of 64 spatially close ones (recursive median split of the centroids in object space,
-// valid for every pose), and a step is four launches:
+// without per-step triangle binning: no (tile, link) queues are built, counted, allocated or filled.  The meshes
+// project to micro-triangles (median bounding box 8 px, a fifth of the non-empty boxes cover no pixel centre at all), for
+// which building and draining per-tile queues cost more than the coverage tests themselves.  Instead ehr_fused_plan
+// groups every link's triangles ONCE into clusters of 64 spatially close ones (recursive median split of the centroids
+// in object space, valid for every pose), and a step is five launches per chunk of views:
 //
 //   vb_vertex_kernel    [pose forward] + clip-space vertices (posc) + one wave per cluster: transforms the cluster's
-//                       triangles, snaps them, and publishes per triangle its pixel box (tbox) and its raster record
-//                       (integer edge functions with the tie rule folded in, depth-range class; trec);
-//                       per cluster and per link the union of the boxes (cbox; lbox through integer atomics).
+//                       triangles, snaps them, tests small boxes exactly (a triangle that covers no pixel centre is
+//                       dropped here, once) and publishes per triangle its pixel box (tbox) and its raster record
+//                       (integer edge functions with the tie rule folded in, depth-range class; trec); per cluster and
+//                       per link the union of the boxes (cbox; lbox through integer atomics).
 //   vb_job_kernel       one WAVE per job = (view, link, 32x8 tile the link's box touches), persistent waves over a job
-//                       list that is never materialised.  A job culls cluster boxes, then triangle boxes, rasterizes the
-//                       survivors with a wave-wide balanced walker into its LDS depth/id buffer (ds_min_u64 on
-//                       ordered(z/w) << 32 | triangle: order independent, hence the oracle's z-buffer bit for bit), finds
-//                       the covered/uncovered pixel pairs with bit arithmetic on the coverage bitmap, runs the silhouette
-//                       analysis and leaves the link's 256 antialiased values + the blended pairs in the job's slot.
-//                       Jobs that were heavy in the previous step go first, one workgroup each.
-//   vb_composite_kernel one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses): sums the links' values in link
-//                       order, clamps, frame loss, mask write, and back-propagates the tile's blended pairs to 12 numbers
-//                       per link which go to the view's fixed-point accumulators.  Tiles no link touches just stream.
-//   fused_finish_kernel (shared with the tile chain)  accumulators -> loss / grad_mvp [-> pose backward -> Adam];
-//                       re-arms the link boxes.
+//                       list that is never materialised.  A job culls cluster boxes, then triangle boxes, and rasterizes
+//                       the survivors COVERAGE FIRST: a wave-wide balanced walker (units of 4 pixels for narrow boxes,
+//                       exactly solved row spans for wide ones) ORs coverage into an LDS bitmap and defers the covered
+//                       units; at the job's end only the units that hold a covered pixel with an uncovered neighbour
+//                       are depth tested (ds_min_u64 on ordered(z/w) << 32 | triangle: order independent, hence the
+//                       oracle's z-buffer bit for bit wherever anyone will look).  Last step's heaviest jobs go first
+//                       on whole workgroups, its long ones as the waves' static first jobs.
+//   vb_slow_kernel      (normally empty) jobs that met a triangle for the general path: near-plane clipping, 64-bit edges.
+//   vb_resolve_kernel   one wave per drawn job: covered/uncovered pixel pairs by bit arithmetic on the coverage bitmap,
+//                       silhouette analysis of the hits, the link's 256 antialiased values + the blended pairs -> job slot.
+//   vb_composite_kernel one wave per tile that holds a job (every tile without a bound reference mask): sums the links'
+//                       values in link order, clamps, frame loss, mask write, back-propagates the tile's blended pairs
+//                       to 12 numbers per link in the view's fixed-point accumulators; its last-arriving workgroup runs
+//                       the finish stage (accumulators -> loss / grad_mvp [-> pose backward -> Adam]).
 //
-// An earlier form of this file kept the depth/id image in HBM and resolved visibility with one 64-bit global atomic-min
-// per covered pixel; global atomics execute memory-side on this part (4.6 G/s with raster locality: 272 us for the
-// 1.26 M fragments of the 8-view workload), see DESIGN.md section 6.
+// An earlier form kept the depth/id image in HBM and resolved visibility with one 64-bit global atomic-min per covered
+// pixel; global atomics execute memory-side on this part (4.6 G/s with raster locality: 272 us for the 1.26 M fragments
+// of the 8-view workload), see DESIGN.md section 6.
 #include <stdlib.h>
 #include <string.h>
 
