@@ -1,6 +1,7 @@
 """``FusedPoseStep`` -- one optimisation step of /root/reference/easyhec/trainer/rbsolver.py:29-43 as a fixed chain of
-HIP launches with no host round trip: pose_forward -> {vertex transform, bin count/alloc/fill, tile kernels,
-reduce} -> pose_backward -> [all-reduce of 8 floats when data-parallel] -> Adam.
+HIP launches with no host round trip: [pose forward + vertices + raster records] -> jobs (coverage, depth where the
+silhouette analysis will look) -> resolve -> composite [+ in its last workgroup: loss, gradients, pose backward] ->
+[all-reduce of 8 floats when data-parallel] -> Adam.
 
 It operates IN PLACE on an :class:`easyhec_amd.rb_solver.RBSolver`'s ``dof`` parameter and ``history_ops`` buffer and
 keeps torch.optim.Adam-compatible state (exp_avg, exp_avg_sq, step), so it is interchangeable with the autograd path
