@@ -82,6 +82,61 @@ def test_fused_slow_tiles_match_oracle(env, oracle, xarm7):
     assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
 
 
+def test_span_walker_on_slivers_and_axis_aligned_edges(env, oracle):
+    """Synthetic long thin triangles (boxes of 4+ units per row: the job kernel's span walker, which solves every row's
+    covered span from the edge functions) at random slopes and sub-pixel offsets, plus exactly horizontal / vertical /
+    45-degree edges through pixel centres (zero edge steps, quotients that are exact integers: the tie cases of the
+    solver's integer correction) and tiny triangles the vertex kernel's exact small-box test has to judge -- masks,
+    losses and gradients against the oracle, bit-exact on the masks."""
+    fused, ctx, _, dev = env
+    H, W = 96, 160
+    rng = np.random.default_rng(12)
+    verts, tris = [], []
+
+    def add(a, b, c):
+        i = len(verts)
+        verts.extend([a, b, c])
+        tris.append([i, i + 1, i + 2])
+
+    def px(x, y, z=0.0):   # pixel coordinates (centre of pixel (ix, iy) = (ix + 0.5, iy + 0.5)) -> object space of an identity MVP
+        return [2.0 * x / W - 1.0, 2.0 * y / H - 1.0, z]
+
+    for _ in range(160):   # slivers: two far-apart points and a third one 0.2-2 pixels off the line, random winding
+        p = rng.uniform([5, 5], [W - 5, H - 5])
+        ang = rng.uniform(0, 2 * np.pi)
+        ln = rng.uniform(20, 90)
+        q = np.clip(p + ln * np.array([np.cos(ang), np.sin(ang)]), 2, [W - 2, H - 2])
+        m = 0.5 * (p + q) + rng.uniform(0.2, 2.0) * np.array([-np.sin(ang), np.cos(ang)])
+        z = rng.uniform(-0.5, 0.5)
+        pts = [px(*p, z), px(*q, z), px(*m, z)]
+        if rng.uniform() < 0.5:
+            pts = pts[::-1]
+        add(*pts)
+    for k in range(12):    # axis-aligned and diagonal edges exactly through pixel centres, widths of 4+ units
+        y0 = 6.5 + 7 * k
+        add(px(10.5, y0), px(70.5, y0), px(40.5, y0 + 3.0))          # horizontal edge on a row of centres
+        add(px(90.5 + k, 4.5), px(90.5 + k, 60.5), px(93.5 + k, 30.5))  # vertical edge on a column of centres
+        add(px(100.5, 10.5 + k), px(150.5, 60.5 + k), px(150.5, 10.5 + k))  # 45 degrees through centres
+    for _ in range(300):   # tiny triangles around pixel centres and between them
+        c = rng.uniform([3, 3], [W - 3, H - 3])
+        d = rng.uniform(-1.2, 1.2, (3, 2))
+        add(*[px(c[0] + d[i, 0], c[1] + d[i, 1]) for i in range(3)])
+    v = np.asarray(verts, np.float32)
+    f = np.asarray(tris, np.int32)
+    scene = fused.LinkScene([v], [f], dev)
+    mvp = np.eye(4, dtype=np.float32)[None, None].repeat(2, axis=0)
+    mvp[1, 0, 0, 3] = 0.37 / W                     # second view: everything shifted by a fraction of a pixel
+    mvp[1, 0, 1, 3] = -0.61 / H
+    ref = (rng.uniform(size=(2, H, W)) > 0.5).astype(np.float32)
+    toff, voff = np.array([0, f.shape[0]], np.int32), np.array([0, v.shape[0]], np.int32)
+    m_ref, l_ref, g_ref = oracle.render_mask_loss(v, f, toff, voff, mvp, ref)
+    assert 0.05 < (m_ref > 0).mean() < 0.9
+    mask, loss, grad = run(fused, ctx, scene, mvp, ref, dev)
+    assert (mask == m_ref).all()
+    assert np.abs(loss - l_ref).max() <= 1e-6 * np.abs(l_ref).max()
+    assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+
+
 def test_fused_golden_fixtures(env, xarm7):
     fused, ctx, scene, dev = env
     g = np.load(os.path.join(GOLD, "fused_xarm7_160x120.npz"))
