@@ -44,7 +44,6 @@ struct StepTail;
 #define VB_LOSS_SLOTS 32          // partial frame-loss sums per view (spreads same-address atomics)
 #define VB_LOSS_STRIDE 16         // i64 between two of them: one 128-byte line each (atomics on one line serialise)
 #define VB_MAX_UNITS 512          // views x links one context plans for
-#define VB_MAX_VIEWS VB_MAX_UNITS  // (every view has at least one link)
 #define VB_SPILL_ITEMS (1 << 20)  // pool of blended-pair items for tiles that overflow their LDS list (16 MB)
 int vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
               const int32_t* tris, const int32_t* tri_link, const int32_t* opp);

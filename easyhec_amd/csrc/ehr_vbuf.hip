@@ -66,7 +66,6 @@ constexpr int VB_MED_CAP = 2048;      // long single-wave jobs remembered per st
 constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
 constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
 constexpr u64 VB_EMPTY = ~0ull;
-#define VB_SMALL_BOX 16                // pixel boxes up to this size are walked by the triangle's own lane
 #define VB_FAST_EXTENT 8192            // snapped extent (1/16 px) up to which 32-bit edge functions are exact
 
 // Counters that many waves hit with atomics each get a 128-byte line of their own behind the meta block (atomics on
