@@ -62,9 +62,11 @@ class NVDiffrastRenderer:
         """Silhouette of one mesh.  verts [N,3] float32 and faces [M,3] int32 on the HIP device, K [3,3] pinhole
         intrinsics, object_pose [4,4] camera<-object (OpenCV axes).  Returns the [H,W] float mask in [0,1] (row 0 = top),
         differentiable w.r.t. object_pose; with ``anti_aliasing=False`` a bool mask (``rast z/w > 0``)."""
-        proj = self._projection(K, verts.device)
-        pose = self.opencv2blender @ object_pose
-        pos_clip = self._clip_positions(proj @ pose, verts)
+        # proj @ (opencv2blender @ object_pose) with the constant product taken once: opencv2blender = diag(1, -1, -1, 1)
+        # only flips signs, so (proj @ o2b) @ pose has the same products and sums, bit for bit, one matmul (and its
+        # backward node) less per call
+        po = self._cached("po", K, lambda: self._projection(K, verts.device) @ self.opencv2blender)
+        pos_clip = self._clip_positions(po @ object_pose, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
     def batch_render_mask(self, verts, faces, K, anti_aliasing=True):
