@@ -1176,137 +1176,6 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
     return drawn ? 1 : 0;
 }
 
-#ifndef VB_HELP
-#define VB_HELP 0
-#endif
-#if VB_HELP
-// ---- helping: waves that have run out of jobs take rasterizer rounds off their siblings' jobs ------------------------
-// The job kernel ends on single-wave jobs that are long chains: ~10 dependent round trips of culling and 5-7 rounds.
-// A wave of the same workgroup that has nothing left to claim takes whole rounds (blocks of 64 queued survivors) of
-// such a job: it reads the block, claims it with a compare-and-swap on the queue's head (monotonic counters: a stale
-// claim can never succeed on a later job), rasterizes it into the owner's coverage / depth buffers (LDS atomics, as in
-// a shared job) and keeps the deferred units in its own list until the owner announces that the coverage is complete;
-// then it flushes them against it and lets go.  No wave ever waits for a wave that could be waiting for it: the owner
-// waits for claimed rounds (`busy`) and for bound helpers' flushes (`bound`), a helper waits for `done` only while it
-// holds no round.  All waits are bounded (a broken protocol raises the overflow flag instead of hanging the GPU).
-struct VbShare {
-    int tail;   // survivors pushed (monotonic over the kernel); the owner alone writes it
-    int head;   // survivors claimed, in blocks of 64 (monotonic); compare-and-swap by the owner and by helpers
-    int busy;   // rounds helpers have claimed and not finished
-    int bound;  // helpers that may hold deferred units of this job
-    int gen;    // odd: a job is open for help; even: none
-    int done;   // == gen: the open job's coverage is complete
-    int abort;  // a helper's round met a triangle for the general path
-    int cost;   // the helpers' part of the job's cost
-    int b, l, rx0, ry0;
-    int fin;    // this wave has left its job loop
-    int pad[3];
-};
-#define VB_POLL_MAX (1 << 22)
-
-// The single-wave job with its survivor queue open to helpers (lean code only: no general triangles, one owner).  ONE
-// call site of the rasterizer round: pressure on the ring, a full block after a push and the final drain (a sentinel
-// pass after the last cluster, which also takes the last, partial block) all go through it.
-__device__ __forceinline__ int vb_job_raster_help(const VbJobArgs& A, VbWaveLds& W_, VbShare& sh, const int* nfin, int b, int l,
-                                                  const VbRegion& rg, int rx0, int ry0, int& nsurv, int& dln) {
-    const int lane = lane_id();
-    const int c0 = A.lcoff[l], c1 = A.lcoff[l + 1];
-    const uint2* const cb = A.rc.cbox + (size_t)b * A.NC;
-    const unsigned rlo = (unsigned)rg.x0 | ((unsigned)rg.y0 << 16), rhi = (unsigned)rg.x1 | ((unsigned)rg.y1 << 16);
-    const size_t vbase = (size_t)b * A.NC * 64;
-    const float4* const pv = A.posc + (size_t)b * A.V;
-    const int4* const cvl = A.cvidx + (size_t)c0 * 64;
-    const unsigned srel0 = (unsigned)c0 * 64u;
-    bool full = false, drawn = false;
-    int tail = sh.tail;  // (== head: the previous job was drained)
-    int ret = 0;
-    for (int cbase = c0;; cbase += 64) {
-        const bool last = cbase >= c1 || full;  // the sentinel pass: nothing to cull, the queue is drained
-        const int c = cbase + lane;
-        bool hit = false;
-        if (!last && c < c1) {
-            const uint2 bx = cb[c];
-            hit = (bx.x & 0xffffu) <= (rhi & 0xffffu) && (bx.y & 0xffffu) >= (rlo & 0xffffu) &&
-                  (bx.x >> 16) <= (rhi >> 16) && (bx.y >> 16) >= (rlo >> 16);
-        }
-        u64 cm = last ? 1ull : __ballot(hit);
-        while (cm) {  // wave-uniform
-            int cc[4];
-            uint2 tb[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                cc[k] = -1;
-                tb[k] = VB_BOX_EMPTY;
-                if (cm && !last) {
-                    cc[k] = cbase + __ffsll((unsigned long long)cm) - 1;
-                    cm &= cm - 1;
-                    tb[k] = A.rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
-                }
-            }
-            if (last) cm = 0;
-            u64 smk[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                smk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
-                                  (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
-#pragma nounroll
-            for (int k = 0; k < (last ? 1 : 4); k++) {
-                const u64 sm = (k == 0) ? smk[0] : (k == 1) ? smk[1] : (k == 2) ? smk[2] : smk[3];
-                const int ck = (k == 0) ? cc[0] : (k == 1) ? cc[1] : (k == 2) ? cc[2] : cc[3];
-                if (!sm && !last) continue;
-                bool pushed = last;  // (the sentinel pushes nothing)
-                for (int spin = 0;; spin++) {
-                    VB_WAVE_SYNC();
-                    const int h = sh.head;
-                    int avail = tail - h;
-                    if (!pushed && avail <= 64) {  // room for up to 64 more entries (the ring holds 128)
-                        if ((sm >> lane) & 1) W_.sq[(tail + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
-                        tail += __popcll(sm);
-                        drawn = true;
-                        pushed = true;
-                        VB_WAVE_SYNC();
-                        if (lane == 0) sh.tail = tail;
-                        avail = tail - h;
-                    }
-                    // a round now?  under pressure (no room to push); a whole block that no free sibling will take;
-                    // at the end whatever is left (the last block may be partial: only the owner takes those)
-                    const int n = min(avail, 64);
-                    const bool want = !pushed ? true : (last ? (avail > 0 && !full) : (avail >= 64 && (*nfin == 0 || avail > 64) && !full));
-                    if (!want) break;
-                    if (n == 64 || last) {
-                        const bool sv = lane < n;
-                        const unsigned sl = sv ? W_.sq[(h + lane) & 127] : srel0;
-                        int ok = 0;
-                        if (lane == 0) ok = atomicCAS(&sh.head, h, h + n) == h;
-                        ok = __builtin_amdgcn_readfirstlane(ok);
-                        if (ok) {
-                            dln = vb_raster_round<false, false>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, W_.key, W_.cov, dln,
-                                                                pv, cvl, full, nsurv);
-                            if (dln < 0) {
-                                ret = -1;
-                                goto out;
-                            }
-                        }
-                    } else {
-                        __builtin_amdgcn_s_sleep(1);  // (pressure, but the blocks in front are being claimed by helpers)
-                    }
-                    if (spin > VB_POLL_MAX) {
-                        ret = -2;
-                        goto out;
-                    }
-                }
-            }
-        }
-        if (last) break;
-    }
-    ret = drawn ? 1 : 0;
-out:
-    VB_WAVE_SYNC();
-    if (lane == 0) sh.head = tail;  // (whatever is still queued -- a region found full, an abort -- is dropped)
-    return ret;
-}
-#endif  // VB_HELP
-
 // A drawn job leaves, in its slot, the coverage rows of its region and the triangle id of every pixel the depth test ran
 // for (all-ones elsewhere), then its descriptor; the resolve kernel takes it from there (an undrawn job's descriptor is
 // -1).  No list of drawn jobs: appending to one costs every job a returning atomic (~3 us under load), and three
@@ -1400,15 +1269,6 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     __shared__ int lcoff[33];                 // first cluster of every link
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbWaveLds& S = lds_all[wave];
-#if VB_HELP
-    __shared__ VbShare share[4];
-    __shared__ int s_nfin;  // waves of this workgroup that have left their job loop
-    if (tid < 4) {
-        VbShare z = {};
-        share[tid] = z;
-    }
-    if (tid == 0) s_nfin = 0;
-#endif
     const int W = g.W, H = g.H, L = g.L, U = B * L;
     // ---- prologue (every workgroup, redundantly): tile range and job count of every (view, link), prefix sum
     if (tid <= L) lcoff[tid] = cl.coff[tid];
@@ -1596,10 +1456,8 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         const long long tl_j0 = __builtin_readcyclecounter();
 #endif
         int job = 0, u = -1, tx = 0, ty = 0;
-        bool from_list = false;  // one of last step's long jobs (its queue is opened to helpers)
         if (first_job && rx < nmx) {
             first_job = false;
-            from_list = true;
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(VB_PRIO_LONG);
 #endif
@@ -1671,64 +1529,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         const long long tl_j1 = __builtin_readcyclecounter();
 #endif
         int nsurv = 0, dln = 0;
-#if VB_HELP
-        int drawn;
-        bool flushed = false;
-        if (COVER || !from_list) {
-            drawn = vb_job_raster<false, COVER>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
-        } else {
-            VbShare& sh = share[wave];
-            if (lane == 0) {
-                sh.b = b;
-                sh.l = l;
-                sh.rx0 = rx0;
-                sh.ry0 = ry0;
-                sh.abort = 0;
-                sh.cost = 0;
-            }
-            VB_WAVE_SYNC();
-            const int g1 = sh.gen + 1;  // odd: open for help
-            if (lane == 0) sh.gen = g1;
-            VB_WAVE_SYNC();
-            drawn = vb_job_raster_help(A, S, sh, &s_nfin, b, l, rg, rx0, ry0, nsurv, dln);
-            VB_WAVE_SYNC();
-            bool broken = drawn == -2;
-            for (int spin = 0;; spin++) {  // rounds that helpers have claimed
-                VB_WAVE_SYNC();
-                if (sh.busy == 0) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (spin > VB_POLL_MAX) {
-                    broken = true;
-                    break;
-                }
-            }
-            VB_WAVE_SYNC();
-            if (sh.abort) drawn = -1;
-            nsurv += sh.cost;
-            if (lane == 0) sh.done = g1;  // the coverage is complete: bound helpers flush their units and let go
-            VB_WAVE_SYNC();
-            if (drawn >= 0 && dln > 0) {
-                vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
-                flushed = true;
-            }
-            for (int spin = 0;; spin++) {
-                VB_WAVE_SYNC();
-                if (sh.bound == 0) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (spin > VB_POLL_MAX) {
-                    broken = true;
-                    break;
-                }
-            }
-            VB_WAVE_SYNC();
-            if (lane == 0) sh.gen = g1 + 1;  // closed
-            if (broken && lane == 0) meta[EHR_META_OVERFLOW] = 1;  // (protocol failure: reported, never a hang)
-            VB_WAVE_SYNC();
-        }
-#else
         const int drawn = vb_job_raster<false, COVER>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
-        const bool flushed = false;
-#endif
         if (COVER) {
             // flagged units (their depth range must be tested per pixel: edge-on slivers mostly) are the only deferred ones
             if (drawn >= 0 && dln > 0)
@@ -1754,7 +1555,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
             continue;
         }
-        if (dln > 0 && !flushed) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+        if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
 #ifdef VB_TIMELINE
         tl_jobs++;
         tl_maxsurv = max(tl_maxsurv, nsurv);
@@ -1786,107 +1587,6 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         }
 #endif
     }
-#if VB_HELP == 1
-    if (!COVER) {
-        // ---- out of jobs: help the siblings with their rounds until every wave of the workgroup is out of jobs
-        if (lane == 0) {
-            share[wave].fin = 1;
-            atomicAdd(&s_nfin, 1);
-        }
-        __builtin_amdgcn_s_setprio(0);  // (polling must not compete with the siblings that still work)
-        int hd = 0, bound_to = -1, bound_gen = 0;
-        int spin = 0;
-        for (;; spin++) {
-            VB_WAVE_SYNC();
-            if (spin > VB_POLL_MAX) {  // protocol failure: reported, never a hang
-                if (lane == 0) {
-                    meta[EHR_META_OVERFLOW] = 1;
-                    if (bound_to >= 0) atomicSub(&share[bound_to].bound, 1);
-                }
-                break;
-            }
-            if (bound_to >= 0) {
-                VbShare& o = share[bound_to];
-                if (o.done == bound_gen) {  // the job's coverage is complete: my deferred units against it, then let go
-                    if (hd > 0 && !o.abort) {
-                        const int ob = o.b, ol = o.l;
-                        vb_flush(S, lds_all[bound_to].key, lds_all[bound_to].cov, hd, posc + (size_t)ob * V, si.cvidx + (size_t)lcoff[ol] * 64, W,
-                                 H, o.rx0, o.ry0);
-                    }
-                    hd = 0;
-                    VB_WAVE_SYNC();
-                    if (lane == 0) atomicSub(&o.bound, 1);
-                    bound_to = -1;
-                    continue;
-                }
-            }
-            int took = 0;
-            for (int d = 1; d < 4; d++) {
-                const int si_ = bound_to >= 0 ? bound_to : ((wave + d) & 3);
-                VbShare& o = share[si_];
-                const int g1 = o.gen;
-                if ((g1 & 1) && o.done != g1 && o.tail - o.head >= 64) {
-                    if (bound_to < 0) {  // bind first: from here on the owner waits for my flush before it lets the job go
-                        if (lane == 0) atomicAdd(&o.bound, 1);
-                        VB_WAVE_SYNC();
-                        if (o.gen != g1 || o.done == g1) {  // (it closed in between)
-                            if (lane == 0) atomicSub(&o.bound, 1);
-                            VB_WAVE_SYNC();
-                            continue;
-                        }
-                        bound_to = si_;
-                        bound_gen = g1;
-                    }
-                    if (lane == 0) atomicAdd(&o.busy, 1);
-                    VB_WAVE_SYNC();
-                    const int h = o.head;
-                    int ok = 0;
-                    unsigned sl = 0;
-                    if (o.tail - h >= 64) {
-                        sl = lds_all[si_].sq[(h + lane) & 127];
-                        if (lane == 0) ok = atomicCAS(&o.head, h, h + 64) == h;
-                        ok = __builtin_amdgcn_readfirstlane(ok);
-                    }
-                    if (ok) {
-                        const int ob = o.b, ol = o.l, orx = o.rx0, ory = o.ry0;
-                        VbRegion org;
-                        org.x0 = max(orx, 0);
-                        org.y0 = max(ory, 0);
-                        org.x1 = min(orx + VB_RW - 1, W - 1);
-                        org.y1 = min(ory + VB_RH - 1, H - 1);
-                        const size_t ovb = (size_t)ob * A.NC * 64;
-                        const unsigned osr = (unsigned)lcoff[ol] * 64u;
-                        bool ofull = false;
-                        int ocost = 0;
-#if VB_PRIO_LONG
-                        __builtin_amdgcn_s_setprio(VB_PRIO_LONG);
-#endif
-                        const int r = vb_raster_round<false, false>(true, ovb + sl, sl - osr, A.rc, org, orx, ory, W, H, S, lds_all[si_].key,
-                                                                    lds_all[si_].cov, hd, posc + (size_t)ob * V,
-                                                                    si.cvidx + (size_t)lcoff[ol] * 64, ofull, ocost);
-                        if (r < 0) {
-                            hd = 0;
-                            if (lane == 0) o.abort = 1;
-                        } else {
-                            hd = r;
-                        }
-                        if (lane == 0) atomicAdd(&o.cost, ocost);
-                        __builtin_amdgcn_s_setprio(0);
-                        took = 1;
-                    }
-                    VB_WAVE_SYNC();
-                    if (lane == 0) atomicSub(&o.busy, 1);
-                }
-                if (bound_to >= 0 || took) break;
-            }
-            if (!took) {
-                VB_WAVE_SYNC();
-                if (bound_to < 0 && s_nfin == 4) break;
-                __builtin_amdgcn_s_sleep(16);
-            }
-        }
-    }
-#endif
 #ifdef VB_TIMELINE
     if (lane == 0 && timeline) {
         const size_t gw = (size_t)blockIdx.x * 4 + wave;
