@@ -1,6 +1,6 @@
-"""Randomised parity sweep (run on the GPU box): the fused op and the scoring op against the CPU oracle on random
+"""Randomised parity sweep (test infrastructure, run by hand on the GPU box; not collected by pytest): the fused op and the scoring op against the CPU oracle on random
 resolutions, zooms, camera distances (down to a few centimetres from the robot) and joint configurations -- masks and
-counts bit-exact, losses / gradients within the suite's tolerances.  python tools/fuzz_parity.py [--cases 120] [--seed 0]"""
+counts bit-exact, losses / gradients within the suite's tolerances.  python tests/fuzz_parity.py [--cases 120] [--seed 0]"""
 import argparse
 import os
 import sys
@@ -9,9 +9,10 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 import helpers  # noqa: E402
 from easyhec_amd import dr, fused, space_explorer as se  # noqa: E402
 from easyhec_amd.config import XARM7_K_1280x720  # noqa: E402
