@@ -119,7 +119,9 @@ def cpu_baseline(p, budget_s=10.0):
     return {"value": round(fps, 3), "unit": "frames/s", "cores": int(cores), "kind": "port",
             "value_1thread": round(fps1, 3), "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
             "sample": f"{reps} x ({mvp.shape[0]} views 1280x720, fwd+bwd) of the same batch at the initial pose, {el:.1f} s "
-                      f"wall, OpenMP over views ({cores} threads busy); 1-thread leg: {reps1} x 1 view, {el1:.1f} s"}
+                      f"wall, OpenMP over views ({cores} threads busy); 1-thread leg: {reps1} x 1 view, {el1:.1f} s; "
+                      "oracle built with gcc -O2 -mfma -ffp-contract=off (oracle/Makefile; not -O3 -march=native: the "
+                      "library is built in the CPU container and must run on the GPU box's host)"}
 
 
 def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
@@ -138,6 +140,70 @@ def measured_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def timed_blocks(step, steps, barrier, min_ms, world=1, dev=None, max_blocks=1000):
+    """Blocks of exactly `steps` steps, each between two barriers (driver contract), repeated until `min_ms` of timed
+    work has accumulated; returns (mean seconds per block, blocks).  Every rank runs the same number of blocks."""
+    elapsed, blocks = 0.0, 0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed += time.perf_counter() - t0
+        blocks += 1
+        again = elapsed * 1e3 < min_ms and blocks < max_blocks
+        if world > 1:
+            flag = torch.tensor([1 if again else 0], device=dev)
+            dist.broadcast(flag, src=0)
+            again = bool(int(flag.item()))
+        if not again:
+            break
+    return elapsed / blocks, blocks
+
+
+def stage_times(p, steps):
+    """hipEvents around each kernel of the chain (eager launches), `steps` more steps of the same optimisation."""
+    from easyhec_amd import fused
+    tr = p["trainer"]
+    fused.set_timing(p["glctx"], True)
+    if tr.fast is not None:
+        tr.fast.release_graph()  # hipEvents between kernels need eager launches
+    for _ in range(steps):
+        tr.step()
+    stage_ms, ncalls = fused.read_timing(p["glctx"])
+    fused.set_timing(p["glctx"], False)
+    return {k: v / max(ncalls, 1) for k, v in stage_ms.items() if not k.startswith("unused")}
+
+
+def side_workload(name, dev, steps, warmup, min_ms=30.0):
+    """One of the other BASELINE configs on this GPU (configs[1], [3] and [4]'s total on one device), timed exactly like the
+    headline: {ms_per_step, value, frac, frac_step, kernel_ms}.  Bounded: ~`min_ms` of timed work."""
+    from easyhec_amd import fused
+    p = build_problem(0, 1, dev, workload=name)
+    tr = p["trainer"]
+
+    def barrier():
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        tr.step()
+    el, blocks = timed_blocks(tr.step, steps, barrier, min_ms)
+    fused.check_status(p["glctx"])
+    st = stage_times(p, steps)
+    bytes_frame = algorithmic_bytes_per_frame(p["robot"], p["H"], p["W"])
+    fps = p["n_views"] * steps / el
+    kernel_ms = st[fused.DOMINANT_STAGE]
+    out = {"ms_per_step": round(el / steps * 1e3, 4), "value": round(fps, 1), "views": p["n_views"],
+           "frac": round(bytes_frame * p["B"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms > 0 else None,
+           "frac_step": round(fps * bytes_frame / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
+           "stage_ms": {k: round(v, 5) for k, v in st.items()},
+           "timed_blocks": blocks, "final_mask_loss": round(float(tr.last_loss), 3)}
+    del tr, p
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: libraries that chat on stdout (RCCL prints a version banner when a
     # communicator is created) go to stderr for the whole run
@@ -154,6 +220,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="reference-shaped torch autograd step instead of the HIP launch chain")
     ap.add_argument("--workload", default=WORKLOAD, help="side measurements only; the headline is the default")
+    ap.add_argument("--no-side", action="store_true", help="skip the side workloads (the other BASELINE configs, ~0.5 s each)")
     ap.add_argument("--graph", action="store_true", help="replay the launch chain as a natively captured hipGraph (saves host time only)")
     args = ap.parse_args()
 
@@ -199,23 +266,7 @@ def main():
     # thin sample (20 steps = 2 ms), so blocks are repeated -- each bracketed the same way, the optimisation simply
     # continues -- until at least --min-ms of timed work has accumulated; the reported time per step is the mean over all
     # timed steps.  Every rank runs the same number of blocks (rank 0's decision is broadcast).
-    elapsed, blocks = 0.0, 0
-    while True:
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed += time.perf_counter() - t0
-        blocks += 1
-        again = elapsed * 1e3 < args.min_ms and blocks < 1000
-        if world > 1:
-            flag = torch.tensor([1 if again else 0], device=dev)
-            dist.broadcast(flag, src=0)
-            again = bool(int(flag.item()))
-        if not again:
-            break
-    elapsed /= blocks  # mean duration of one block of --steps steps
+    elapsed, blocks = timed_blocks(step, args.steps, barrier, args.min_ms, world, dev)  # mean duration of one block
     fused.check_status(p["glctx"])
     per_rank_ms, allreduce_us = None, None
     if world > 1:
@@ -246,14 +297,25 @@ def main():
         allreduce_us = (time.perf_counter() - ta) / 200 * 1e6
     final_loss = float(tr.last_loss)
 
+    # the same step WITH the rendered masks written (rb_solver.py:73-77 materialises `rendered_masks` every step): the
+    # chain then streams every tile of every view (the bound reference's cached sums do not apply) and writes mask[B,H,W]
+    with_mask_ms = None
+    if tr.fast is not None and world == 1:
+        mstep = lambda: tr.fast.step(want_mask=True)  # noqa: E731
+        for _ in range(max(2, args.warmup // 4)):
+            mstep()
+        el_m, _ = timed_blocks(mstep, args.steps, barrier, min(args.min_ms, 30.0))
+        with_mask_ms = el_m / args.steps * 1e3
     # roofline leg: hipEvents around each kernel of the fused op, same K steps again (continuing the optimisation)
-    fused.set_timing(p["glctx"], True)
-    if tr.fast is not None:
-        tr.fast._graph = None  # hipEvents between kernels need eager launches
-    for _ in range(args.steps):
-        step()
-    stage_ms, ncalls = fused.read_timing(p["glctx"])
-    fused.set_timing(p["glctx"], False)
+    stage_ms = stage_times(p, args.steps)
+    side = None
+    if world == 1 and rank == 0 and not args.no_side and args.workload == WORKLOAD and not args.eager:
+        side = {}
+        for name in ("xarm7_640x480_1view", "franka_1920x1080_16view", "xarm7_1280x720_64view"):
+            try:
+                side[name] = side_workload(name, dev, max(10, args.steps // 2), max(5, args.warmup // 2))
+            except Exception as e:  # a side measurement must never cost the headline line
+                side[name] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         frames = p["n_views"] * args.steps
@@ -261,7 +323,7 @@ def main():
         bytes_frame = algorithmic_bytes_per_frame(p["robot"], p["H"], p["W"])
         # the dominant kernel (fused.DOMINANT_KERNEL), bracketed by its own pair of hipEvents on the launch stream
         # (compare with rocprofv3's average for it in profiles/)
-        tile_ms = stage_ms[fused.DOMINANT_STAGE] / max(ncalls, 1)
+        tile_ms = stage_ms[fused.DOMINANT_STAGE]
         bytes_launch = bytes_frame * p["B"]
         achieved = bytes_launch / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
         step_gbs = fps * bytes_frame / 1e9  # SURVEY 8d's own definition: frames/s x bytes_frame (whole step, all kernels)
@@ -279,6 +341,22 @@ def main():
                 traffic_src = {"file": "profiles/traffic.json", "commit": tj.get("commit"), "launch_form": tj.get("launch_form")}
             except Exception:
                 traffic = None
+        # what binds the dominant kernel besides bandwidth (it is not HBM-bound at 8 views): VALU issue utilisation from the SQ
+        # counters and the compiler's register / spill figures, carried like `traffic` from a committed profile of this
+        # command (profiles/counters.json, tools/make_counters.py; names its commit)
+        counters = {}
+        cpath = os.path.join(ROOT, "profiles", "counters.json")
+        if os.path.exists(cpath) and args.workload == WORKLOAD:
+            try:
+                cj = json.load(open(cpath))
+                counters = {"valu_util": cj.get("valu_util"), "wave_active_frac": cj.get("wave_active_frac"),
+                            "spilled_sgprs": cj.get("resources", {}).get("spilled_sgprs"),
+                            "spilled_vgprs": cj.get("resources", {}).get("spilled_vgprs"),
+                            "vgprs": cj.get("resources", {}).get("vgprs"), "waves_per_simd": cj.get("resources", {}).get("waves_per_simd"),
+                            "kernel_us_rocprof": cj.get("kernel_us_rocprof"),
+                            "counters_source": {"file": "profiles/counters.json", "commit": cj.get("commit")}}
+            except Exception:
+                counters = {}
         out = {
             "metric": "mask-render fwd+bwd frames/sec, xArm7 50k-tri @1280x720x8-view" if args.workload == WORKLOAD else f"mask-render fwd+bwd frames/sec, {args.workload}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,6 +370,9 @@ def main():
                        # touches is a cached constant -- an exact algebraic saving (64-bit fixed-point sums, bit-identical
                        # to streaming the whole image every step), not skipped work
                        "ref_sums": "bound once" if tr.fast is not None else "n/a",
+                       # the timed launch form writes no mask image (mask = NULL; loss, gradient and Adam bit-identical to the
+                       # form that does): `with_mask_ms_per_step` below times the same chain writing rendered_masks every step
+                       "mask_output": False if tr.fast is not None else True,
                        "step": "torch autograd" if args.eager else ("HIP launch chain" + (", hipGraph replay" if used_graph else "")),
                        "parallelism": (f"dp{world} over views, one 8-float all-reduce/step ("
                                        + ("ncclAllReduce on the chain's stream, library-owned RCCL communicator"
@@ -308,8 +389,14 @@ def main():
                          # real HBM rate of the whole step: counter bytes / driver-timed step (next to the algorithmic one)
                          "hbm_actual_step": round(traffic / (elapsed / args.steps) / 1e9, 2) if traffic else None,
                          "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": round(tile_ms, 5),
-                         "stage_ms": {k: round(v / max(ncalls, 1), 5) for k, v in stage_ms.items() if not k.startswith("unused")}},
+                         "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}},
         }
+        out["roofline"].update(counters)
+        if with_mask_ms is not None:
+            out["with_mask_ms_per_step"] = round(with_mask_ms, 4)
+            out["with_mask_value"] = round(p["n_views"] / (with_mask_ms * 1e-3), 1)
+        if side is not None:
+            out["side"] = side
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms
             out["allreduce_8float_us"] = round(allreduce_us, 2)

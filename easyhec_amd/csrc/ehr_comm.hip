@@ -26,12 +26,19 @@ static RcclApi g_rccl;
 
 static int rccl_load() {
     if (g_rccl.lib) return EHR_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // First the copy the host process already holds (PyTorch bundles its own librccl.so: a second RCCL beside it would
+    // set up the GPU's transports twice), found with RTLD_NOLOAD; only then a fresh load.
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
     for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
         if (h) break;
     }
+    if (!h)
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
     if (!h) return fail(EHR_ERR_INVALID, "RCCL not found (librccl.so): %s", dlerror());
     RcclApi a;
     a.lib = h;
@@ -74,6 +81,10 @@ int ehr_comm_init(ehr_ctx* ctx, const void* id128, int nranks, int rank) {
     int rc = rccl_load();
     if (rc) return rc;
     if (ctx->comm) {
+        if (ctx->gexec) {  // a captured data-parallel step holds the old communicator in its all-reduce node
+            EHR_HIP(hipGraphExecDestroy(ctx->gexec));
+            ctx->gexec = nullptr;
+        }
         EHR_NCCL(g_rccl.CommDestroy((ncclComm_t)ctx->comm));
         ctx->comm = nullptr;
     }
@@ -102,6 +113,10 @@ int ehr_comm_destroy(ehr_ctx* ctx) {
     if (!ctx || !ctx->comm) return EHR_OK;
     ncclComm_t c = (ncclComm_t)ctx->comm;
     ctx->comm = nullptr;
+    if (ctx->gexec) {
+        (void)hipGraphExecDestroy(ctx->gexec);
+        ctx->gexec = nullptr;
+    }
     EHR_NCCL(g_rccl.CommDestroy(c));
     return EHR_OK;
 }

@@ -116,12 +116,19 @@ int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
 
 int ehr_fused_bind_ref(ehr_ctx* ctx, const float* ref, void* stream) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_fused_bind_ref: ctx is NULL");
+    if (ctx->capturing) return fail(EHR_ERR_INVALID, "ehr_fused_bind_ref: not inside a graph capture");
+    // A captured chain has the bound-reference form (and the cached sums' pointers) baked into its kernel arguments: binding,
+    // re-binding or unbinding under it would make its replays use stale sums.  The graph goes; ehr_graph_launch then fails
+    // loudly ("no instantiated graph") until the chain is captured again.
+    if (ctx->gexec) {
+        EHR_HIP(hipGraphExecDestroy(ctx->gexec));
+        ctx->gexec = nullptr;
+    }
     if (!ref) {  // unbind
         ctx->vb_ref = nullptr;
         return EHR_OK;
     }
     if (ctx->pB == 0) return fail(EHR_ERR_INVALID, "ehr_fused_bind_ref: call ehr_fused_plan first");
-    if (ctx->capturing) return fail(EHR_ERR_INVALID, "ehr_fused_bind_ref: not inside a graph capture");
     return vbuf_bind_ref(ctx, ref, (hipStream_t)stream);
 }
 

@@ -41,6 +41,10 @@ struct Scratch {
 
 struct StepHead;
 struct StepTail;
+struct RasterShape {  // what makes two drop-in rasterize calls "the same frame again" for the sync-free size read-back
+    int B, V, T, H, W, ranged;
+    bool operator==(const RasterShape& o) const { return B == o.B && V == o.V && T == o.T && H == o.H && W == o.W && ranged == o.ranged; }
+};
 #define VB_LOSS_SLOTS 32          // partial frame-loss sums per view (spreads same-address atomics)
 #define VB_LOSS_STRIDE 16         // i64 between two of them: one 128-byte line each (atomics on one line serialise)
 #define VB_MAX_UNITS 512          // views x links one context plans for
@@ -68,7 +72,7 @@ struct ehr_ctx {
     int* host_pinned = nullptr;  // 8 ints, pinned: size read-backs of the scoring op ([0..5]) and the drop-in rasterize ([6..7])
     hipEvent_t ev_size[2] = {nullptr, nullptr};  // drop-in rasterize: "the size in host_pinned[k] has arrived"
     bool size_valid[2] = {false, false};
-    long long size_key[2] = {0, 0};              // (B, T, H, W) of the call that produced it
+    ehr::RasterShape size_shape[2] = {};         // shape of the call that produced it
     int size_slot = 0;
     // fused path plan
     int pB = 0, pL = 0, pV = 0, pT = 0, pH = 0, pW = 0;

@@ -61,26 +61,43 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
     const int tx = tile % g.ntx, ty = tile / g.ntx;
     const int rx0 = tx * EHR_TILE_W, ry0 = ty * EHR_TILE_H;
     const int tid = threadIdx.x;
-    if (meta[EHR_META_TOTAL] > entries_cap) {
-        // the queues did not fit (the host skipped its size read-back because the previous frames needed far less): the
-        // image is NaN, never a silently incomplete one; the next call sees the size and grows the storage
-        const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
-        const int ix = rx0 + lx, iy = ry0 + ly;
-        if (ix < g.W && iy < g.H) {
-            const float nanv = __int_as_float(0x7fc00000);
-            const size_t pix = ((size_t)b * g.H + iy) * g.W + ix;
-            rast[pix] = make_float4(nanv, nanv, nanv, nanv);
-            if (WITH_DB) rast_db[pix] = make_float4(nanv, nanv, nanv, nanv);
-        }
-        return;
-    }
     key[tid] = ~0ull;
     const int kidx = b * g.nt + tile;
-    int n = counts[kidx];
+    const int n = counts[kidx];
     const int off = offsets[kidx];
-    if (off + n > entries_cap) n = max(entries_cap - off, 0);
     __syncthreads();
-    if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, &wscratch, nullptr, RoundZero());
+    if (off + n <= entries_cap) {
+        if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, &wscratch, nullptr, RoundZero());
+    } else {
+        // This tile's queue did not fit the queue storage (the host skipped its size read-back because the previous frames of
+        // this shape needed far less, or the call is being replayed from a captured graph): the tile finds its triangles
+        // itself -- every triangle of the image is tested against the tile, 256 at a time, with the binning pass's own test,
+        // and the hits go through the same rasterizer from a list in LDS.  The depth test is order independent, so the
+        // result is the one the queue would have given, bit for bit; only slower (the host grows the storage as soon as it
+        // sees the size: never an incomplete or NaN image).
+        __shared__ int4 bf_ent[EHR_TILE_THREADS];
+        __shared__ int bf_n;
+        int t0, t1;
+        src.range(b, t0, t1);
+        for (int base = t0; base < t1; base += EHR_TILE_THREADS) {
+            if (tid == 0) bf_n = 0;
+            __syncthreads();
+            const int t = base + tid;
+            int v0 = 0, v1 = 0, v2 = 0, link = 0;
+            if (t < t1 && src.indices(t, v0, v1, v2, link)) {
+                const float4* pv = src.verts(b);
+                const float4 p[3] = {pv[v0], pv[v1], pv[v2]};
+                int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+                bool slow = false;
+                if (tri_tile_range<0>(p, g.W, g.H, tx0, tx1, ty0, ty1, slow) && tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1)
+                    bf_ent[atomicAdd(&bf_n, 1)] = make_int4(t, v0, v1, v2);
+            }
+            __syncthreads();
+            const int m = bf_n;
+            if (m > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, bf_ent, m, g.W, g.H, rx0, ry0, key, &wscratch, nullptr, RoundZero());
+            __syncthreads();
+        }
+    }
     __syncthreads();
     // shade: one thread per pixel
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
@@ -283,7 +300,9 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + EHR_META_INTS + (ranges_host ? 2 * (size_t)B : 0)) * sizeof(int)))) return rc;
     if ((rc = ctx->offsets.reserve((size_t)nkeys * sizeof(int)))) return rc;
     if (ctx->entries_cap == 0) {
-        size_t want = std::max((size_t)1 << 20, (size_t)B * (size_t)std::max(T, 1) * 2);
+        // (EHR_RASTER_MIN_ENTRIES: test hook for the undersized-storage path; default floor 1 M entries = 16 MB)
+        static const size_t floor_entries = getenv("EHR_RASTER_MIN_ENTRIES") ? (size_t)std::max(1, atoi(getenv("EHR_RASTER_MIN_ENTRIES"))) : (size_t)1 << 20;
+        size_t want = std::max(floor_entries, getenv("EHR_RASTER_MIN_ENTRIES") ? (size_t)0 : (size_t)B * (size_t)std::max(T, 1) * 2);
         if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
         ctx->entries_cap = want;
     }
@@ -321,33 +340,40 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     // Size read-back.  The queue storage must hold `total` entries, known only on the device.  Steady state (a solve
     // renders the same meshes again and again): the total travels to pinned host memory asynchronously and the NEXT call
     // looks at it -- if the last completed call of this shape needed at most half of the storage, this call does not
-    // wait (a frame that suddenly needs more than twice as much comes out as NaN, see raster_tile_kernel, and the call
-    // after it grows the storage).  Otherwise (first calls, new shape, tight storage) synchronise once and grow, like
-    // nvdiffrast's own rasterizer.
-    const int slot = ctx->size_slot ^= 1;
-    if (!ctx->ev_size[0]) {
-        EHR_HIP(hipEventCreateWithFlags(&ctx->ev_size[0], hipEventDisableTiming));
-        EHR_HIP(hipEventCreateWithFlags(&ctx->ev_size[1], hipEventDisableTiming));
-    }
-    const long long shape_key = ((long long)B << 48) ^ ((long long)T << 24) ^ ((long long)H << 12) ^ W;
-    bool wait = true;
-    {
-        const int prev = slot ^ 1;
-        if (ctx->size_valid[prev] && ctx->size_key[prev] == shape_key && hipEventQuery(ctx->ev_size[prev]) == hipSuccess &&
-            2 * (size_t)ctx->host_pinned[6 + prev] + 1024 <= ctx->entries_cap)
-            wait = false;
-    }
-    EHR_HIP(hipMemcpyAsync(ctx->host_pinned + 6 + slot, meta, sizeof(int), hipMemcpyDeviceToHost, stream));
-    EHR_HIP(hipEventRecord(ctx->ev_size[slot], stream));
-    ctx->size_valid[slot] = true;
-    ctx->size_key[slot] = shape_key;
-    if (wait) {
-        EHR_HIP(hipStreamSynchronize(stream));
-        size_t total = (size_t)ctx->host_pinned[6 + slot];
-        if (2 * total + 1024 > ctx->entries_cap) {
-            size_t want = 2 * total + total / 2 + 4096;
-            if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
-            ctx->entries_cap = want;
+    // wait.  A frame that suddenly needs more than the storage holds is still rendered exactly: the tiles whose queues
+    // did not fit find their triangles themselves (raster_tile_kernel's fallback; slower, never incomplete), and the
+    // call after it sees the size and grows the storage.  Otherwise (first calls, new shape, tight storage) synchronise
+    // once and grow, like nvdiffrast's own rasterizer.  Inside a stream capture (a torch.cuda.graphs capture of a whole
+    // solver step) nothing on the host may wait or reallocate: the call is recorded with the storage as it is.
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    if (!capturing) {
+        const int slot = ctx->size_slot ^= 1;
+        if (!ctx->ev_size[0]) {
+            EHR_HIP(hipEventCreateWithFlags(&ctx->ev_size[0], hipEventDisableTiming));
+            EHR_HIP(hipEventCreateWithFlags(&ctx->ev_size[1], hipEventDisableTiming));
+        }
+        const RasterShape shape = {B, V, T, H, W, ranges_host ? 1 : 0};
+        bool wait = true;
+        {
+            const int prev = slot ^ 1;
+            if (ctx->size_valid[prev] && ctx->size_shape[prev] == shape && hipEventQuery(ctx->ev_size[prev]) == hipSuccess &&
+                2 * (size_t)ctx->host_pinned[6 + prev] + 1024 <= ctx->entries_cap)
+                wait = false;
+        }
+        EHR_HIP(hipMemcpyAsync(ctx->host_pinned + 6 + slot, meta, sizeof(int), hipMemcpyDeviceToHost, stream));
+        EHR_HIP(hipEventRecord(ctx->ev_size[slot], stream));
+        ctx->size_valid[slot] = true;
+        ctx->size_shape[slot] = shape;
+        if (wait) {
+            EHR_HIP(hipStreamSynchronize(stream));
+            size_t total = (size_t)ctx->host_pinned[6 + slot];
+            if (2 * total + 1024 > ctx->entries_cap) {
+                size_t want = 2 * total + total / 2 + 4096;
+                if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
+                ctx->entries_cap = want;
+            }
         }
     }
     int4* entries = (int4*)ctx->entries.ptr;

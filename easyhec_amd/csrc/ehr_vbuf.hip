@@ -2169,8 +2169,10 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
 #endif
 }
 
-// Content hash of the scoring op's mesh arrays (position-weighted sum of their 32-bit words): the cluster index holds
-// copies of the vertex positions, so a mesh edited in place under the same pointers must rebuild it.
+// Content hash of the scoring op's mesh arrays: the cluster index holds copies of the vertex positions, so a mesh edited
+// in place under the same pointers must rebuild it.  Every (word, position) pair goes through a 64-bit finaliser
+// (murmur3's fmix64) before it is summed: a sum of the raw words, however weighted, is linear, and two compensating
+// edits would cancel; the sum of the mixed values is still order independent.
 __global__ void __launch_bounds__(256)
 vb_hash_kernel(const unsigned* __restrict__ a, size_t na, const unsigned* __restrict__ b, size_t nb, const unsigned* __restrict__ c,
                size_t nc, unsigned long long* __restrict__ out) {
@@ -2178,7 +2180,13 @@ vb_hash_kernel(const unsigned* __restrict__ a, size_t na, const unsigned* __rest
     const size_t n = na + nb + nc;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const unsigned w = i < na ? a[i] : (i < na + nb ? b[i - na] : c[i - na - nb]);
-        h += ((unsigned long long)w + 0x9e3779b97f4a7c15ull) * (2ull * i + 1ull);
+        unsigned long long x = (unsigned long long)w + 0x9e3779b97f4a7c15ull * ((unsigned long long)i + 1ull);
+        x ^= x >> 33;
+        x *= 0xff51afd7ed558ccdull;
+        x ^= x >> 33;
+        x *= 0xc4ceb9fe1a85ec53ull;
+        x ^= x >> 33;
+        h += x;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);

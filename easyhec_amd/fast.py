@@ -30,7 +30,9 @@ class FusedPoseStep:
         dev = model.dof.device
         self.dev = dev
         self.H, self.W = model.H, model.W
-        self.ref = batch["mask"].to(dev, torch.float32).contiguous()
+        # a private copy, always (``.to`` / ``.contiguous`` return the caller's own tensor when nothing has to change, and
+        # the sums cached by ``bind_ref`` below must not go stale under an in-place edit of ``batch["mask"]``)
+        self.ref = batch["mask"].to(dev, torch.float32).contiguous().clone()
         self.link_poses = batch["link_poses"].to(dev, torch.float32).contiguous()
         self.K = batch["K"][0].to(dev, torch.float32).contiguous()
         self.B, self.L = self.link_poses.shape[0], self.link_poses.shape[1]
@@ -45,7 +47,15 @@ class FusedPoseStep:
         # process group makes a single-rank communicator (the same launch sequence on one GPU).
         self.rccl = bool(rccl) if rccl is not None else (self.distributed and dist.get_backend(self.pg) == "nccl")
         if self.rccl:
-            self._init_comm()
+            try:
+                self._init_comm()
+            except RuntimeError as e:
+                if rccl:  # asked for explicitly: fail loudly
+                    raise
+                import sys
+                print(f"[easyhec_amd] library-owned RCCL exchange unavailable ({e}); using torch.distributed.all_reduce",
+                      file=sys.stderr)
+                self.rccl = False
         # optimiser state (torch.optim.Adam names): a fresh Adam (step 0, zero moments) unless load_state_dict restores
         # one -- like the reference's load_model path.  The row of ``history_ops`` the next step records its pose in is a
         # counter of its own (the reference's first all-zero row, rb_solver.py:50-51): it starts at the model's history
@@ -85,6 +95,16 @@ class FusedPoseStep:
             idbuf = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
         with torch.cuda.device(self.dev):
             _lib.check(lib.ehr_comm_init(self.glctx.handle, idbuf, world, rank), "ehr_comm_init")
+            # self-check before the solve depends on it: one all-reduce of a known vector on the new communicator must
+            # give what the process group gives (the N > 1 form of this exchange has never run on hardware in the build
+            # container; a mismatch here raises, and the default selection above falls back to torch.distributed)
+            probe = torch.full((8,), float(rank + 1), device=self.dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(lib.ehr_comm_allreduce(self.glctx.handle, _lib.ptr(probe), 8, stream), "ehr_comm_allreduce")
+            torch.cuda.synchronize()
+            want = world * (world + 1) / 2.0
+            if not bool((probe == want).all()):
+                raise RuntimeError(f"ehr_comm_allreduce self-check: got {probe.tolist()}, expected {want}")
 
     # -- one step -------------------------------------------------------------------------------------------------
     def _enqueue(self, want_mask, stream=None):

@@ -76,6 +76,26 @@ def test_ops_golden_fixture(env):
     assert np.abs(tp.grad.cpu().numpy()[0] - g["grad_pos"][0]).max() <= 1e-5 * np.abs(g["grad_pos"]).max()
 
 
+def test_rasterize_survives_a_frame_that_outgrows_the_queue_storage():
+    """the drop-in rasterizer skips its size read-back when the previous frames of the same shape
+    needed little; a frame that then needs more entries than the storage holds must still come out exact (the tiles whose
+    queues did not fit find their triangles themselves), never NaN or incomplete, and the storage grows afterwards."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env2 = dict(os.environ, EHR_RASTER_MIN_ENTRIES="64")
+    out = subprocess.run([sys.executable, os.path.join(here, "raster_growth_worker.py")], env=env2, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert len(res) == 7
+    for r in res:
+        assert r["rast_equal"] and r["db_equal"] and not r["nan"], r
+    assert res[4]["covered"] > 10 * res[0]["covered"]  # the zoomed frames really are much larger
+
+
 def test_range_mode_and_batches(env, oracle):
     dr, ctx, dev = env
     rng = np.random.default_rng(9)

@@ -1,0 +1,46 @@
+"""The ORACLE against real nvdiffrast outputs (tests/golden/nvdiffrast_*.npz, written on an NVIDIA box by
+tools/dump_nvdiffrast_golden.py).  No such file can be produced in the build container or on the AMD box (nvdiffrast is
+CUDA-only and not installed: SURVEY 8c), so until someone commits them this test is SKIPPED and parity stays
+"unpinned"; with them it is the pin: the oracle's rast / antialias / gradients vs nvdiffrast's on the committed inputs
+and on the adversarial cases (intra-link depth contention at silhouettes, sub-1/16-pixel slivers, edges through pixel
+centres)."""
+import numpy as np
+import pytest
+
+import nvdiffrast_golden_common as C
+
+
+def test_oracle_matches_nvdiffrast_dump(oracle, capsys):
+    fs = C.files()
+    if not fs:
+        pytest.skip("no tests/golden/nvdiffrast_*.npz: run tools/dump_nvdiffrast_golden.py on an NVIDIA box and commit its output")
+    lines, bad = [], []
+    for f in fs:
+        g = np.load(f, allow_pickle=False)
+        H, W = int(g["H"]), int(g["W"])
+        name = f.split("/")[-1]
+        if str(g["kind"]) == "ops":
+            pos, tri, attr = g["pos"], g["tri"], g["attr"]
+            rast, _ = oracle.rasterize(pos[None], tri, [H, W])
+            col = oracle.interpolate(attr, rast, tri)
+            aa = oracle.antialias(col, rast, pos[None], tri)
+            gc, gp = oracle.antialias_grad(col, rast, pos[None], tri, g["dy"])
+            _, gr = oracle.interpolate_grad(attr, rast, tri, gc)
+            gp = gp + oracle.rasterize_grad(pos[None], tri, rast, gr)
+            line, ok = C.score_ops(name, g, rast, aa, gp)
+        else:
+            links = C.load_links(str(g["robot"]))
+            verts = np.concatenate([v for v, _ in links]).astype(np.float32)
+            voff = np.cumsum([0] + [v.shape[0] for v, _ in links]).astype(np.int32)
+            toff = np.cumsum([0] + [f_.shape[0] for _, f_ in links]).astype(np.int32)
+            tris = np.concatenate([f_ + voff[i] for i, (_, f_) in enumerate(links)]).astype(np.int32)
+            B = g["mvp"].shape[0]
+            ref = np.unpackbits(g["ref"])[:B * H * W].reshape(B, H, W).astype(np.float32)
+            mask, loss, gm = oracle.render_mask_loss(verts, tris, toff, voff, g["mvp"], ref)
+            line, ok = C.score_fused(name, g, mask, loss, gm)
+        lines.append(("ok   " if ok else "DIFF ") + line)
+        if not ok:
+            bad.append(name)
+    with capsys.disabled():
+        print("\n[oracle vs nvdiffrast]\n" + "\n".join(lines))
+    assert not bad, "oracle differs from nvdiffrast beyond the stated tolerances on: " + ", ".join(bad)
