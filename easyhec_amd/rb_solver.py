@@ -47,6 +47,7 @@ class RBSolver(nn.Module):
         # (one sync) whenever it may be stale: after load_state_dict and after steps of the HIP launch chain, which
         # writes the rows itself (None = unknown).
         self._hist_n = 0
+        self._hist_dev = None  # device-side cursor (a [1] int64 tensor) while the step is being replayed from a graph
         self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_hist_n", None))
 
     def history_cursor(self):
@@ -96,10 +97,16 @@ class RBSolver(nn.Module):
     def forward(self, dps, with_outputs=True):
         assert dps.get("global_step", 0) == 0
         renderer = self._ensure_renderer()
-        put_id = self.history_cursor()  # rb_solver.py:50-51 without the per-step .item() sync
-        if put_id < self.history_ops.shape[0]:
-            self.history_ops[put_id] = self.dof.detach()
-            self._hist_n = put_id + 1
+        if self._hist_dev is not None:
+            # captured step (RBSolverTrainer(graph=True)): a host counter would be frozen into the graph, so the cursor
+            # lives on the device and every replay records its pose in the next row (the last row absorbs an overrun)
+            self.history_ops.index_copy_(0, self._hist_dev, self.dof.detach()[None])
+            self._hist_dev.add_(1).clamp_(max=self.history_ops.shape[0] - 1)
+        else:
+            put_id = self.history_cursor()  # rb_solver.py:50-51 without the per-step .item() sync
+            if put_id < self.history_ops.shape[0]:
+                self.history_ops[put_id] = self.dof.detach()
+                self._hist_n = put_id + 1
         Tc_c2b = self.Tc_c2b()
         masks_ref = dps["mask"]
         link_poses = dps["link_poses"]

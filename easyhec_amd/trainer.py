@@ -18,7 +18,7 @@ from .se3 import se3_log_map
 __all__ = ["RBSolverTrainer", "make_optimizer", "shard_views"]
 
 
-def make_optimizer(cfg, model):
+def make_optimizer(cfg, model, capturable=False):
     """solver/build.py:12-29: one param group per parameter, weight decay on everything not named *bias*."""
     params = []
     for key, value in model.named_parameters():
@@ -26,7 +26,7 @@ def make_optimizer(cfg, model):
             continue
         params += [{"params": [value], "lr": cfg.solver.max_lr, "weight_decay": cfg.solver.weight_decay}]
     if cfg.solver.optimizer == "Adam":
-        return torch.optim.Adam(params, cfg.solver.max_lr)
+        return torch.optim.Adam(params, cfg.solver.max_lr, capturable=capturable)
     if cfg.solver.optimizer == "SGD":
         return torch.optim.SGD(params, cfg.solver.max_lr, momentum=0.9)
     raise NotImplementedError(cfg.solver.optimizer)
@@ -46,17 +46,22 @@ class RBSolverTrainer:
         """batch: dict of this rank's device tensors (mask, link_poses, K, Tc_c2b) -- the single batch the reference
         builds with batch_size=100 >= #frames (configs/xarm7/example.yaml:45).
         fast: run the step as the fixed HIP launch chain of :class:`easyhec_amd.fast.FusedPoseStep` (same arithmetic,
-        no autograd / torch glue); graph: additionally replay it as a captured hipGraph."""
+        no autograd / torch glue); graph: additionally replay it as a captured hipGraph (fast) or, without ``fast``, record
+        the torch-autograd step -- the three drop-in ops per (view, link), backward, torch Adam -- in a
+        ``torch.cuda.CUDAGraph`` and replay that (see :meth:`_capture_autograd_step`)."""
         self.cfg = cfg
         self.model = model
         self.batch = dict(batch)
         self.batch.setdefault("global_step", 0)
-        self.optimizer = make_optimizer(cfg, model)
+        self.optimizer = make_optimizer(cfg, model, capturable=bool(graph and not fast))
         self.global_steps = 0
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
         self.last_loss = None
         self.fast = None
+        self._cuda_graph = None
+        if graph and not fast:
+            self._capture_autograd_step()
         if fast:
             from .fast import FusedPoseStep
             if cfg.solver.do_grad_clip or cfg.solver.optimizer != "Adam":
@@ -70,8 +75,65 @@ class RBSolverTrainer:
             if not torch.allclose(gt.cpu(), torch.eye(4)):  # decided once, not per step (rb_solver.py:80)
                 self.batch["gt_dof6"] = se3_log_map(gt[None].permute(0, 2, 1), backend="opencv")[0]
 
+    def _capture_autograd_step(self):
+        """graph=True without fast: the reference-shaped step -- RBSolver.forward through the three drop-in ops (or the
+        fused op) under torch autograd, loss.backward(), torch.optim.Adam(capturable=True).step() -- recorded once into
+        a ``torch.cuda.CUDAGraph`` and replayed: ~1 500 Python-driven launches per step become one graph launch.  The
+        ops allocate their outputs from the graph's private pool and never synchronise (the drop-in rasterizer records
+        the call with its queue storage as the warm-up steps sized it; a frame that outgrows it is still exact, only
+        slower).  Single process only; the pose history cursor moves to the device (RBSolver._hist_dev)."""
+        if self.distributed:
+            raise RuntimeError("graph capture of the autograd step is single-process only")
+        m = self.model
+        dev = m.dof.device
+        if "gt_dof6" not in self.batch and "Tc_c2b" in self.batch:
+            gt = self.batch["Tc_c2b"][0]
+            if not torch.allclose(gt.cpu(), torch.eye(4)):
+                self.batch["gt_dof6"] = se3_log_map(gt[None].permute(0, 2, 1), backend="opencv")[0]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self._static_loss = torch.zeros((), device=dev)
+        snap_dof = m.dof.detach().clone()
+        snap_hist = m.history_ops.clone()
+        hist_n = m.history_cursor()
+        m._hist_dev = torch.full((1,), hist_n, dtype=torch.int64, device=dev)
+        with torch.cuda.stream(side):
+            for _ in range(3):  # warm-up: sizes every scratch buffer, builds the caches, initialises the Adam state
+                self.optimizer.zero_grad(set_to_none=False)
+                _, ld = m(self.batch, with_outputs=False)
+                sum(ld.values()).backward()
+                self.optimizer.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        # the warm-up steps must not count: parameters, Adam moments, step counter and history go back
+        with torch.no_grad():
+            m.dof.copy_(snap_dof)
+            m.history_ops.copy_(snap_hist)
+            m._hist_dev.fill_(hist_n)
+            for st in self.optimizer.state.values():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        g = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=False)
+        with torch.cuda.graph(g):
+            self.optimizer.zero_grad(set_to_none=False)
+            _, ld = m(self.batch, with_outputs=False)
+            loss = sum(ld.values())
+            loss.backward()
+            self.optimizer.step()
+            self._static_loss.copy_(loss.detach())
+        # the capture pass itself does not execute: state is still the snapshot's
+        self._cuda_graph = g
+
     # one optimisation step == one "epoch" of the reference (trainer/rbsolver.py:29-43)
     def step(self, with_outputs=False):
+        if self._cuda_graph is not None and not with_outputs:
+            self._cuda_graph.replay()
+            self.model._hist_n = None  # the device cursor moved; the host one is stale
+            self.global_steps += 1
+            self.last_loss = self._static_loss
+            return {}, self._static_loss
         if self.fast is not None:
             # ONE optimiser state whatever is asked for: the launch chain also produces the rendered masks
             loss_value = self.fast.step(want_mask=with_outputs)[0]

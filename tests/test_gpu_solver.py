@@ -239,3 +239,28 @@ def test_online_loop_solver_plus_explorer(xarm7):
     assert len({tuple(np.round(q, 6)) for q in asked}) == 4          # the explorer moved the robot every round
     emm, edeg = pose_error(Tc_gt, Tc)
     assert emm <= 1.0 and edeg <= 0.1, (emm, edeg)
+
+
+def test_graph_replay_of_the_three_op_step_equals_eager(xarm7):
+    """the reference-shaped step (three drop-in ops per (view, link) under torch autograd + torch
+    Adam) recorded in a torch.cuda.CUDAGraph replays to the same trajectory as the eager step: same op sequence on the same
+    inputs; the antialias gradient uses float atomics, so `dof` is compared within float-reassociation noise, the history
+    rows and the loss curve likewise."""
+    from easyhec_amd.trainer import RBSolverTrainer
+    from test_gpu_fast import problem
+    cfg, make, batch = problem(xarm7, 2, 120, 160, 0.125)
+    cfg.model.rbsolver.use_fused = False
+    ma, mb = make(), make()
+    ta = RBSolverTrainer(cfg, ma, batch)
+    tb = RBSolverTrainer(cfg, mb, batch, graph=True)
+    assert tb._cuda_graph is not None
+    la, lb = [], []
+    for _ in range(8):
+        la.append(float(ta.step()[1]))
+        lb.append(float(tb.step()[1]))
+    torch.cuda.synchronize()
+    assert np.allclose(la, lb, rtol=1e-4), (la, lb)
+    assert la[-1] < la[0]
+    assert (ma.dof.detach() - mb.dof.detach()).abs().max() <= 1e-5
+    assert mb.history_cursor() == 8 and ma.history_cursor() == 8
+    assert (ma.history_ops[:8] - mb.history_ops[:8]).abs().max() <= 1e-5

@@ -23,6 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--graph", action="store_true", help="record the autograd step in a torch.cuda.CUDAGraph and replay it "
+                    "(RBSolverTrainer(graph=True)): the ~1 500 launches of the three-op step at GPU speed")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     wl = WORKLOADS["xarm7_1280x720_8view"]
@@ -39,7 +41,7 @@ def main():
         model = RBSolver(cfg, meshes=rb.meshes).to(dev)
         batch = {"mask": torch.zeros((a.views, H, W), device=dev), "link_poses": torch.tensor(lp, device=dev),
                  "K": torch.tensor(K, dtype=torch.float32, device=dev)[None].repeat(a.views, 1, 1)}
-        tr = RBSolverTrainer(cfg, model, batch)
+        tr = RBSolverTrainer(cfg, model, batch, graph=a.graph)
         for _ in range(3):
             tr.step()
         torch.cuda.synchronize()
@@ -48,8 +50,8 @@ def main():
             tr.step()
         torch.cuda.synchronize()
         dt = (time.time() - t0) / a.steps
-        out["fused_autograd" if fusedflag else "three_ops"] = {"ms_per_step": round(dt * 1e3, 3),
-                                                              "frames_per_s": round(a.views / dt, 1)}
+        out[("fused_autograd" if fusedflag else "three_ops") + ("_graph" if a.graph else "")] = {
+            "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(a.views / dt, 1), "loss": round(float(tr.last_loss), 3)}
     print(json.dumps(out))
 
 
