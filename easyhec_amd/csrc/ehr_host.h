@@ -39,6 +39,12 @@ struct Scratch {
     unsigned long long moves = 0;  // bumped whenever this buffer moves: captured graphs hold raw pointers
 };
 
+// Device fills / copies of the drop-in ops as plain kernels (ehr_raster.hip): a hipMemsetAsync / hipMemcpyAsync recorded
+// inside a torch.cuda.graphs capture of a solver step becomes a memset / memcpy graph node, and a graph holding such
+// nodes faulted on its SECOND replay on this stack (ROCm 7.0 / MI355X; kernels only: replays fine).
+int zero_words(void* dst, size_t nwords, hipStream_t stream);
+int copy_words(void* dst, const void* src, size_t nwords, hipStream_t stream);
+
 struct StepHead;
 struct StepTail;
 struct RasterShape {  // what makes two drop-in rasterize calls "the same frame again" for the sync-free size read-back

@@ -360,9 +360,9 @@ int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, c
     hipStream_t stream = (hipStream_t)stream_;
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
-    if (out != color)
-        EHR_HIP(hipMemcpyAsync(out, color, n * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    EHR_HIP(hipMemsetAsync(work, 0, sizeof(int4), stream));
+    int rc;
+    if (out != color && (rc = copy_words(out, color, n * C, stream))) return rc;
+    if ((rc = zero_words(work, 4, stream))) return rc;
     aa_discover_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)rast, B, H, W, (int4*)work);
     EHR_LAUNCH_CHECK();
     aa_mesh_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp, range_mode, V, T,
@@ -379,7 +379,8 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
     hipStream_t stream = (hipStream_t)stream_;
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
-    EHR_HIP(hipMemcpyAsync(grad_color, dy, n * C * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    int rc;
+    if ((rc = copy_words(grad_color, dy, n * C, stream))) return rc;
     aa_grad_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, dy, (const int4*)work,
                                              range_mode, V, T, H, W, C, grad_color, grad_pos);
     EHR_LAUNCH_CHECK();

@@ -43,6 +43,34 @@ void Scratch::release() {
     cap = 0;
 }
 
+static __global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static __global__ void __launch_bounds__(256) copy_words_kernel(unsigned* __restrict__ d, const unsigned* __restrict__ s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+static __global__ void __launch_bounds__(256) copy_words4_kernel(uint4* __restrict__ d, const uint4* __restrict__ s, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+int zero_words(void* dst, size_t nwords, hipStream_t stream) {
+    if (nwords == 0) return EHR_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((nwords + 255) / 256, 2048);
+    zero_words_kernel<<<grid, 256, 0, stream>>>((unsigned*)dst, nwords);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+int copy_words(void* dst, const void* src, size_t nwords, hipStream_t stream) {
+    if (nwords == 0) return EHR_OK;
+    if ((nwords & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
+        const size_t n4 = nwords >> 2;
+        copy_words4_kernel<<<(unsigned)std::min<size_t>((n4 + 255) / 256, 4096), 256, 0, stream>>>((uint4*)dst, (const uint4*)src, n4);
+    } else {
+        copy_words_kernel<<<(unsigned)std::min<size_t>((nwords + 255) / 256, 4096), 256, 0, stream>>>((unsigned*)dst, (const unsigned*)src, nwords);
+    }
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
 // ---- drop-in rasterize tile kernel -------------------------------------------------------------------------------
 
 // One workgroup per (image, tile).  LDS: 256 x 8-byte keys + the waves' raster scratch.  Writes rast (and rast_db)
@@ -329,7 +357,7 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     src.L = 1;
     src.image_stride = ranges_host ? 0 : V;
 
-    EHR_HIP(hipMemsetAsync(counts, 0, ((size_t)2 * nkeys + 8) * sizeof(int), stream));
+    if ((rc = zero_words(counts, (size_t)2 * nkeys + 8, stream))) return rc;
     dim3 bgrid((tmax + 255) / 256, B);
     if (tmax > 0) {
         bin_kernel<0, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta, nullptr);

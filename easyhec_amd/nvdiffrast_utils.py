@@ -35,4 +35,6 @@ def transform_pos(mtx, pos):
 def opencv2blender(device=None, dtype=torch.float32):
     """diag(1,-1,-1,1): OpenCV camera (x right, y down, z forward) -> GL camera
     (nvdiffrast_renderer.py:18-22; the matrix is its own inverse)."""
-    return torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], dtype=dtype, device=device))
+    d = torch.ones(4, dtype=dtype, device=device)  # (built on the device: a host list is a pageable copy, which a stream
+    d[1:3] = -1.0                                  #  capture rejects)
+    return torch.diag(d)

@@ -52,7 +52,8 @@ def se3_exp_map(log_transform, eps=1e-4):
     V = _se3_V_matrix(log_rotation, log_rotation_hat, log_rotation_hat_square, rotation_angles, eps=eps)
     T = torch.bmm(V, log_translation[:, :, None])[:, :, 0]
     top = torch.cat([R, T[:, :, None]], dim=2)
-    bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=log_transform.dtype, device=log_transform.device)
+    # (generated on the device: a host list would be a pageable host-to-device copy, which a stream capture rejects)
+    bottom = torch.eye(4, dtype=log_transform.dtype, device=log_transform.device)[3]
     transform = torch.cat([top, bottom[None, None, :].expand(N, 1, 4)], dim=1)
     return transform.permute(0, 2, 1)
 
