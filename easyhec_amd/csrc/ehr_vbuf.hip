@@ -49,20 +49,19 @@ constexpr int VB_RH = EHR_TILE_H + 2;
 constexpr int VB_RN = VB_RW * VB_RH;   // 340
 constexpr int VB_WORDS = (VB_RN + 63) / 64;  // 6 coverage words
 constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min y, max x, max y, padding to a 64-byte line
-// Scheduling hint (results never depend on it): jobs that were long in the PREVIOUS step (poses move little between
-// optimisation steps) are started FIRST in this one, and the longest of them are cut into PIECES -- K independent
-// single-wave jobs that each take every K-th candidate cluster of the job into a coverage / depth buffer of their own; the
-// piece that finishes last merges the others' buffers into its own (coverage: OR; depth/id keys: minimum) and publishes
-// the job.  Cost = 4-pixel units walked + 3 per span row + 256 per rasterizer round: a tile of 130 long thin triangles
-// (7000 units) keeps one wave busy for 60 us, one of 380 small ones for 25.
-#define VB_LONG_T_DEFAULT 1200         // cost from which a job goes on the list (started first, at raised issue priority)
-#define VB_PIECE_T_DEFAULT 900         // a listed job of cost c is cut into ceil(c / this) pieces (<= VB_PIECE_MAX)
-constexpr int VB_HINT_CAP = 2048;     // listed jobs remembered per step and class (the kernel uses at most a grid's worth)
-constexpr int VB_PIECE_WORDS = 352;   // u64 per piece buffer: depth/id keys of the region [340] | coverage rows [10] | pad
-// Issue priority (s_setprio) of the waves on listed jobs: what the kernel ends on is a long job started first that runs
-// beside three siblings per SIMD for most of its life.
+#define VB_HEAVY_T_DEFAULT 2500        // cost (4-pixel units walked + 256 per rasterizer round) from which a job counts as
+                                      // heavy: next step a whole workgroup takes it.  Units, not triangles: a tile of 130 long
+                                      // thin triangles (7000 units) keeps a wave busy for 60 us, one of 380 small ones for 25
+constexpr int VB_HEAVY_CAP = 4096;    // heavy jobs remembered per step
+constexpr int VB_MED_CAP = 2048;      // long single-wave jobs remembered per step (they are started first)
+#define VB_MED_T_DEFAULT 1500          // cost from which a single-wave job counts as long
+// Issue priority (s_setprio) of the waves on the jobs the kernel ends on: a long job started first runs beside three
+// siblings per SIMD for most of its life (41 us instead of 30); with priority 48.5 instead of 50.0 us at 8 views.
 #ifndef VB_PRIO_LONG
 #define VB_PRIO_LONG 3
+#endif
+#ifndef VB_PRIO_HEAVY
+#define VB_PRIO_HEAVY 2
 #endif
 constexpr int VB_JOB_ITEMS = 64;       // blended pairs kept in LDS per tile; the rest spills to a global pool
 constexpr int VB_SPILL_BLOCK = 2048;   // items per spill allocation (one per overflowing tile)
@@ -131,30 +130,17 @@ __device__ __forceinline__ int vb_mbcnt(u64 m) {  // set bits of m below this la
 
 // ---- stage 1: vertices, screen boxes of triangles / clusters / links ---------------------------------------------
 
-// The hint's storage (ctx scratch, carried from step to step), one base pointer.  Everything a step consumes was written
-// by the job kernel of the step before (the wave that finishes a long job enters it in the list of its class and stamps
-// it: no pass over the lists anywhere); two copies by generation parity, the one being written and the one being consumed:
-//   gen   [64]                 0 generation (one per call); 32 + 2 p (64-bit, a line of their own): the class counters of copy p:
-//                              workgroup slots of the jobs shared by 4 or 8 | jobs shared by 2 << 20 | unshared long jobs << 40
-//   list  [2][3][VB_HINT_CAP]  class 0 (unshared), 1 (shared by 2), 2 (by 4 / 8): dense (view, link, tile) id | flags << 27
-//                              (flags 2, 3: left / right half of a job shared by two groups of 4)
-//   lcost [2][VB_HINT_CAP]     the cost that put an entry on its list (diagnostics)
-//   tick  [VB_HINT_CAP]        64-bit arrival ticket of the two halves of a job shared by 8: count (8 bits) | halves that drew
-//                              (16) | general-path flags (8) | summed cost << 32; back to zero when the second half has read it
-//   pbuf  [VB_HINT_CAP][VB_PIECE_WORDS] u64: a half's coverage / depth buffer, by its class-2 list slot
-//   stamp [B * L * nt]         == generation: the job is on a current list (the single-job enumeration skips it)
-struct VbHint {
-    int* base;
-    static constexpr size_t O_LIST = 64, O_LCOST = O_LIST + 6 * VB_HINT_CAP, O_TICK = O_LCOST + 2 * VB_HINT_CAP,
-                            O_PBUF = O_TICK + 2 * VB_HINT_CAP, O_STAMP = O_PBUF + 2 * (size_t)VB_HINT_CAP * VB_PIECE_WORDS;
-    __host__ __device__ __forceinline__ int* gen() const { return base; }
-    __host__ __device__ __forceinline__ u64* counter(int k) const { return (u64*)(base + 32) + k; }
-    __host__ __device__ __forceinline__ unsigned* list(int k, int cls) const { return (unsigned*)(base + O_LIST + (3 * k + cls) * VB_HINT_CAP); }
-    __host__ __device__ __forceinline__ int* lcost(int k) const { return base + O_LCOST + k * VB_HINT_CAP; }
-    __host__ __device__ __forceinline__ u64* tick() const { return (u64*)(base + O_TICK); }
-    __host__ __device__ __forceinline__ u64* pbuf() const { return (u64*)(base + O_PBUF); }
-    __host__ __device__ __forceinline__ int* stamp() const { return base + O_STAMP; }
-    static size_t ints(size_t stamps) { return O_STAMP + stamps; }
+// Jobs that turned out heavy in the PREVIOUS step (poses move little between optimisation steps): remembered by their
+// dense (view, link, tile) id, stamped into a table at the start of the step so that the single-wave enumeration skips
+// them, and processed first, each by a whole workgroup.  Purely a scheduling hint: results do not depend on it.
+struct VbHeavy {
+    int* gen;     // [0] generation (one per call), [1..2] entries in list 0 / 1, [4..5] entries in mlist 0 / 1
+    int* list;    // [2][VB_HEAVY_CAP] dense ids; list (gen & 1) is being written, the other one is being consumed
+    int* mlist;   // [2][VB_MED_CAP] likewise: jobs below the heavy threshold that were long all the same
+    int* stamp;   // [B * L * nt]  == generation: handled by a heavy workgroup this step; == -generation: a long job, dealt
+                  // out as some wave's first job
+    int mcap;     // long jobs consumed per step: min(VB_MED_CAP, 2 x workgroups of the job kernel) -- every one of them
+                  // must find a wave with a static first job, and at least half the workgroups have those
 };
 
 struct VbClusters {          // static acceleration index built by ehr_fused_plan (host): triangles grouped into
@@ -255,7 +241,7 @@ __global__ void __launch_bounds__(256)
 vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vert_link,
                  const int32_t* __restrict__ tris, VbClusters cl, StepHead head, float* __restrict__ mvp, int V, int nvb,
                  BinGeom g, float4* __restrict__ posc, VbRecs rc, int* __restrict__ lbox, int* __restrict__ zacc,
-                 int nzacc, int* __restrict__ meta, int B, int gx, int xcd_views, VbHint hv, int chunk_role) {
+                 int nzacc, int* __restrict__ meta, int B, int gx, int xcd_views, VbHeavy hv, int chunk_role) {
     __shared__ float Tc[16];
     __shared__ float M[32][16];
     // 1-D grid of B * gx workgroups.  xcd_views > 0 (B a multiple of 8): workgroup w runs on XCD w % 8 (observed, used
@@ -339,12 +325,21 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         }
     }
     if (first) {
-        // new generation of the scheduling hint: the list the last step wrote becomes this step's work plan, the other
-        // copy starts empty (its tables are written by this step's job kernel as it goes)
+        // new generation of the heavy-job hint: stamp last step's heavy jobs, start this step's list empty
+        __shared__ int s_gen;
         if (tid == 0) {
-            const int gen = hv.gen()[0] + 1;
-            hv.gen()[0] = gen;
-            *hv.counter(gen & 1) = 0ull;
+            s_gen = hv.gen[0] + 1;
+            hv.gen[0] = s_gen;
+            hv.gen[1 + (s_gen & 1)] = 0;
+            hv.gen[4 + (s_gen & 1)] = 0;
+        }
+        __syncthreads();
+        {
+            const int gen = s_gen, cur = (gen - 1) & 1;
+            const int n = min(hv.gen[1 + cur], VB_HEAVY_CAP);
+            for (int i = tid; i < n; i += 256) hv.stamp[hv.list[cur * VB_HEAVY_CAP + i]] = gen;
+            const int n2 = min(hv.gen[4 + cur], hv.mcap);
+            for (int i = tid; i < n2; i += 256) hv.stamp[hv.mlist[cur * VB_MED_CAP + i]] = -gen;
         }
         if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
         if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors of the 8 XCDs, tickets, slow-job count
@@ -1244,23 +1239,10 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
 // Stage 2: one WAVE per job = (view, link, 32x8 tile the link's screen box touches); persistent waves over the job list,
 // which is never materialised (every workgroup derives it from the link boxes with a prefix sum over B * L counts).
 // A job culls the link's cluster boxes, then the triangle boxes of the surviving clusters, and rasterizes the survivors
-// into an LDS coverage bitmap / depth-id buffer (tile + 1-pixel halo).  It leaves, in the job's slot (view, link, tile),
-// the coverage words, the triangle id of every region pixel the silhouette analysis will ask for (jid) and a descriptor
-// (jdesc; -1 and jn = -1 when nothing was drawn); the resolve kernel takes it from there.
-//
-// Who goes first, and who shares.  With ~1.2 jobs per wave nothing averages out: the kernel ends when its longest chain
-// does.  Jobs that were long in the previous step are on lists (VbHint) and are started FIRST, and the longer ones are
-// shared by a GROUP of 2 or 4 waves of one workgroup, the longest by two such groups of 4.  Sharing is by SCREEN SPACE:
-// wave w of a group draws the link's triangles into its own column strip of the tile (plus the strip's 1-pixel halo), so
-// inside its strip its coverage is complete and the coverage-first depth test (only covered pixels with an uncovered
-// neighbour) works as for a whole job; all waves of a group draw into ONE coverage / depth buffer in LDS (ds_or / ds_min:
-// order independent), so nothing has to be merged.  No barriers: a wave that finishes its strip takes an LDS ticket; the
-// last one publishes the job, the others go on to other jobs with a buffer from the group's free stack (the LDS of a
-// wave that is still busy in the shared buffer lies idle).  Two groups of 4 (two workgroups, 16 columns each) meet in
-// global memory: each stores its buffer (agent-scope stores), takes a ticket on the job, and the second one merges the
-// first one's buffer into its own (coverage: OR; keys: minimum).  Bit-identical to the unshared job by construction:
-// every pixel is drawn by a strip that sees all the triangles that can cover it and all four of its neighbours.
-// (Round 3 shared by candidate clusters, behind four barriers, in a second copy of the job loop.)
+// into the wave's LDS depth/id buffer (tile + 1-pixel halo).  It leaves, in the job's slot (view, link, tile), the
+// triangle id of every region pixel (jid) and a descriptor (jdesc; -1 and jn = -1 when nothing was drawn); the resolve
+// kernel takes it from there.  No workgroup barriers after the prologue except in the heavy-job phase; thousands of
+// independent waves hide each other's latency.
 #ifndef VB_JOB_WAVES
 #define VB_JOB_WAVES 4
 #endif
@@ -1270,32 +1252,26 @@ template <bool COVER>
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
 vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
               unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, unsigned* __restrict__ jutile, int jcap,
-              int* __restrict__ meta, int dbg, VbHint hv, long long* __restrict__ timeline,
+              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline,
               const float4* __restrict__ posc, int V, VbSlotIdx si, u64* __restrict__ jcov,
-              int4* __restrict__ slow_list, int long_t0, int piece_t0) {
+              int4* __restrict__ slow_list, int heavy_t, int med_t0) {
     __shared__ VbWaveLds lds_all[4];
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the scheduling hint of the previous step is requested before anything else (dependent round trips that would
-    // otherwise sit between the prologue and the wave's first job)
-    const int gen = COVER ? 0 : hv.gen()[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
-    const u64 counts_prev = COVER ? 0ull : *hv.counter(hcur);
+    // the scheduling hint of the previous step is requested before anything else (two dependent round trips that would
+    // otherwise sit between the prologue and a heavy job)
+    const int gen = hv.gen[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
+    const int nheavy_prev = hv.gen[1 + hcur];
+    const int hid_first = hv.list[hcur * VB_HEAVY_CAP + min((int)blockIdx.x, VB_HEAVY_CAP - 1)];
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
     __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
     __shared__ int lcoff[33];                 // first cluster of every link
-    __shared__ int s_free;                    // buffers (lds_all[k].key / .cov) nobody is using: a group's idle ones
-    __shared__ int s_tick[4], s_cost[4];      // per shared buffer: arrivals | drew << 8 | general-path << 16; summed cost
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbWaveLds& S = lds_all[wave];
     const int W = g.W, H = g.H, L = g.L, U = B * L;
     // ---- prologue (every workgroup, redundantly): tile range and job count of every (view, link), prefix sum
     if (tid <= L) lcoff[tid] = cl.coff[tid];
-    if (tid < 4) {
-        s_tick[tid] = 0;
-        s_cost[tid] = 0;
-    }
-    if (tid == 0) s_free = 0;
     for (int u = tid; u < U; u += 256) {
         int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
         const bool ne = vb_unit_tiles(lbox + VB_LBOX_STRIDE * (size_t)u, W, H, tx0, ty0, nx, ny, COVER ? 0 : 1);
@@ -1355,105 +1331,145 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     A.W = W;
     A.H = H;
     A.L = L;
-    // The lists are used only while the machine is short of jobs (at most ~2 per wave): with many views per GPU the kernel
-    // is bound by the sum of the jobs, not by the longest, and a shared job costs more than the job (triangles that touch
-    // several strips are set up in each).  EHR_VB_DEBUG & 64: off.
-    const int nwaves = (int)gridDim.x * 4;
-    const bool hint_on = !COVER && !(dbg & 64) && total <= 2 * nwaves;
-    // class capacities: at most a quarter of the grid each for the jobs shared by 4, by 2 and the unshared long ones
-    const int cap4 = (int)gridDim.x >> 2, cap2 = (int)gridDim.x >> 1, cap1 = (int)gridDim.x;
-    const int n4 = hint_on ? min((int)(counts_prev & 0xfffffu), cap4) : 0;            // workgroup slots of class 4 (a job
-    const int n2 = hint_on ? min((int)((counts_prev >> 20) & 0xfffffu), cap2) : 0;    // shared by 8 takes two)
-    const int n1 = hint_on ? min((int)((counts_prev >> 40) & 0xfffffu), cap1) : 0;
-    const int W4 = n4, W2 = (n2 + 1) >> 1, W1 = (n1 + 3) >> 2;  // workgroups whose waves start with listed jobs
-    // ... and when there are fewer jobs than waves (one view, small images) most waves are idle anyway: jobs are listed and
-    // shared from a proportionally lower cost (down to an eighth), so that the longest ones are spread
-    const float tscale = fminf(1.f, fmaxf(0.125f, (float)total / (float)(2 * (int)gridDim.x)));
-    const int long_t = max((int)((float)long_t0 * tscale), 1);
-    const int piece_t = max((int)((float)piece_t0 * tscale), 128);
-    // lane 0 of the wave that finishes a job (the last one, if it was shared): a long job enters the next step's list of
-    // its class and is stamped -- one returning atomic (the three class counters in one 64-bit word on a line of its own).
-    // `cost` is the sum over the kcur waves that shared it, and a shared job costs more than the job, so the sum must not
-    // drive the class on its own: shared by twice as many when the waves' shares still average two piece lengths, by half
-    // as many when they fall below 0.8, left alone in between.
-    // ---- this wave's listed job, if any: workgroups [0, W4) one class-4 slot each, [W4, W4 + W2) two class-2 jobs each,
-    //      [W4 + W2, W4 + W2 + W1) four unshared ones
-    const int wg = (int)blockIdx.x;
-    int first_id = -1, gk = 1, gw0 = wave, half = -1, slot4 = 0;  // dense id; waves in the group; its first wave; half of a job of 8
-    if (wg < W4) {
-        const unsigned e = hv.list(hcur, 2)[wg];
-        first_id = (int)(e & 0x7ffffffu);
-        gk = 4;
-        gw0 = 0;
-        slot4 = wg;
-        if (e >> 28) half = (int)((e >> 27) & 1u);
-    } else if (wg < W4 + W2) {
-        const int j = 2 * (wg - W4) + (wave >> 1);
-        if (j < n2) {
-            first_id = (int)(hv.list(hcur, 1)[j] & 0x7ffffffu);
-            gk = 2;
-            gw0 = wave & 2;
-        }
-    } else if (wg < W4 + W2 + W1) {
-        const int j = 4 * (wg - W4 - W2) + wave;
-        if (j < n1) first_id = (int)(hv.list(hcur, 0)[j] & 0x7ffffffu);
+    // ---- heavy jobs first, one workgroup each: the four waves share the job's depth/id buffer (wave 0's) and split the
+    //      candidate clusters; wave 0 publishes.  A job alone costs up to ~80 us on one wave (a thousand candidate
+    //      triangles in one tile), which used to be the duration of this kernel at small batch sizes.
+    __shared__ int s_heavy[2];  // drawn flag, survivors
+    // Only when the machine is short of jobs (at most ~2 per wave): with many views per GPU the kernel is bound by the
+    // sum of the jobs, not by the longest, and four waves on one job are less efficient than four jobs (measured: 64
+    // views 8 % slower with the heavy phase, 8 views 10 % faster, 1 view 40 % faster).
+    // Likewise when heavy jobs are the rule rather than the exception (more than one per two workgroups: the Franka
+    // meshes at 1080p have ~3000 of them in 8100 jobs and run 17 % slower with the heavy phase; the 8-view xArm7
+    // workload has ~220 in 5000).
+    const int hmax = (dbg >> 8) ? (dbg >> 8) : (int)gridDim.x / 2;  // (EHR_VB_DEBUG bits 8..: experiment with the limit)
+    const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > hmax) ? 0 : min(nheavy_prev, VB_HEAVY_CAP);
+    // ... and when there are fewer jobs than waves (one view, small images) most workgroups are idle anyway: jobs count as
+    // heavy from a proportionally lower cost (down to an eighth: a few rounds), so that the longest ones are shared
+    {
+        const float f = fminf(1.f, fmaxf(0.125f, (float)total / (float)(2 * (int)gridDim.x)));
+        heavy_t = (int)((float)heavy_t * f);
     }
-    // workgroups whose waves start with listed jobs take no static job: the first hk of this XCD's workgroups
-    const int nhw = min(W4 + W2 + W1, (int)gridDim.x);
+    auto remember_heavy = [&](int id) {
+        const int at = atomicAdd(&hv.gen[1 + hnxt], 1);
+        if (at < VB_HEAVY_CAP) hv.list[hnxt * VB_HEAVY_CAP + at] = id;
+    };
+    // Long jobs below the heavy threshold: a wave that claims one late (after two or three others) is what the kernel
+    // ends on -- 30 us on one wave whenever it starts -- so they are remembered as well and dealt out as static FIRST jobs,
+    // one per wave, in the next step.  Only when the machine is short of jobs (at most 1.5 per wave): with more, claiming
+    // balances the waves anyway and the jobs are better off in their own XCD's eighth of the list (L2).
+    const int med_t = max(med_t0, 1);
+    const int nmed = ((dbg & (64 | 128)) || total > 6 * (int)gridDim.x) ? 0 : min(hv.gen[4 + hcur], hv.mcap);
+    auto remember_long = [&](int id) {
+        const int at = atomicAdd(&hv.gen[4 + hnxt], 1);
+        if (at < VB_MED_CAP) hv.mlist[hnxt * VB_MED_CAP + at] = id;
+    };
+    if (tid < 2) s_heavy[tid] = 0;
+    __syncthreads();
+#if VB_PRIO_HEAVY
+    if ((int)blockIdx.x < nheavy) __builtin_amdgcn_s_setprio(VB_PRIO_HEAVY);
+#endif
+    for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform
+        const int id = (hj == (int)blockIdx.x) ? hid_first : hv.list[hcur * VB_HEAVY_CAP + hj];
+        const int u = id / g.nt, tile = id - u * g.nt;
+        const int tx = tile % g.ntx, ty = tile / g.ntx;
+        const unsigned ut = utile[u];
+        const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
+        const int job = upre[u] + (ty - ty0) * nx + (tx - tx0);
+        if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
+        const int b = u / L, l = u - b * L;
+        const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+        VbRegion rg;
+        rg.x0 = max(rx0, 0);
+        rg.y0 = max(ry0, 0);
+        rg.x1 = min(rx0 + VB_RW - 1, W - 1);
+        rg.y1 = min(ry0 + VB_RH - 1, H - 1);
+        VbWaveLds& S0 = lds_all[0];
+        for (int i = tid; i < VB_RN; i += 256) S0.key[i] = VB_EMPTY;
+        if (tid < VB_RH) S0.cov[tid] = 0ull;
+        __syncthreads();
+        int nsurv = 0, dln = 0;
+        const int drawn = vb_job_raster<false>(A, S, S0.key, S0.cov, b, l, rg, rx0, ry0, wave, 4, nsurv, dln);
+        if (lane == 0) {
+            if (drawn > 0) atomicOr(&s_heavy[0], 1);
+            if (drawn < 0) atomicOr(&s_heavy[0], 2);  // a triangle for the general path: wave 0 redoes the job alone
+            atomicAdd(&s_heavy[1], nsurv);
+        }
+        __syncthreads();  // the job's coverage is complete: every wave filters its own deferred units against it
+        const int any_drawn = s_heavy[0];
+        int tot_surv = s_heavy[1];
+        if (!(any_drawn & 2) && dln > 0)
+            vb_flush(S, S0.key, S0.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+        __syncthreads();
+        if (any_drawn == 1) vb_publish(A, S0.key, S0.cov, job, u, tx, ty, wave, 4);  // every wave its share of the words
+        if (wave == 0) {
+            if (any_drawn & 2) {  // put aside for vb_slow_kernel
+                if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
+            } else if (any_drawn) {
+            } else if (lane == 0) {
+                jn[job] = -1;
+                jdesc[job] = -1;
+            }
+            if (lane == 0) {
+                s_heavy[0] = 0;
+                s_heavy[1] = 0;
+                if (tot_surv >= heavy_t)
+                    remember_heavy(id);
+                else if (tot_surv >= med_t)
+                    remember_long(id);
+#ifdef VB_TIMELINE
+                S0.tl_flushes = tot_surv;  // (profiling build: wave 0's counters are reset after the heavy phase; parked here)
+#endif
+            }
+        }
+        __syncthreads();
+    }
+
+#if VB_PRIO_HEAVY
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    // workgroups that just spent their time on a heavy job take no static job: the first hk of this XCD's workgroups
+    const int nhw = min(nheavy, (int)gridDim.x);
     const int hk = (nhw > xcd) ? (nhw - xcd + 7) >> 3 : 0;
     const int kx = blockIdx.x >> 3;                      // this workgroup's index inside its XCD
-    const int nsn = ((gridDim.x >> 3) - hk) * 4;         // waves of this XCD that take a static first job
+    const int nsw = ((gridDim.x >> 3) - hk) * 4;         // waves of this XCD that take a static first job
 #ifdef VB_TIMELINE
-    const long long tl_heavy = tl_start;
+    const long long tl_heavy = wall_clock64();
     int tl_jobs = 0, tl_maxsurv = 0, tl_sumsurv = 0;
-    const int tl_hcost = 0;
+#endif
+#ifdef VB_TIMELINE
+    const int tl_hcost = (wave == 0) ? lds_all[0].tl_flushes : 0;
+    VB_WAVE_SYNC();
     if (lane == 0) {
         S.tl_units = S.tl_rounds = S.tl_flushes = S.tl_tested = S.tl_deferred = 0;
         for (int k = 0; k < 8; k++) S.tl_c[k] = 0;
     }
 #endif
-    // every wave's own buffer starts empty; a group draws into its first wave's, and the other waves' buffers are free
-    // for whoever of the group finishes early
-    if (!COVER) {
-#pragma unroll
-        for (int k = 0; k < VB_WORDS; k++) {
-            const unsigned i = 64u * k + lane;
-            if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
-        }
-    }
-    if (lane < VB_RH) S.cov[lane] = 0ull;
-    int job = 0, u = -1, tx = 0, ty = 0;
-    bool have_first = false;
-    if (first_id >= 0) {
-        u = first_id / g.nt;
-        const int tile = first_id - u * g.nt;
-        tx = tile % g.ntx;
-        ty = tile / g.ntx;
-        if (u < U) {
-            const unsigned ut = utile[u];
-            const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
-            job = upre[u] + (ty - ty0) * nx + (tx - tx0);
-            have_first = !(n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total);  // else: the link moved away
-        }
-        if (have_first && gk > 1 && wave == gw0 && lane == 0) atomicOr(&s_free, ((1 << gk) - 2) << gw0);
-    }
-    if (wg < W4 + W2) __syncthreads();  // (workgroup-uniform) the shared buffers are empty, the free stack is set up
     bool first_job = kx >= hk;
-    int sjob = jbeg + (kx - hk) * 4 + wave;
-    int myset = wave;  // the buffer this wave draws its own jobs into
+    // static first jobs: wave rx of this XCD's static waves (global rank 8 rx + xcd) takes long job number <rank> of the
+    // previous step if there is one, else the (rx - nmx)-th job of the XCD's eighth; the rest of the eighth is claimed
+    const int rx = (kx - hk) * 4 + wave;
+    const int nmx = (nmed > xcd) ? (nmed - xcd + 7) >> 3 : 0;  // long jobs that go to this XCD's waves (<= nsw, see mcap)
+    const int nsn = nsw - nmx;                                 // static jobs of the eighth itself
+    int sjob = jbeg + rx - nmx;
     for (;;) {
 #ifdef VB_TIMELINE
         const long long tl_j0 = __builtin_readcyclecounter();
 #endif
-        int share = 0, nshare = 1, set = myset;
-        if (have_first) {
-            have_first = false;
-            nshare = gk;
-            share = wave - gw0;
-            set = gw0;
+        int job = 0, u = -1, tx = 0, ty = 0;
+        if (first_job && rx < nmx) {
+            first_job = false;
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(VB_PRIO_LONG);
 #endif
+            const int id = hv.mlist[hcur * VB_MED_CAP + 8 * rx + xcd];
+            u = id / g.nt;
+            const int tile = id - u * g.nt;
+            tx = tile % g.ntx;
+            ty = tile / g.ntx;
+            const unsigned ut = utile[u];
+            const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
+            job = upre[u] + (ty - ty0) * nx + (tx - tx0);
+            if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
         } else {
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(0);
@@ -1463,7 +1479,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
                 sjob += nsn;
                 first_job = false;
                 if (job >= jbeg + nsn && !(dbg & 8)) job = jend;  // (more static waves than jobs)
-            } else {  // whoever is done first takes the next one
+            } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
                 if (lane == 0) job = jbeg + nsn + atomicAdd(cursor, 1);
                 job = __builtin_amdgcn_readfirstlane(job);
             }
@@ -1485,11 +1501,10 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
                 ty = (int)((ut >> 10) & 4095u) + k / nx;
                 tx = (int)(ut & 1023u) + k - (k / nx) * nx;
             }
-            // on a list: some waves' first job
-            if (nhw > 0 && hv.stamp()[u * g.nt + ty * g.ntx + tx] == gen) continue;
+            const int st = (nheavy > 0 || nmed > 0) ? hv.stamp[u * g.nt + ty * g.ntx + tx] : 0;
+            // a workgroup took this one in the heavy phase / it is some wave's first job
+            if ((nheavy > 0 && st == gen) || (nmed > 0 && st == -gen)) continue;
         }
-        u64* const key = lds_all[set].key;
-        u64* const cov = lds_all[set].cov;
         const int b = u / L, l = u - b * L;
         const size_t slot = (size_t)job;
         const int dense_id = u * g.nt + ty * g.ntx + tx;
@@ -1500,29 +1515,25 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         rg.x1 = min(rx0 + VB_RW - 1 - (COVER ? 1 : 0), W - 1);
         rg.y1 = min(ry0 + VB_RH - 1 - (COVER ? 1 : 0), H - 1);
         VB_WAVE_SYNC();
-        if (nshare == 1) {  // (a shared buffer was emptied before the group started)
-            if (!COVER) {
+        if (!COVER) {
 #pragma unroll
-                for (int k = 0; k < VB_WORDS; k++) {
-                    const unsigned i = 64u * k + lane;
-                    if (i < (unsigned)VB_RN) key[i] = VB_EMPTY;
-                }
+            for (int k = 0; k < VB_WORDS; k++) {
+                const unsigned i = 64u * k + lane;
+                if (i < (unsigned)VB_RN) S.key[i] = VB_EMPTY;
             }
-            if (lane < VB_RH) cov[lane] = 0ull;
         }
+        if (lane < VB_RH) S.cov[lane] = 0ull;
         if (COVER && lane == 0) S.bad = 0;
         VB_WAVE_SYNC();
 #ifdef VB_TIMELINE
         const long long tl_j1 = __builtin_readcyclecounter();
 #endif
         int nsurv = 0, dln = 0;
-        // (one of a group: every nshare-th candidate cluster of the job, into the group's buffer)
-        const int csh = (nshare > 1 && half > 0 ? nshare : 0) + share, cns = (nshare > 1 && half >= 0 ? 2 : 1) * nshare;
-        const int drawn = vb_job_raster<false, COVER>(A, S, key, cov, b, l, rg, rx0, ry0, csh, cns, nsurv, dln);
+        const int drawn = vb_job_raster<false, COVER>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
         if (COVER) {
             // flagged units (their depth range must be tested per pixel: edge-on slivers mostly) are the only deferred ones
             if (drawn >= 0 && dln > 0)
-                vb_flush<true>(S, key, cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+                vb_flush<true>(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
             VB_WAVE_SYNC();
             if (drawn < 0 || S.bad) {  // a triangle for the general path, or a drawn pixel with a depth <= 0: coverage cannot
                 if (lane == 0) jn[0] = 1;  // decide here and the caller falls back for the whole call
@@ -1532,7 +1543,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
                 // the tile's 32 x 8 interior of the coverage rows, OR-ed into the (view, tile) words (all links of a view)
                 VB_WAVE_SYNC();
                 if (lane < 4) {
-                    const u64 w = ((cov[2 * lane + 1] >> 1) & 0xffffffffull) | (((cov[2 * lane + 2] >> 1) & 0xffffffffull) << 32);
+                    const u64 w = ((S.cov[2 * lane + 1] >> 1) & 0xffffffffull) | (((S.cov[2 * lane + 2] >> 1) & 0xffffffffull) << 32);
                     // (layout [candidate][tile][pose][4]: the count kernel reads a candidate's words of a tile in one piece;
                     //  jcap carries S, the poses per candidate, in this form)
                     if (w) atomicOr((unsigned long long*)&jcov[((((size_t)(b / jcap) * g.nt + (size_t)ty * g.ntx + tx) * jcap + (b % jcap)) * 4 + lane)], w);
@@ -1540,133 +1551,23 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             }
             continue;
         }
-#ifdef VB_GROUP_WAIT  // experiment: wait for the whole group's coverage before the flush
-        if (nshare > 1) {
-            VB_WAVE_SYNC();
-            if (lane == 0) {
-                atomicAdd(&s_cost[set], 1 << 20);
-                while ((__hip_atomic_load(&s_cost[set], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 20) < nshare) __builtin_amdgcn_s_sleep(2);
-            }
-            VB_WAVE_SYNC();
+        if (drawn < 0) {  // a triangle for the general path (near-plane clipping, huge extent): put the job aside
+            if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
+            continue;
         }
-#endif
-        // the deferred units are filtered against the coverage of this wave's rectangle (complete there, see above)
-        if (drawn >= 0 && dln > 0) vb_flush(S, key, cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
-        int state = (drawn < 0) ? 2 : (drawn > 0 ? 1 : 0);  // 2: a triangle for the general path (near-plane clipping, huge extent)
-        int cost = nsurv, kshare = nshare;
-        if (nshare > 1) {
-            // ---- one of a group: LDS ticket on the shared buffer; whoever is not last goes on with a free buffer
-            VB_WAVE_SYNC();  // this wave's LDS atomics into the shared buffer are performed
-            int tot = 0, fr = 0;
-            if (lane == 0) {
-                atomicAdd(&s_cost[set], cost);
-                const int add = 1 | ((state == 1) ? (1 << 8) : 0) | ((state == 2) ? (1 << 16) : 0);
-                tot = atomicAdd(&s_tick[set], add) + add;
-                if ((tot & 0xff) != nshare) {  // pop a free buffer
-                    for (;;) {
-                        const int m = __hip_atomic_load(&s_free, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const int bsel = __ffs(m) - 1;  // (never empty: a group frees one buffer per wave that is not its last)
-                        if (atomicAnd(&s_free, ~(1 << bsel)) & (1 << bsel)) {
-                            fr = bsel;
-                            break;
-                        }
-                    }
-                }
-            }
-            tot = __builtin_amdgcn_readfirstlane(tot);
-            if ((tot & 0xff) != nshare) {
-                myset = __builtin_amdgcn_readfirstlane(fr);
-                continue;
-            }
-            myset = set;  // the last of the group keeps the shared buffer
-            VB_WAVE_SYNC();
-            cost = __builtin_amdgcn_readfirstlane(s_cost[set]) & 0xfffff;
-            state = ((tot >> 16) & 0xff) ? 2 : (((tot >> 8) & 0xff) ? 1 : 0);
-            if (half >= 0) {
-                // ---- one of two groups: the halves meet in global memory (agent-scope stores: written through to where the
-                //      other workgroup's loads will find them); the second arrival merges the first one's buffer into its own
-                kshare = 8;
-                const int s_lo = (half == 0) ? slot4 : slot4 - 1;  // the pair's ticket lives with its left half
-                u64* const mine = hv.pbuf() + (size_t)slot4 * VB_PIECE_WORDS;
-                if (state == 1) {
-#pragma unroll
-                    for (int k = 0; k < VB_WORDS; k++) {
-                        const unsigned i = 64u * k + lane;
-                        if (i < (unsigned)VB_RN) __hip_atomic_store(&mine[i], key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (lane < VB_RH) __hip_atomic_store(&mine[VB_RN + lane], cov[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // performed before the ticket is taken
-                unsigned tlo = 0, thi = 0;
-                if (lane == 0) {
-                    const u64 add = 1ull | ((state == 1) ? (1ull << (8 + half)) : 0ull) | ((state == 2) ? (1ull << 24) : 0ull) |
-                                    ((u64)(unsigned)cost << 32);
-                    const u64 t2 = atomicAdd((unsigned long long*)&hv.tick()[s_lo], add) + add;
-                    tlo = (unsigned)t2;
-                    thi = (unsigned)(t2 >> 32);
-                }
-                tlo = (unsigned)__builtin_amdgcn_readfirstlane((int)tlo);
-                if ((tlo & 0xffu) != 2u) continue;  // the other half is still at work: it will publish
-                thi = (unsigned)__builtin_amdgcn_readfirstlane((int)thi);
-                if (lane == 0) hv.tick()[s_lo] = 0ull;  // ready for the next step
-                cost = (int)thi;
-                const bool other_drew = ((tlo >> 8) & 3u & ~(1u << half)) != 0;
-                state = (tlo >> 24) ? 2 : (((tlo >> 8) & 3u) ? 1 : 0);
-                if (state == 1 && other_drew) {
-                    const u64* const other = hv.pbuf() + (size_t)(half == 0 ? slot4 + 1 : slot4 - 1) * VB_PIECE_WORDS;
-                    u64 v[VB_WORDS];  // one round trip: all of the buffer's words are requested before any is looked at
-#pragma unroll
-                    for (int k = 0; k < VB_WORDS; k++) {
-                        const unsigned i = 64u * k + lane;
-                        v[k] = (i < (unsigned)VB_RN) ? __hip_atomic_load(&other[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : VB_EMPTY;
-                    }
-                    const u64 cv = (lane < VB_RH) ? __hip_atomic_load(&other[VB_RN + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-#pragma unroll
-                    for (int k = 0; k < VB_WORDS; k++) {
-                        const unsigned i = 64u * k + lane;
-                        if (i < (unsigned)VB_RN && v[k] < key[i]) key[i] = v[k];
-                    }
-                    if (lane < VB_RH) cov[lane] |= cv;
-                    VB_WAVE_SYNC();
-                }
-            }
-        }
+        if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
 #ifdef VB_TIMELINE
         tl_jobs++;
         tl_maxsurv = max(tl_maxsurv, nsurv);
         tl_sumsurv += nsurv;
 #endif
-        if (lane == 0) {  // a long job enters the next step's list of its class (comment above)
-            const int id = dense_id, kcur = kshare;
-            do {
-                if (!hint_on) break;
-                // how many waves next time: the smallest power of two that brings a wave's share below piece_t (sharing by
-                // clusters adds little work, so the sum over the waves is the job's cost); a class is left downwards only
-                // when the cost has fallen 15 % below its lower boundary (no flapping at the boundaries)
-                int K = (cost <= piece_t) ? 1 : (cost <= 2 * piece_t ? 2 : (cost <= 4 * piece_t ? 4 : 8));
-                if (K < kcur && 20 * cost > 17 * (piece_t * kcur / 2)) K = kcur;
-                if (K == 1 && cost < long_t) break;
-                const u64 add = (K == 8) ? 2ull : (K == 4 ? 1ull : (K == 2 ? (1ull << 20) : (1ull << 40)));
-                const u64 old = atomicAdd((unsigned long long*)hv.counter(hnxt), add);
-                const int at = (K >= 4) ? (int)(old & 0xfffffu) : (K == 2 ? (int)((old >> 20) & 0xfffffu) : (int)((old >> 40) & 0xfffffu));
-                const int cap = (K >= 4) ? cap4 : (K == 2 ? cap2 : cap1);
-                if (at + (K == 8 ? 2 : 1) > cap) break;
-                unsigned* const lst = hv.list(hnxt, K >= 4 ? 2 : (K == 2 ? 1 : 0));
-                if (K == 8) {  // two workgroup slots: the left and the right half of the tile
-                    lst[at] = (unsigned)id | (2u << 27);
-                    lst[at + 1] = (unsigned)id | (3u << 27);
-                } else {
-                    lst[at] = (unsigned)id;
-                }
-                hv.lcost(hnxt)[(K >= 4 ? 0 : (K == 2 ? cap4 : cap4 + cap2)) + at] = cost;
-                hv.stamp()[id] = gen + 1;
-            } while (0);
+        if (lane == 0) {
+            if (nsurv >= heavy_t)
+                remember_heavy(dense_id);
+            else if (nsurv >= med_t)
+                remember_long(dense_id);
         }
-        if (state == 2) {  // put the job aside for the general path
-            if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
-            continue;
-        }
-        if (state == 0) {  // the link's box touches this tile, its triangles do not
+        if (drawn == 0) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
                 jn[slot] = -1;
                 jdesc[slot] = -1;
@@ -1676,7 +1577,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 #ifdef VB_TIMELINE
         const long long tl_j2 = __builtin_readcyclecounter();
 #endif
-        vb_publish(A, key, cov, job, u, tx, ty);
+        vb_publish(A, S.key, S.cov, job, u, tx, ty);
 #ifdef VB_TIMELINE
         if (lane == 0) {
             const long long now = __builtin_readcyclecounter();
@@ -1688,21 +1589,21 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     }
 #ifdef VB_TIMELINE
     if (lane == 0 && timeline) {
-        const size_t gwi = (size_t)blockIdx.x * 4 + wave;
+        const size_t gw = (size_t)blockIdx.x * 4 + wave;
         const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave slot, SIMD, CU, SH, SE
         const unsigned xccid = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
-        timeline[4 * gwi] = tl_start;
-        timeline[4 * gwi + 1] = wall_clock64();
-        timeline[4 * gwi + 2] = tl_heavy;
-        timeline[4 * gwi + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
+        timeline[4 * gw] = tl_start;
+        timeline[4 * gw + 1] = wall_clock64();
+        timeline[4 * gw + 2] = tl_heavy;
+        timeline[4 * gw + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
                                ((long long)(hwid & 0xffff) << 32) | ((long long)(xccid & 0xf) << 48);
-        long long* const txp = timeline + 4 * (size_t)gridDim.x * 4 + 12 * gwi;
-        txp[0] = S.tl_units;
-        txp[1] = S.tl_rounds;
-        txp[2] = (long long)S.tl_flushes | ((long long)S.tl_tested << 16) | ((long long)S.tl_deferred << 40);
-        for (int k = 0; k < 4; k++) txp[3 + k] = S.tl_c[k];
-        txp[7] = tl_hcost;
-        for (int k = 0; k < 3; k++) txp[8 + k] = S.tl_c[4 + k];
+        long long* const tx = timeline + 4 * (size_t)gridDim.x * 4 + 12 * gw;
+        tx[0] = S.tl_units;
+        tx[1] = S.tl_rounds;
+        tx[2] = (long long)S.tl_flushes | ((long long)S.tl_tested << 16) | ((long long)S.tl_deferred << 40);
+        for (int k = 0; k < 4; k++) tx[3 + k] = S.tl_c[k];
+        tx[7] = tl_hcost;
+        for (int k = 0; k < 3; k++) tx[8 + k] = S.tl_c[4 + k];
     }
 #else
     (void)timeline;
@@ -2562,8 +2463,8 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         const size_t nslot = (size_t)ctx->vb_jcap;
         if ((rc = ctx->vb_jobs.reserve(nslot * slot_bytes + (2 * (size_t)Bc * L + 1) * sizeof(int) + 32))) return rc;
     }
-    {  // scheduling hint (VbHint): generation + counts | two lists | piece tables and buffers | stamp table (dense ids of a chunk)
-        const size_t ints = VbHint::ints((size_t)Bc * L * gp.nt);
+    {  // heavy-job hint: generation + two counts | two lists | stamp table (dense ids of a chunk)
+        const size_t ints = 8 + 2 * (size_t)VB_HEAVY_CAP + 2 * (size_t)VB_MED_CAP + (size_t)Bc * L * gp.nt;
         if ((rc = ctx->vb_heavy.reserve(ints * sizeof(int)))) return rc;
         EHR_HIP(hipMemset(ctx->vb_heavy.ptr, 0, ints * sizeof(int)));
     }
@@ -2591,24 +2492,9 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
         int m8[8];
         EHR_HIP(hipMemcpy(m8, (char*)ctx->vb_acc.ptr + off, sizeof(m8), hipMemcpyDeviceToHost));
         fprintf(stderr, "[ehr vbuf] overflow %d spill %d jobs %d\n", m8[EHR_META_OVERFLOW], m8[EHR_META_SPILL], m8[5]);
-        {
-            std::vector<int> hb(VbHint::O_TICK);
-            EHR_HIP(hipMemcpy(hb.data(), ctx->vb_heavy.ptr, hb.size() * sizeof(int), hipMemcpyDeviceToHost));
-            const int gen = hb[0], w = gen & 1;  // the lists the last call wrote
-            const unsigned long long c = *(const unsigned long long*)&hb[32 + 2 * w];
-            const int n4 = (int)(c & 0xfffff), n2 = (int)((c >> 20) & 0xfffff), n1 = (int)((c >> 40) & 0xfffff);
-            int hist[12] = {0};
-            long long csum = 0;
-            const int* lc = &hb[VbHint::O_LCOST + w * VB_HINT_CAP];
-            for (int i = 0; i < VB_HINT_CAP; i++)
-                if (lc[i] > 0) {
-                    hist[std::min(lc[i] / 500, 11)]++;
-                    csum += lc[i];
-                }
-            fprintf(stderr, "[ehr vbuf] scheduling hint: generation %d; listed for the next step: %d workgroup slots of jobs shared by 4 / 8, %d jobs shared by 2, %d unshared; cost histogram per 500 (both copies' stale entries included):", gen, n4, n2, n1);
-            for (int k = 0; k < 12; k++) fprintf(stderr, " %d", hist[k]);
-            fprintf(stderr, " sum %lld\n", csum);
-        }
+        int hg[3];
+        EHR_HIP(hipMemcpy(hg, ctx->vb_heavy.ptr, sizeof(hg), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ehr vbuf] heavy jobs: generation %d, lists %d / %d\n", hg[0], hg[1], hg[2]);
         int cur[8];
         for (int k = 0; k < 8; k++)
             EHR_HIP(hipMemcpy(&cur[k], vb_line((int*)((char*)ctx->vb_acc.ptr + off), k), sizeof(int), hipMemcpyDeviceToHost));
@@ -2728,8 +2614,11 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     cl.NC = NC;
     VbSlotIdx si;
     si.cvidx = (const int4*)(cl.cvert + 3 * (size_t)NC1 * 64);
-    VbHint hv;
-    hv.base = (int*)ctx->vb_heavy.ptr;
+    VbHeavy hv;
+    hv.gen = (int*)ctx->vb_heavy.ptr;
+    hv.list = hv.gen + 8;
+    hv.mlist = hv.list + 2 * VB_HEAVY_CAP;
+    hv.stamp = hv.mlist + 2 * VB_MED_CAP;
 
     hipEvent_t* ev = nullptr;
     if (ctx->timing) {
@@ -2746,8 +2635,9 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     const int vec_ok = ((W & 3) == 0) && (((uintptr_t)ref & 15) == 0) && (!mask || ((uintptr_t)mask & 15) == 0);
     static const int dbg_env = getenv("EHR_VB_DEBUG") ? atoi(getenv("EHR_VB_DEBUG")) : 0;  // measurement aid only
     static const int job_grid = getenv("EHR_VB_JOB_GRID") ? atoi(getenv("EHR_VB_JOB_GRID")) : 4;   // tuning knob
-    static const int long_t = getenv("EHR_VB_LONG_T") ? atoi(getenv("EHR_VB_LONG_T")) : VB_LONG_T_DEFAULT;      // tuning knob
-    static const int piece_t = getenv("EHR_VB_PIECE_T") ? atoi(getenv("EHR_VB_PIECE_T")) : VB_PIECE_T_DEFAULT;  // tuning knob
+    static const int heavy_t = getenv("EHR_VB_HEAVY_T") ? atoi(getenv("EHR_VB_HEAVY_T")) : VB_HEAVY_T_DEFAULT;  // tuning knob
+    static const int med_t = getenv("EHR_VB_MED_T") ? atoi(getenv("EHR_VB_MED_T")) : VB_MED_T_DEFAULT;        // tuning knob
+    hv.mcap = std::min(VB_MED_CAP, 2 * (((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7));
     static const int vertex_grid = getenv("EHR_VB_VERTEX_GRID") ? atoi(getenv("EHR_VB_VERTEX_GRID")) : 5;  // tuning knob
     static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
     static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
@@ -2811,7 +2701,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         // stage 1: jobs = (view, link, tile) -> coverage and the triangle ids the silhouette analysis will ask for
         const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
         vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg,
-                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, long_t, piece_t);
+                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t, med_t);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
         static const int slow_grid = getenv("EHR_VB_SLOW_GRID") ? atoi(getenv("EHR_VB_SLOW_GRID")) : 32;  // tuning knob
@@ -2925,7 +2815,7 @@ int ehr::vbuf_score(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     Qc = std::max(1, std::min(Qc, (int)(8192.0 * 1048576.0 / (view_bytes * S))));
     Qc = std::min(Qc, Q);
     const int Bc = Qc * S;
-    const size_t n_hv = 64;  // (the hint is off on this chain: its generation word and counters)
+    const size_t n_hv = 8 + 2 * (size_t)VB_HEAVY_CAP + 2 * (size_t)VB_MED_CAP;
     const size_t misc_ints = (size_t)VB_LBOX_STRIDE * Bc * L + EHR_META_INTS + (VB_LINES + 2) * 32 + n_hv + 16 + 64 + 2 * 32 * (size_t)Qc;
     if ((rc = ctx->sc_posc.reserve((size_t)Bc * V * sizeof(float4)))) return rc;
     if ((rc = ctx->sc_entries.reserve((size_t)Bc * NC * (64 * 40 + 8)))) return rc;
@@ -2938,8 +2828,12 @@ int ehr::vbuf_score(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     unsigned long long* sacc0 = (unsigned long long*)(((uintptr_t)(sticky + 16) + 127) & ~(uintptr_t)127);  // [2][Qc][16]
     u64* tcov = (u64*)(sacc0 + 2 * 16 * (size_t)Qc);
     float4* posc = (float4*)ctx->sc_posc.ptr;
-    VbHint hv;
-    hv.base = hvp;
+    VbHeavy hv;
+    hv.gen = hvp;
+    hv.list = hv.gen + 8;
+    hv.mlist = hv.list + 2 * VB_HEAVY_CAP;
+    hv.stamp = hv.gen;  // (never touched: the hint is off)
+    hv.mcap = 0;
     EHR_HIP(hipMemsetAsync(hvp, 0, (n_hv + 16) * sizeof(int), stream));
     EHR_HIP(hipMemsetAsync(sacc0, 0, 2 * 16 * (size_t)Qc * sizeof(unsigned long long), stream));
     EHR_HIP(hipMemsetAsync(score, 0, (size_t)Q * sizeof(long long), stream));
