@@ -68,10 +68,13 @@ def build_problem(rank, world, dev, eager=False, graph=True, workload=WORKLOAD):
     # reference masks = binarised ground-truth silhouettes rendered by the HIP path (no dataset offline)
     renderer = model._ensure_renderer()
     scene = model._ensure_scene()
-    with torch.no_grad():
+    with torch.no_grad():  # (on a context of its own, released afterwards: the solve's context holds what the solve needs)
+        tmp_ctx = dr.RasterizeCudaContext(dev)
         mvp_gt = fused.mvp_matrices(Kt, H, W, Tgt, lp)
-        gt_mask, _ = fused.render_mask_loss(renderer.glctx, scene, mvp_gt, torch.zeros((B, H, W), device=dev))
-    ref = (gt_mask > 0.5).float().contiguous()
+        gt_mask, _ = fused.render_mask_loss(tmp_ctx, scene, mvp_gt, torch.zeros((B, H, W), device=dev))
+        ref = (gt_mask > 0.5).float().contiguous()
+        torch.cuda.synchronize()
+        del tmp_ctx, gt_mask
     batch = {"mask": ref, "link_poses": lp, "K": Kt[None].repeat(B, 1, 1), "Tc_c2b": Tgt[None].repeat(B, 1, 1)}
     trainer = RBSolverTrainer(cfg, model, batch, fast=not eager, graph=graph)
     return dict(robot=robot, H=H, W=W, K=K, B=B, model=model, trainer=trainer, link_poses=link_poses, Tc_gt=Tc_gt,
@@ -378,7 +381,9 @@ def main():
                                        + ("ncclAllReduce on the chain's stream, library-owned RCCL communicator"
                                           if tr.fast is not None and tr.fast.rccl else "torch.distributed") + ")")
                        if world > 1 else "single GPU",
-                       "final_mask_loss": round(final_loss, 3)},
+                       "final_mask_loss": round(final_loss, 3),
+                       # device memory the solve's rasterizer context holds (job slots: one per view tile by default)
+                       "context_scratch_mb": round(p["glctx"].scratch_bytes() / 1048576.0, 1)},
             "roofline": {"bound": "hbm", "kernel": fused.DOMINANT_KERNEL, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          # the same algorithmic bytes over the WHOLE step (driver-timed value x bytes_frame): the honest

@@ -17,6 +17,7 @@ SIGNATURES = {
     "ehr_device_arch": (ctypes.c_char_p, [c_int]),
     "ehr_ctx_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     "ehr_ctx_destroy": (c_int, [c_void_p]),
+    "ehr_ctx_scratch_bytes": (c_size_t, [c_void_p]),
     "ehr_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p]),
     "ehr_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

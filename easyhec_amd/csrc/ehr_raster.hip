@@ -309,6 +309,16 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     return EHR_OK;
 }
 
+size_t ehr_ctx_scratch_bytes(ehr_ctx* c) {
+    if (!c) return 0;
+    size_t n = 0;
+    for (const Scratch* s : {&c->counts, &c->offsets, &c->entries, &c->vb_clus, &c->vb_heavy, &c->vb_idx, &c->vb_boxes, &c->vb_units,
+                             &c->vb_acc, &c->vb_posc, &c->vb_jobs, &c->vb_spill, &c->vb_refsum, &c->sc_counts, &c->sc_offsets,
+                             &c->sc_entries, &c->sc_posc, &c->sc_clus, &c->sc_misc})
+        n += s->cap;
+    return n;
+}
+
 int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
                       int T, int H, int W, float* rast, float* rast_db, void* stream_) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: ctx is NULL");

@@ -59,6 +59,10 @@ class RasterizeCudaContext:
     def handle(self):
         return self._h
 
+    def scratch_bytes(self):
+        """Device memory this context holds at the moment (``ehr_ctx_scratch_bytes``)."""
+        return int(_lib.lib().ehr_ctx_scratch_bytes(self._h))
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

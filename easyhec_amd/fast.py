@@ -22,7 +22,7 @@ def _f(x):
 
 class FusedPoseStep:
     def __init__(self, model, batch, lr=0.003, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0005, near=0.001, far=10.0,
-                 process_group=None, rccl=None):
+                 process_group=None, rccl=None, slack=None):
         self.model = model
         self.renderer = model._ensure_renderer()
         self.scene = model._ensure_scene()
@@ -73,7 +73,13 @@ class FusedPoseStep:
         self.loss = torch.zeros((1,), device=dev)
         self.grad = torch.zeros((6,), device=dev)
         self.mask = torch.empty((self.B, self.H, self.W), device=dev)
-        fused._ensure_plan(self.glctx, self.scene, self.B, self.H, self.W)
+        # job slots: `slack` per view tile instead of one per (view, link, tile) -- 100 MB instead of 0.8 GB of scratch at 8
+        # views 720p x 8 links; the workloads here use a sixth of that.  A view that needs more (every pixel under more
+        # than `slack` link boxes on average) is REPORTED -- NaN loss, dof and Adam state untouched -- and
+        # :meth:`recover_from_overflow` plans again with a slot for every (view, link, tile).  EHR_VB_SLACK overrides (0 = all).
+        import os
+        self.slack = float(os.environ.get("EHR_VB_SLACK", 1.0)) if slack is None else float(slack)
+        fused._ensure_plan(self.glctx, self.scene, self.B, self.H, self.W, slack=self.slack)
         # the reference masks are constants of the solve: cache the loss of the tiles no link touches once
         # (ehr_fused_bind_ref; bit-identical results).  self.ref is this object's private copy, never written to.
         fused.bind_ref(self.glctx, self.scene, self.ref)
@@ -170,6 +176,27 @@ class FusedPoseStep:
                 raise
             _lib.check(lib.ehr_graph_end(self.glctx.handle), "ehr_graph_end")
         self._graph = True
+
+    def recover_from_overflow(self):
+        """Call when a step's loss came back NaN.  Synchronises.  If the context reports an overflow and the plan was
+        slot-limited, plans again with a slot for every (view, link, tile), re-binds the reference masks, re-captures the
+        graph if there was one, and returns True: the steps since the overflow changed nothing (dof, Adam moments and step
+        counter stay untouched on a NaN), so the caller simply goes on stepping.  Raises on any other overflow."""
+        try:
+            fused.check_status(self.glctx)
+        except RuntimeError:
+            if self.slack == 0.0:
+                raise
+        else:
+            return False
+        had_graph = bool(self._graph)
+        self.release_graph()
+        self.slack = 0.0
+        fused._ensure_plan(self.glctx, self.scene, self.B, self.H, self.W, slack=0.0)
+        fused.bind_ref(self.glctx, self.scene, self.ref)
+        if had_graph:
+            self.capture()
+        return True
 
     def release_graph(self):
         if self._graph:

@@ -48,6 +48,7 @@ class _Plan:
 
     def __init__(self, glctx, scene, B, H, W, slack=0.0):
         self.key = _plan_key(scene, B, H, W)
+        self.slack = float(slack)
         with torch.cuda.device(glctx.device):
             _lib.check(_lib.lib().ehr_fused_plan(glctx.handle, B, scene.num_links, scene.num_verts, scene.num_tris, H, W,
                                                  ctypes.c_float(slack), _lib.ptr(scene.verts), _lib.ptr(scene.tris),
@@ -59,10 +60,15 @@ def _plan_key(scene, B, H, W):
     return (B, H, W, scene.num_links, scene.num_verts, scene.num_tris, scene.verts.data_ptr(), scene.tris.data_ptr())
 
 
-def _ensure_plan(glctx, scene, B, H, W):
+def _ensure_plan(glctx, scene, B, H, W, slack=None):
+    """slack: job slots per view tile (``ehr_fused_plan``); 0 = one per (view, link, tile), which can never overflow.  None
+    (the autograd path): a plan of this shape that exists is kept whatever its budget, a new one gets every slot (a NaN
+    gradient would poison torch's Adam); the launch chain of :class:`easyhec_amd.fast.FusedPoseStep` asks for 1 (an eighth
+    of the scratch at 8 links) and recovers from the reported overflow by planning again with 0."""
     plan = getattr(glctx, "_plan", None)
-    if plan is None or plan.key != _plan_key(scene, B, H, W):
-        glctx._plan = _Plan(glctx, scene, B, H, W)
+    same = plan is not None and plan.key == _plan_key(scene, B, H, W)
+    if not same or (slack is not None and getattr(plan, "slack", 0.0) != float(slack)):
+        glctx._plan = _Plan(glctx, scene, B, H, W, slack=0.0 if slack is None else slack)
         glctx._bound_ref = None  # ehr_fused_plan forgets a bound reference mask
 
 

@@ -198,7 +198,12 @@ class RBSolverTrainer:
             if do_log:
                 lv = float(loss)
                 if lv != lv and self.fast is not None:
-                    # the chain reports an internal overflow as NaN (and leaves dof / Adam state untouched): say why
+                    # the chain reports an internal overflow as NaN (and leaves dof / Adam state untouched): either the
+                    # slot-limited plan was too small -- planned again with every slot, the solve goes on -- or it says why
+                    if self.fast.recover_from_overflow():
+                        if log is not None:
+                            log(f"step {self.global_steps}: job slots overflowed; planned again with a slot per (view, link, tile)")
+                        continue
                     from . import fused
                     fused.check_status(self.fast.glctx)
                 history.append((self.global_steps, lv))

@@ -44,6 +44,8 @@ const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xna
 /* replaces dr.RasterizeCudaContext() -- nvdiffrast_renderer.py:23.  Owns binning scratch, grown on demand. */
 int ehr_ctx_create(int device, ehr_ctx** out);
 int ehr_ctx_destroy(ehr_ctx* ctx);
+/* Device memory the context holds at the moment (its scratch buffers; they grow on demand and are released with it). */
+size_t ehr_ctx_scratch_bytes(ehr_ctx* ctx);
 
 /* replaces dr.rasterize -- nvdiffrast_renderer.py:39.
  * instance mode (ranges_host == NULL): pos [B,V,4], every image draws all T triangles.

@@ -235,3 +235,19 @@ def test_fresh_optimiser_on_a_loaded_model_is_adam_step_one(xarm7, tmp_path):
     tr2.step()
     torch.cuda.synchronize()
     assert torch.equal(tr2.model.history_ops[:40], hist40)
+
+
+def test_default_solver_context_stays_under_100_mb_at_8_views_720p(xarm7):
+    """8 views x 8 links at 1280x720 used to reserve 0.8 GB of job slots (one per (view, link, tile))
+    for 17 MB touched; the launch chain now plans one slot per view tile."""
+    from easyhec_amd.fast import FusedPoseStep
+    cfg, make, batch = problem(xarm7, 8, 720, 1280, 1.0)
+    m = make()
+    f = FusedPoseStep(m, batch)
+    for _ in range(3):
+        f.step()
+    torch.cuda.synchronize()
+    from easyhec_amd import fused
+    fused.check_status(f.glctx)
+    mb = f.glctx.scratch_bytes() / 1048576.0
+    assert f.slack == 1.0 and mb <= 200.0, mb   # 100 MB of slots + records, clip-space vertices, hint tables, spill pool (16 MB)

@@ -494,6 +494,48 @@ def test_job_slots_limited_by_slack_report_overflow(env, xarm7):
     assert torch.isfinite(loss).all() and float(loss.min()) > 100.0   # (SSE against an empty reference = covered area)
 
 
+def test_default_launch_chain_recovers_from_a_slot_overflow(env, xarm7):
+    """the launch chain plans ONE job slot per view tile by default (100 MB instead of 0.8 GB at 8
+    views 720p x 8 links).  A close-up in which the links' boxes pile up needs more: the step reports it (NaN loss, dof and
+    Adam untouched), RBSolverTrainer.fit plans again with a slot per (view, link, tile) and goes on -- and the solve ends
+    exactly where a solve with every slot from the start ends."""
+    fused, _, scene, dev = env
+    from easyhec_amd.config import Cfg
+    from easyhec_amd.rb_solver import RBSolver
+    from easyhec_amd.trainer import RBSolverTrainer
+    H, W, B = 64, 96, 2
+    K, lp, Tc, mvp = workload(xarm7, H, W, 0.075, B, seed=3)
+    K = np.array(K, dtype=np.float64)
+    K[:2, :2] *= 2.5  # zoom: the robot fills the frame, the links' boxes overlap everywhere
+    cfg = Cfg()
+    cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
+    cfg.model.rbsolver.init_Tc_c2b = np.asarray(Tc).tolist()
+    cfg.solver.log_interval = 1
+    ref = torch.zeros((B, H, W), device=dev)
+    ref[:, 10:50, 20:70] = 1.0
+    batch = {"mask": ref, "link_poses": torch.tensor(lp, dtype=torch.float32, device=dev),
+             "K": torch.tensor(K, dtype=torch.float32, device=dev)[None].repeat(B, 1, 1)}
+    ends = []
+    for slack in (None, 0.0):
+        model = RBSolver(cfg, meshes=xarm7.meshes).to(dev)
+        tr = RBSolverTrainer(cfg, model, batch, fast=True)
+        if slack is not None:  # every slot from the start
+            tr.fast.slack = 0.0
+            fused._ensure_plan(tr.fast.glctx, tr.fast.scene, B, H, W, slack=0.0)
+            fused.bind_ref(tr.fast.glctx, tr.fast.scene, tr.fast.ref)
+        else:
+            assert tr.fast.slack == 1.0
+        logs = []
+        hist = tr.fit(num_steps=6 if slack is None else 5, log=logs.append)
+        if slack is None:
+            assert any("job slots overflowed" in l for l in logs), logs  # the first step was the reported one
+            assert tr.fast.slack == 0.0
+        assert all(np.isfinite(l) for _, l in hist[-5:])
+        ends.append((model.dof.detach().clone(), tr.fast.step_t.clone()))
+    assert int(ends[0][1]) == int(ends[1][1]) == 5            # five real Adam steps either way
+    assert torch.equal(ends[0][0], ends[1][0])                # ... to the same pose, bit for bit
+
+
 @pytest.mark.parametrize("H,W,scale,B", [(720, 1280, 1.0, 8), (100, 150, 0.12, 3)])
 def test_bound_reference_is_bit_identical(env, xarm7, H, W, scale, B):
     """ehr_fused_bind_ref caches, per tile, the fixed-point sum(ref^2) the composite stage would add for a tile no link
