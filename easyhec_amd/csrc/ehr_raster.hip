@@ -232,7 +232,7 @@ using namespace ehr;
 
 extern "C" {
 
-int ehr_version(void) { return 3; }
+int ehr_version(void) { return 4; }
 
 const char* ehr_last_error(void) { return g_last_error.c_str(); }
 

@@ -98,10 +98,15 @@ class _RasterizeFunc(torch.autograd.Function):
         ctx.save_for_backward(pos, tri, rast)
         ctx.range_mode = ranges is not None
         ctx.mark_non_differentiable(db)
+        # no gradient reaches `rast` on EasyHeC's path (the colour is constant, antialias returns none for it): without this
+        # autograd would materialise a zero image and run the backward kernel on it, per (view, link)
+        ctx.set_materialize_grads(False)
         return rast, db
 
     @staticmethod
     def backward(ctx, dy, ddb):
+        if dy is None:
+            return None, None, None, None, None, None
         pos, tri, rast = ctx.saved_tensors
         B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
         V, T = pos.shape[-2], tri.shape[0]

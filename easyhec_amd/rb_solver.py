@@ -82,10 +82,13 @@ class RBSolver(nn.Module):
         """The reference's own schedule (rb_solver.py:60-72): one rasterize / interpolate / antialias round trip per
         (frame, link) through the drop-in ops, links summed and clamped, SSE per frame, mean over frames."""
         per_frame_loss, per_frame_mask = [], []
+        # rb_solver.py:63 forms Tc_c2b @ link_poses[bid, link] inside the loop: one batched product for all (frame, link)
+        # pairs instead (the same 4-term dot products; one matmul and one backward node instead of B x L of each)
+        Tc_c2l = Tc_c2b[None, None] @ link_poses
         for frame in range(masks_ref.shape[0]):
             silhouettes = [
                 renderer.render_mask(getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}"), K=K,
-                                     object_pose=Tc_c2b @ link_poses[frame, k])
+                                     object_pose=Tc_c2l[frame, k])
                 for k in range(self.nlinks)
             ]
             composite = torch.stack(silhouettes).sum(0).clamp(max=1)
