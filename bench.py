@@ -223,6 +223,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="reference-shaped torch autograd step instead of the HIP launch chain")
     ap.add_argument("--workload", default=WORKLOAD, help="side measurements only; the headline is the default")
+    ap.add_argument("--no-with-mask", action="store_true", help="skip the with-mask leg (profiling runs: one launch form per kernel)")
     ap.add_argument("--no-side", action="store_true", help="skip the side workloads (the other BASELINE configs, ~0.5 s each)")
     ap.add_argument("--graph", action="store_true", help="replay the launch chain as a natively captured hipGraph (saves host time only)")
     args = ap.parse_args()
@@ -303,7 +304,7 @@ def main():
     # the same step WITH the rendered masks written (rb_solver.py:73-77 materialises `rendered_masks` every step): the
     # chain then streams every tile of every view (the bound reference's cached sums do not apply) and writes mask[B,H,W]
     with_mask_ms = None
-    if tr.fast is not None and world == 1:
+    if tr.fast is not None and world == 1 and not args.no_with_mask:
         mstep = lambda: tr.fast.step(want_mask=True)  # noqa: E731
         for _ in range(max(2, args.warmup // 4)):
             mstep()
