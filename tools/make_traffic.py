@@ -45,7 +45,7 @@ def main():
     rb = load_robot("xarm7")
     alg = algorithmic_bytes_per_frame(rb, H, W) * B
     G = 12 * rb.num_verts + 12 * rb.num_tris
-    out = {"round": 3, "commit": commit,
+    out = {"round": 4, "commit": commit,
            "launch_form": "ehr_solver_step, reference masks bound (ehr_fused_bind_ref), mask = NULL: what bench.py times",
            "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/step_bench.py ; the same with --pmc WRITE_SIZE "
                       "(separate passes, 8 views 1280x720 xArm7, mean of the last 100 launches of every kernel)",
