@@ -41,6 +41,25 @@ def test_hip_ops_and_fused_path_match_nvdiffrast_dump(capsys):
             mask, loss = fused.render_mask_loss(ctx, scene, tm, ref)
             loss.sum().backward()
             line, ok = C.score_fused(name, g, mask.detach().cpu().numpy(), loss.detach().cpu().numpy(), tm.grad.cpu().numpy())
+            if "pos_clip" in g.files:  # the strict one: the HIP three ops on the dump's own clip-space positions
+                voff = np.cumsum([0] + [v.shape[0] for v, _ in links])
+                ids = np.zeros_like(g["tri_ids"])
+                comp = torch.zeros((B, H, W), device=dev)
+                for b in range(B):
+                    acc = torch.zeros((H, W), device=dev)
+                    for l, (v, f_) in enumerate(links):
+                        pos = torch.tensor(np.ascontiguousarray(g["pos_clip"][b, voff[l]:voff[l + 1]])[None], device=dev)
+                        tf = torch.tensor(f_, device=dev)
+                        rast, _ = dr.rasterize(ctx, pos, tf, [H, W])
+                        col, _ = dr.interpolate(torch.ones((1, v.shape[0], 3), device=dev), rast, tf)
+                        aa = dr.antialias(col, rast, pos, tf)
+                        ids[b, l] = rast[0, :, :, 3].cpu().numpy()
+                        acc = acc + torch.flip(aa[0, :, :, 0], dims=[0])
+                    comp[b] = acc.clamp(max=1)
+                line2, ok2 = C.score_links(name, g, ids, comp.cpu().numpy())
+                lines.append(("ok   " if ok2 else "DIFF ") + line2)
+                if not ok2:
+                    bad.append(name + " (links)")
         lines.append(("ok   " if ok else "DIFF ") + line)
         if not ok:
             bad.append(name)

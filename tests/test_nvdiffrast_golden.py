@@ -38,6 +38,23 @@ def test_oracle_matches_nvdiffrast_dump(oracle, capsys):
             ref = np.unpackbits(g["ref"])[:B * H * W].reshape(B, H, W).astype(np.float32)
             mask, loss, gm = oracle.render_mask_loss(verts, tris, toff, voff, g["mvp"], ref)
             line, ok = C.score_fused(name, g, mask, loss, gm)
+            if "pos_clip" in g.files:  # the strict one: the oracle's three ops on the dump's own clip-space positions
+                ids = np.zeros_like(g["tri_ids"])
+                comp = np.zeros((B, H, W), np.float32)
+                for b in range(B):
+                    acc = np.zeros((H, W), np.float32)
+                    for l, (v, f_) in enumerate(links):
+                        pos = np.ascontiguousarray(g["pos_clip"][b, voff[l]:voff[l + 1]])
+                        rast, _ = oracle.rasterize(pos[None], f_, [H, W])
+                        col = oracle.interpolate(np.ones((1, v.shape[0], 3), np.float32), rast, f_)
+                        aa = oracle.antialias(col, rast, pos[None], f_)
+                        ids[b, l] = rast[0, :, :, 3]
+                        acc = acc + aa[0, ::-1, :, 0]
+                    comp[b] = np.minimum(acc, 1.0)
+                line2, ok2 = C.score_links(name, g, ids, comp)
+                lines.append(("ok   " if ok2 else "DIFF ") + line2)
+                if not ok2:
+                    bad.append(name + " (links)")
         lines.append(("ok   " if ok else "DIFF ") + line)
         if not ok:
             bad.append(name)

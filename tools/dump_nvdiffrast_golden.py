@@ -84,6 +84,7 @@ def link_masks(dr, link_meshes, mvp, ref, H, W):
     tm = torch.tensor(mvp, device=dev, requires_grad=True)
     tref = torch.tensor(ref, device=dev)
     masks, ids = [], np.zeros((B, L, H, W), np.float32)
+    clip = [[None] * L for _ in range(B)]
     for b in range(B):
         per_link = []
         for l, (v, f) in enumerate(link_meshes):
@@ -96,12 +97,18 @@ def link_masks(dr, link_meshes, mvp, ref, H, W):
             col = dr.antialias(col, rast, pos_clip, tf)
             per_link.append(torch.flip(col[0, :, :, 0], dims=[0]))
             ids[b, l] = rast[0, :, :, 3].detach().cpu().numpy()
+            clip[b][l] = pos_clip[0].detach().cpu().numpy()
         masks.append(torch.stack(per_link).sum(0).clamp(max=1))
     mask = torch.stack(masks)
     loss_b = ((mask - tref) ** 2).sum(dim=(1, 2))
     loss_b.sum().backward()
+    # the clip-space positions torch.matmul produced here (cuBLAS rounds the 4-term dot products its own way): with them a
+    # consumer can run its three ops on IDENTICAL inputs -- renderer semantics apart from GEMM rounding, which alone flips
+    # isolated razor-edge pixels (this repo's fused path transforms with an fma chain; its own three ops fed by torch.matmul
+    # differ from it at 1 pixel of 38 400 on the 160x120 fixture)
+    pos_clip_all = np.stack([np.concatenate(clip[b], axis=0) for b in range(B)])
     return {"mask": mask.detach().cpu().numpy(), "loss": loss_b.detach().cpu().numpy(), "grad_mvp": tm.grad.cpu().numpy(),
-            "tri_ids": ids}
+            "tri_ids": ids, "pos_clip": pos_clip_all}
 
 
 def load_links(name):
