@@ -317,7 +317,8 @@ def main():
         side = {}
         for name in ("xarm7_640x480_1view", "franka_1920x1080_16view", "xarm7_1280x720_64view"):
             try:
-                side[name] = side_workload(name, dev, max(10, args.steps // 2), max(5, args.warmup // 2))
+                # (its own step counts: a side measurement is bounded by time -- ~0.1-0.2 s of GPU work each --, not by the driver's --steps)
+                side[name] = side_workload(name, dev, 100, 30, min_ms=40.0)
             except Exception as e:  # a side measurement must never cost the headline line
                 side[name] = {"error": f"{type(e).__name__}: {e}"}
 
