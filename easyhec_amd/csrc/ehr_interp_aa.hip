@@ -173,8 +173,11 @@ static unsigned topo_slots(int T) {
 #define AA_FLAG_TRI1 8
 #define AA_FLAG_BLEND 16
 
+// (also copies color -> out, pixel by pixel, when they differ: the blend kernel that follows accumulates into out; a copy
+//  kernel of its own was one more launch per (view, link) image)
 __global__ void __launch_bounds__(256) aa_discover_kernel(const float4* __restrict__ rast, int B, int H, int W,
-                                                          int4* __restrict__ work) {
+                                                          int4* __restrict__ work, const float* __restrict__ color,
+                                                          float* __restrict__ out, int C) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t P = (size_t)H * W;
     bool in = idx < P * B;
@@ -185,6 +188,8 @@ __global__ void __launch_bounds__(256) aa_discover_kernel(const float4* __restri
         int rem = (int)(idx - (size_t)b * P);
         py = rem / W;
         px = rem - py * W;
+        if (out != color)
+            for (int c = 0; c < C; c++) out[idx * C + c] = color[idx * C + c];
         float t0 = rast[idx].w;
         if (px + 1 < W) hit0 = rast[idx + 1].w != t0;
         if (py + 1 < H) hit1 = rast[idx + W].w != t0;
@@ -271,9 +276,11 @@ __global__ void __launch_bounds__(256) aa_grad_kernel(const float* __restrict__ 
             float gk = g[k];
             if (gk != 0.f) {
                 dd += gk * (c1[k] - c0[k]);
-                float v = alpha * gk;
-                atomicAdd(&grad_color[pix0 * C + k], -v);
-                atomicAdd(&grad_color[pix1 * C + k], v);
+                if (grad_color) {
+                    float v = alpha * gk;
+                    atomicAdd(&grad_color[pix0 * C + k], -v);
+                    atomicAdd(&grad_color[pix1 * C + k], v);
+                }
             }
         }
         if (dd == 0.f) continue;
@@ -361,9 +368,8 @@ int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, c
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
     int rc;
-    if (out != color && (rc = copy_words(out, color, n * C, stream))) return rc;
     if ((rc = zero_words(work, 4, stream))) return rc;
-    aa_discover_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)rast, B, H, W, (int4*)work);
+    aa_discover_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)rast, B, H, W, (int4*)work, color, out, C);
     EHR_LAUNCH_CHECK();
     aa_mesh_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp, range_mode, V, T,
                                              H, W, C, out, (int4*)work);
@@ -374,13 +380,13 @@ int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, c
 int ehr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
                        const void* work, int range_mode, int B, int V, int T, int H, int W, int C, float* grad_color,
                        float* grad_pos, void* stream_) {
-    if (!color || !rast || !pos || !tri || !dy || !work || !grad_color || !grad_pos)
+    if (!color || !rast || !pos || !tri || !dy || !work || !grad_pos)  // (grad_color may be NULL: the caller does not need it)
         return fail(EHR_ERR_INVALID, "ehr_antialias_grad: NULL tensor");
     hipStream_t stream = (hipStream_t)stream_;
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
     int rc;
-    if ((rc = copy_words(grad_color, dy, n * C, stream))) return rc;
+    if (grad_color && (rc = copy_words(grad_color, dy, n * C, stream))) return rc;
     aa_grad_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, dy, (const int4*)work,
                                              range_mode, V, T, H, W, C, grad_color, grad_pos);
     EHR_LAUNCH_CHECK();

@@ -244,7 +244,9 @@ class _AntialiasFunc(torch.autograd.Function):
         V, T = pos.shape[-2], tri.shape[0]
         range_mode = int(pos.dim() == 2)
         dy = dy.contiguous()
-        g_color = torch.empty_like(color)
+        # (EasyHeC's colour is interpolated from constant attributes: nothing asks for its gradient, and the full-image copy
+        #  of dy it starts from is a kernel per (view, link))
+        g_color = torch.empty_like(color) if ctx.needs_input_grad[0] else None
         g_pos = torch.zeros_like(pos)
         with torch.cuda.device(color.device):
             _lib.check(_lib.lib().ehr_antialias_grad(_lib.ptr(color), _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri),

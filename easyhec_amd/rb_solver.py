@@ -82,16 +82,22 @@ class RBSolver(nn.Module):
         """The reference's own schedule (rb_solver.py:60-72): one rasterize / interpolate / antialias round trip per
         (frame, link) through the drop-in ops, links summed and clamped, SSE per frame, mean over frames."""
         per_frame_loss, per_frame_mask = [], []
-        # rb_solver.py:63 forms Tc_c2b @ link_poses[bid, link] inside the loop: one batched product for all (frame, link)
-        # pairs instead (the same 4-term dot products; one matmul and one backward node instead of B x L of each)
-        Tc_c2l = Tc_c2b[None, None] @ link_poses
+        # The reference's schedule -- one rasterize / interpolate / antialias round trip per (frame, link) -- with the
+        # small host-side products around it batched (results are the same dot products; the step is bound by its number
+        # of launches, ~2 400 of them): rb_solver.py:63's Tc_c2b @ link_poses[bid, link] and nvdiffrast_renderer.py:35-37's
+        # proj @ opencv2blender @ pose as two batched products for all (frame, link) pairs, transform_pos as one product per
+        # link for all frames, and the vertical flip (nvdiffrast_renderer.py:47: a permutation, it commutes with the sum
+        # over links and the clamp) once per frame instead of once per link.
+        mvp_all = renderer.clip_matrices(K, Tc_c2b[None, None] @ link_poses)          # [B, L, 4, 4]
+        pos_all = [renderer.clip_positions_batched(mvp_all[:, k], getattr(self, f"vertices_{k}"))  # [B, V_k, 4] each
+                   for k in range(self.nlinks)]
         for frame in range(masks_ref.shape[0]):
             silhouettes = [
-                renderer.render_mask(getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}"), K=K,
-                                     object_pose=Tc_c2l[frame, k])
+                renderer.mask_from_clip(pos_all[k][frame][None], getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}"),
+                                        flip=False)
                 for k in range(self.nlinks)
             ]
-            composite = torch.stack(silhouettes).sum(0).clamp(max=1)
+            composite = torch.flip(torch.stack(silhouettes).sum(0).clamp(max=1), dims=[0])
             per_frame_mask.append(composite)
             per_frame_loss.append(((composite - masks_ref[frame].float()) ** 2).sum())
         return torch.stack(per_frame_mask), torch.stack(per_frame_loss).mean()

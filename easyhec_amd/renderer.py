@@ -69,6 +69,22 @@ class NVDiffrastRenderer:
         pos_clip = self._clip_positions(po @ object_pose, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
+    # -- batched forms of the per-call products (used by RBSolver's three-op schedule; same arithmetic per element) ----
+    def clip_matrices(self, K, object_poses):
+        """proj(K) @ opencv2blender @ object_poses for a [..., 4, 4] batch of camera<-object poses."""
+        po = self._cached("po", K, lambda: self._projection(K, object_poses.device) @ self.opencv2blender)
+        return po @ object_poses
+
+    def clip_positions_batched(self, mtx, verts):
+        """transform_pos for a batch of matrices [B, 4, 4] over one vertex array [V, 3] -> [B, V, 4]."""
+        posw = self._cached("posw", verts, lambda: torch.cat(
+            [verts, torch.ones([verts.shape[0], 1], dtype=verts.dtype, device=verts.device)], dim=1))
+        return torch.matmul(posw[None], mtx.transpose(1, 2))
+
+    def mask_from_clip(self, pos_clip, verts, faces, anti_aliasing=True, flip=True):
+        """rasterize -> interpolate(ones) -> antialias on given clip-space positions [1, V, 4] (the body of render_mask)."""
+        return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing, flip=flip)
+
     def batch_render_mask(self, verts, faces, K, anti_aliasing=True):
         """Vertices already in the camera frame (nvdiffrast_renderer.py:49-72)."""
         proj = self._projection(K, verts.device)
@@ -76,7 +92,7 @@ class NVDiffrastRenderer:
         pos_clip = self._clip_positions(proj @ pose, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
-    def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing):
+    def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing, flip=True):
         rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution)
         if anti_aliasing:
             vtx_color = self._cached("ones", verts, lambda: torch.ones((1,) + tuple(verts.shape), dtype=torch.float,
@@ -89,5 +105,6 @@ class NVDiffrastRenderer:
             mask = color[0, :, :, 0]
         else:
             mask = rast_out[0, :, :, 2] > 0
-        mask = torch.flip(mask, dims=[0])
+        if flip:
+            mask = torch.flip(mask, dims=[0])
         return mask

@@ -81,7 +81,7 @@ int ehr_antialias_topology(const int32_t* tri, int T, int32_t* opp, void* scratc
 size_t ehr_antialias_work_bytes(int B, int H, int W);
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                       int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work, void* stream);
-/* grad_color [B,H,W,C] is overwritten; grad_pos (pos's shape) is ACCUMULATED into (caller zero-fills). */
+/* grad_color [B,H,W,C] is overwritten (may be NULL: not wanted); grad_pos (pos's shape) is ACCUMULATED into (caller zero-fills). */
 int ehr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
                        const void* work, int range_mode, int B, int V, int T, int H, int W, int C, float* grad_color,
                        float* grad_pos, void* stream);
