@@ -71,7 +71,11 @@ int vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int3
 struct ehr_ctx {
     int device = 0;
     // bin queues: counts/cursors/offsets are indexed by (image, tile, link)
-    ehr::Scratch counts;    // int32 [2 * nkeys + 4]: counts | cursors | {total, overflow, nonempty, pad}
+    ehr::Scratch counts;    // int32 [2 * nkeys + 48]: counts | cursors | meta {total, overflow, nonempty, ...}.  ALL ZERO between
+                            // calls: the last kernel of a drop-in rasterize call zeroes every word the call dirtied
+                            // (a fill kernel per call was a tenth of the three-op step's launches)
+    unsigned long long counts_clean = ~0ull;  // == counts.moves: the buffer is known to be all zero
+    ehr::Scratch ranges;    // int32 [2 * B]: the per-image triangle ranges of a range-mode call
     ehr::Scratch offsets;   // int32 [nkeys]
     ehr::Scratch entries;   // int32 [entries_cap]
     size_t entries_cap = 0; // in entries

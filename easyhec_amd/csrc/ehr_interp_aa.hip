@@ -167,100 +167,140 @@ static unsigned topo_slots(int T) {
 
 // ---- antialias ---------------------------------------------------------------------------------------------------
 
-// work buffer: int4 header {count, 0, 0, 0} followed by int4 items {px, py, flags, alpha bits}
-// flags: bits 0-1 di, bit 2 d (vertical pair), bit 3 chosen triangle is pixel1's, bit 4 blended, bits 16.. image
+// work buffer (forward -> backward): one SEGMENT per workgroup of the forward kernel (256 pixels): int4 header
+// {count, 0, 0, 0} followed by up to 512 int4 items {px, py, flags, alpha bits} -- the BLENDED pairs whose first pixel
+// the workgroup owns.  Every workgroup writes its own header, so nothing has to be zeroed beforehand.
+// flags: bits 0-1 di, bit 2 d (vertical pair), bit 3 chosen triangle is pixel1's, bits 16.. image
 #define AA_FLAG_D 4
 #define AA_FLAG_TRI1 8
-#define AA_FLAG_BLEND 16
+constexpr int AA_SEG = 513;  // int4 per segment
 
-// (also copies color -> out, pixel by pixel, when they differ: the blend kernel that follows accumulates into out; a copy
-//  kernel of its own was one more launch per (view, link) image)
-__global__ void __launch_bounds__(256) aa_discover_kernel(const float4* __restrict__ rast, int B, int H, int W,
-                                                          int4* __restrict__ work, const float* __restrict__ color,
-                                                          float* __restrict__ out, int C) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t P = (size_t)H * W;
-    bool in = idx < P * B;
-    int b = 0, px = 0, py = 0;
-    bool hit0 = false, hit1 = false;
-    if (in) {
-        b = (int)(idx / P);
-        int rem = (int)(idx - (size_t)b * P);
-        py = rem / W;
-        px = rem - py * W;
-        if (out != color)
-            for (int c = 0; c < C; c++) out[idx * C + c] = color[idx * C + c];
-        float t0 = rast[idx].w;
-        if (px + 1 < W) hit0 = rast[idx + 1].w != t0;
-        if (py + 1 < H) hit1 = rast[idx + W].w != t0;
+// One pixel pair (pix0 = (px, py) of image b, pix1 = its right (d = 0) or upper (d = 1) neighbour) whose triangle ids
+// differ: pick the nearer triangle, find the silhouette edge that crosses between the two pixel centres.
+struct AAHit {
+    bool found;
+    float alpha;
+    int flags;  // di | AA_FLAG_TRI1
+};
+__device__ __forceinline__ AAHit aa_pair(const float4* __restrict__ rast, const float4* __restrict__ pos,
+                                         const int32_t* __restrict__ tri, const int32_t* __restrict__ opp, int range_mode,
+                                         int V, int T, int H, int W, size_t P, int b, int px, int py, int d) {
+    AAHit h;
+    h.found = false;
+    h.alpha = 0.f;
+    h.flags = 0;
+    const size_t pix0 = (size_t)b * P + (size_t)py * W + px;
+    const size_t pix1 = pix0 + (d ? (size_t)W : 1);
+    const float4 r0 = rast[pix0], r1 = rast[pix1];
+    const int tri0 = float_to_tri(r0.w) - 1, tri1 = float_to_tri(r1.w) - 1;
+    int t = (tri0 >= 0) ? tri0 : tri1;
+    if (tri0 >= 0 && tri1 >= 0) t = (r0.z < r1.z) ? tri0 : tri1;
+    const bool chose0 = !(t == tri1);
+    int cx = px, cy = py;
+    if (!chose0) {
+        cx += 1 - d;
+        cy += d;
     }
-    // wave-level compaction: ballot + prefix popcount, one atomic per wave
-    u64 m0 = __ballot(hit0), m1 = __ballot(hit1);
-    int n0 = __popcll(m0), n1 = __popcll(m1);
-    int lane = lane_id();
-    int base = 0;
-    if (lane == 0 && (n0 + n1) > 0) base = atomicAdd(&work[0].x, n0 + n1);
-    base = __shfl(base, 0, 64);
-    u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (hit0) work[1 + base + __popcll(m0 & below)] = make_int4(px, py, b << 16, 0);
-    if (hit1) work[1 + base + n0 + __popcll(m1 & below)] = make_int4(px, py, (b << 16) | AA_FLAG_D, 0);
-}
-
-__global__ void __launch_bounds__(256) aa_mesh_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
-                                                      const float4* __restrict__ pos, const int32_t* __restrict__ tri,
-                                                      const int32_t* __restrict__ opp, int range_mode, int V, int T,
-                                                      int H, int W, int C, float* __restrict__ out,
-                                                      int4* __restrict__ work) {
-    const int count = work[0].x;
-    size_t P = (size_t)H * W;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        int4 item = work[1 + i];
-        int px = item.x, py = item.y, b = item.z >> 16, d = (item.z & AA_FLAG_D) ? 1 : 0;
-        size_t pix0 = (size_t)b * P + (size_t)py * W + px;
-        size_t pix1 = pix0 + (d ? (size_t)W : 1);
-        float4 r0 = rast[pix0], r1 = rast[pix1];
-        int tri0 = float_to_tri(r0.w) - 1, tri1 = float_to_tri(r1.w) - 1;
-        int t = (tri0 >= 0) ? tri0 : tri1;
-        if (tri0 >= 0 && tri1 >= 0) t = (r0.z < r1.z) ? tri0 : tri1;
-        bool chose0 = !(t == tri1);
-        int cx = px, cy = py;
-        if (!chose0) {
-            cx += 1 - d;
-            cy += d;
-        }
-        if (t < 0 || t >= T) continue;
-        int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
-        if ((unsigned)vi[0] >= (unsigned)V || (unsigned)vi[1] >= (unsigned)V || (unsigned)vi[2] >= (unsigned)V) continue;
-        const float4* pb = pos + (range_mode ? 0 : (size_t)b * V);
-        float4 p[3], o[3];
+    if (t < 0 || t >= T) return h;
+    const int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    if ((unsigned)vi[0] >= (unsigned)V || (unsigned)vi[1] >= (unsigned)V || (unsigned)vi[2] >= (unsigned)V) return h;
+    const float4* pb = pos + (range_mode ? 0 : (size_t)b * V);
+    float4 p[3], o[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            p[k] = pb[vi[k]];
-            int ov = opp[3 * t + k];
-            o[k] = ((unsigned)ov < (unsigned)V) ? pb[ov] : p[k];
-        }
-        AAPair a = aa_analyze(p, o, cx, cy, d, chose0, W, H);
-        if (!a.found) continue;
-        const float* c0 = color + pix0 * C;
-        const float* c1 = color + pix1 * C;
-        float* dst = out + (a.alpha > 0.f ? pix0 : pix1) * C;
-        for (int k = 0; k < C; k++) atomicAdd(&dst[k], a.alpha * (c1[k] - c0[k]));
-        item.z |= a.di | (a.tri1 ? AA_FLAG_TRI1 : 0) | AA_FLAG_BLEND;
-        item.w = __float_as_int(a.alpha);
-        work[1 + i] = item;
+    for (int k = 0; k < 3; k++) {
+        p[k] = pb[vi[k]];
+        const int ov = opp[3 * t + k];
+        o[k] = ((unsigned)ov < (unsigned)V) ? pb[ov] : p[k];
     }
+    const AAPair a = aa_analyze(p, o, cx, cy, d, chose0, W, H);
+    if (!a.found) return h;
+    h.found = true;
+    h.alpha = a.alpha;
+    h.flags = a.di | (a.tri1 ? AA_FLAG_TRI1 : 0);
+    return h;
 }
 
+// The whole forward pass in ONE launch, one thread per pixel, gathering instead of scattering: a pixel's output is its
+// colour plus the blends of the (up to four) pairs it belongs to that land on it -- its own right / upper pair when
+// alpha > 0, its left / lower neighbour's pair when alpha <= 0 -- added in a fixed order (no atomics: the result is
+// bit-reproducible and equals a serial sweep's, bit for bit; the pair analysis runs twice, once from either side, on the
+// few thousand silhouette pixels of an image).  Round 3 had three launches here (zero the list's counter, discover the pairs + copy the colour, analyse and
+// scatter with float atomics).
+__global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
+                                                     const float4* __restrict__ pos, const int32_t* __restrict__ tri,
+                                                     const int32_t* __restrict__ opp, int range_mode, int B, int V, int T,
+                                                     int H, int W, int C, float* __restrict__ out,
+                                                     int4* __restrict__ work) {
+    __shared__ int s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t P = (size_t)H * W;
+    int4* const seg = work + (size_t)blockIdx.x * AA_SEG;
+    if (idx < P * B) {
+        const int b = (int)(idx / P);
+        const int rem = (int)(idx - (size_t)b * P);
+        const int py = rem / W, px = rem - py * W;
+        const float t0 = rast[idx].w;
+        // the four pairs this pixel belongs to: {first pixel, d, does this pixel own it}
+        const bool hasR = px + 1 < W && rast[idx + 1].w != t0;
+        const bool hasU = py + 1 < H && rast[idx + W].w != t0;
+        const bool hasL = px > 0 && rast[idx - 1].w != t0;
+        const bool hasD = py > 0 && rast[idx - W].w != t0;
+        float alpha[4] = {0.f, 0.f, 0.f, 0.f};
+        size_t other[4] = {idx, idx, idx, idx};
+        if (hasR) {
+            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px, py, 0);
+            if (h.found && h.alpha != 0.f) {
+                seg[1 + atomicAdd(&s_count, 1)] = make_int4(px, py, (b << 16) | h.flags, __float_as_int(h.alpha));
+                if (h.alpha > 0.f) alpha[0] = h.alpha, other[0] = idx + 1;  // lands on pix0 = this pixel: a (c1 - c0)
+            }
+        }
+        if (hasU) {
+            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px, py, 1);
+            if (h.found && h.alpha != 0.f) {
+                seg[1 + atomicAdd(&s_count, 1)] = make_int4(px, py, (b << 16) | AA_FLAG_D | h.flags, __float_as_int(h.alpha));
+                if (h.alpha > 0.f) alpha[1] = h.alpha, other[1] = idx + W;
+            }
+        }
+        if (hasL) {  // pair (left neighbour, this pixel): lands here (pix1) when alpha <= 0: a (c1 - c0) = -a (c_left - c_this)
+            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px - 1, py, 0);
+            if (h.found && !(h.alpha > 0.f)) alpha[2] = h.alpha, other[2] = idx - 1;
+        }
+        if (hasD) {
+            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px, py - 1, 1);
+            if (h.found && !(h.alpha > 0.f)) alpha[3] = h.alpha, other[3] = idx - W;
+        }
+        for (int k = 0; k < C; k++) {
+            const float c = color[idx * C + k];
+            float v = c;
+            // every term is alpha (c1 - c0) of its pair: this pixel is pix1 of its neighbours' pairs, pix0 of its own.
+            // Order = the pairs' order in a sweep over first pixels, horizontal before vertical (the oracle's, and a
+            // serial implementation's): lower neighbour's vertical pair, left neighbour's horizontal one, own two.
+            if (alpha[3] != 0.f) v += alpha[3] * (c - color[other[3] * C + k]);
+            if (alpha[2] != 0.f) v += alpha[2] * (c - color[other[2] * C + k]);
+            if (alpha[0] != 0.f) v += alpha[0] * (color[other[0] * C + k] - c);
+            if (alpha[1] != 0.f) v += alpha[1] * (color[other[1] * C + k] - c);
+            out[idx * C + k] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) seg[0] = make_int4(s_count, 0, 0, 0);
+}
+
+// backward: one wave per segment of the forward pass's list
 __global__ void __launch_bounds__(256) aa_grad_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
                                                       const float4* __restrict__ pos, const int32_t* __restrict__ tri,
-                                                      const float* __restrict__ dy, const int4* __restrict__ work,
+                                                      const float* __restrict__ dy, const int4* __restrict__ work, int nseg,
                                                       int range_mode, int V, int T, int H, int W, int C,
                                                       float* __restrict__ grad_color, float* __restrict__ grad_pos) {
-    const int count = work[0].x;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= nseg) return;
+    const int4* const seg = work + (size_t)s * AA_SEG;
+    const int count = seg[0].x;
     size_t P = (size_t)H * W;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        int4 item = work[1 + i];
-        if (!(item.z & AA_FLAG_BLEND)) continue;
+    for (int i = threadIdx.x & 63; i < count; i += 64) {
+        int4 item = seg[1 + i];
         float alpha = __int_as_float(item.w);
         if (alpha == 0.f) continue;
         int px = item.x, py = item.y, b = item.z >> 16, d = (item.z & AA_FLAG_D) ? 1 : 0;
@@ -357,22 +397,20 @@ int ehr_antialias_topology(const int32_t* tri, int T, int32_t* opp, void* scratc
     return EHR_OK;
 }
 
-size_t ehr_antialias_work_bytes(int B, int H, int W) { return ((size_t)2 * B * H * W + 1) * sizeof(int4); }
+static size_t aa_segments(int B, int H, int W) { return ((size_t)B * H * W + 255) / 256; }
+size_t ehr_antialias_work_bytes(int B, int H, int W) { return std::max<size_t>(aa_segments(B, H, W), 1) * AA_SEG * sizeof(int4); }
 
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                       int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work, void* stream_) {
     if (!color || !rast || !pos || !tri || !opp || !out || !work)
         return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: NULL tensor");
+    if (out == color) return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: out must not alias color (every pixel reads its neighbours' colours)");
     if (B >= 32768) return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: batch too large");
     hipStream_t stream = (hipStream_t)stream_;
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
-    int rc;
-    if ((rc = zero_words(work, 4, stream))) return rc;
-    aa_discover_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)rast, B, H, W, (int4*)work, color, out, C);
-    EHR_LAUNCH_CHECK();
-    aa_mesh_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp, range_mode, V, T,
-                                             H, W, C, out, (int4*)work);
+    aa_fwd_kernel<<<(unsigned)aa_segments(B, H, W), 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp,
+                                                                      range_mode, B, V, T, H, W, C, out, (int4*)work);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }
@@ -387,8 +425,9 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
     if (n == 0) return EHR_OK;
     int rc;
     if (grad_color && (rc = copy_words(grad_color, dy, n * C, stream))) return rc;
-    aa_grad_kernel<<<1024, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, dy, (const int4*)work,
-                                             range_mode, V, T, H, W, C, grad_color, grad_pos);
+    const int nseg = (int)aa_segments(B, H, W);
+    aa_grad_kernel<<<(nseg + 3) / 4, 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, dy, (const int4*)work,
+                                                       nseg, range_mode, V, T, H, W, C, grad_color, grad_pos);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

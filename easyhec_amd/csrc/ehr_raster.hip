@@ -77,12 +77,12 @@ int copy_words(void* dst, const void* src, size_t nwords, hipStream_t stream) {
 // for every pixel of the tile.
 template <bool WITH_DB>
 __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSource src, BinGeom g,
-                                                                      const int* __restrict__ counts,
+                                                                      int* __restrict__ counts,
                                                                       const int* __restrict__ offsets,
                                                                       const int4* __restrict__ entries, int entries_cap,
                                                                       float4* __restrict__ rast,
                                                                       float4* __restrict__ rast_db,
-                                                                      const int* __restrict__ meta) {
+                                                                      int* __restrict__ meta) {
     __shared__ u64 key[EHR_TILE_W * EHR_TILE_H];
     __shared__ BlockRaster wscratch;
     const int tile = blockIdx.x, b = blockIdx.y;
@@ -94,6 +94,13 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
     const int n = counts[kidx];
     const int off = offsets[kidx];
     __syncthreads();
+    // this launch is the last reader of the call's counters: leave them zero for the next call (its own queue's count
+    // and fill cursor; workgroup 0 the meta words), so that no call has to start with a fill kernel
+    if (tid == 0) {
+        counts[kidx] = 0;
+        counts[gridDim.x * gridDim.y + kidx] = 0;  // cursors = counts + nkeys
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 8) meta[tid] = 0;
     if (off + n <= entries_cap) {
         if (n > 0) raster_queue<EHR_TILE_W, EHR_TILE_H, true>(src, b, entries + off, n, g.W, g.H, rx0, ry0, key, &wscratch, nullptr, RoundZero());
     } else {
@@ -280,6 +287,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(c->device);
     c->counts.release();
+    c->ranges.release();
     c->offsets.release();
     c->entries.release();
     c->sc_counts.release();
@@ -312,7 +320,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
 size_t ehr_ctx_scratch_bytes(ehr_ctx* c) {
     if (!c) return 0;
     size_t n = 0;
-    for (const Scratch* s : {&c->counts, &c->offsets, &c->entries, &c->vb_clus, &c->vb_heavy, &c->vb_idx, &c->vb_boxes, &c->vb_units,
+    for (const Scratch* s : {&c->counts, &c->ranges, &c->offsets, &c->entries, &c->vb_clus, &c->vb_heavy, &c->vb_idx, &c->vb_boxes, &c->vb_units,
                              &c->vb_acc, &c->vb_posc, &c->vb_jobs, &c->vb_spill, &c->vb_refsum, &c->sc_counts, &c->sc_offsets,
                              &c->sc_entries, &c->sc_posc, &c->sc_clus, &c->sc_misc})
         n += s->cap;
@@ -335,7 +343,8 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     g.L = 1;
     const int nkeys = B * g.nt;
     int rc;
-    if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + EHR_META_INTS + (ranges_host ? 2 * (size_t)B : 0)) * sizeof(int)))) return rc;
+    if ((rc = ctx->counts.reserve(((size_t)2 * nkeys + EHR_META_INTS) * sizeof(int)))) return rc;
+    if (ranges_host && (rc = ctx->ranges.reserve(2 * (size_t)B * sizeof(int)))) return rc;
     if ((rc = ctx->offsets.reserve((size_t)nkeys * sizeof(int)))) return rc;
     if (ctx->entries_cap == 0) {
         // (EHR_RASTER_MIN_ENTRIES: test hook for the undersized-storage path; default floor 1 M entries = 16 MB)
@@ -351,7 +360,7 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     int2* ranges_dev = nullptr;
     int tmax = T;
     if (ranges_host) {
-        ranges_dev = (int2*)(meta + EHR_META_INTS);
+        ranges_dev = (int2*)ctx->ranges.ptr;
         EHR_HIP(hipMemcpyAsync(ranges_dev, ranges_host, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
         tmax = 0;
         for (int b = 0; b < B; b++) tmax = std::max(tmax, ranges_host[2 * b + 1]);
@@ -367,7 +376,12 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     src.L = 1;
     src.image_stride = ranges_host ? 0 : V;
 
-    if ((rc = zero_words(counts, (size_t)2 * nkeys + 8, stream))) return rc;
+    // counts | cursors | meta are all zero between calls (raster_tile_kernel, the last kernel below, zeroes what a call
+    // dirtied); only a fresh or moved buffer, or one a failed call left behind, is cleared here.
+    if (ctx->counts_clean != ctx->counts.moves) {
+        if ((rc = zero_words(counts, ctx->counts.cap / sizeof(int), stream))) return rc;
+    }
+    ctx->counts_clean = ~0ull;  // (until this call's last kernel is enqueued)
     dim3 bgrid((tmax + 255) / 256, B);
     if (tmax > 0) {
         bin_kernel<0, false><<<bgrid, 256, 0, stream>>>(src, g, counts, cursors, offsets, nullptr, 0, meta, nullptr);
@@ -429,6 +443,7 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
         raster_tile_kernel<false><<<tgrid, EHR_TILE_THREADS, 0, stream>>>(src, g, counts, offsets, entries, ecap,
                                                                          (float4*)rast, nullptr, meta);
     EHR_LAUNCH_CHECK();
+    ctx->counts_clean = ctx->counts.moves;
     return EHR_OK;
 }
 

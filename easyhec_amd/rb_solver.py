@@ -18,6 +18,26 @@ from .se3 import se3_exp_map, se3_log_map
 __all__ = ["RBSolver"]
 
 
+class _LinkComposite(torch.autograd.Function):
+    """``flip(stack(silhouettes).sum(0).clamp(max=1), dims=[0])`` (rb_solver.py:66-69 + nvdiffrast_renderer.py:47), the same
+    forward ops in the same order; the backward computes the gradient image once -- flip, then clamp's pass-through mask
+    (``sum <= 1``, as torch's clamp backward has it) -- and hands that one contiguous tensor to every link, where autograd's
+    own chain (sum -> expand -> stack -> unbind) hands out stride-0 views that each consumer has to copy."""
+
+    @staticmethod
+    def forward(ctx, *silhouettes):
+        total = torch.stack(silhouettes).sum(0)
+        ctx.save_for_backward(total)
+        ctx.n = len(silhouettes)
+        return torch.flip(total.clamp(max=1), dims=[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (total,) = ctx.saved_tensors
+        g = torch.where(total <= 1, torch.flip(dy, dims=[0]), 0.0)
+        return (g,) * ctx.n
+
+
 class RBSolver(nn.Module):
     def __init__(self, cfg, meshes=None):
         """cfg: :class:`easyhec_amd.config.Cfg` (fields of defaults.py ``model.rbsolver``).
@@ -88,16 +108,18 @@ class RBSolver(nn.Module):
         # proj @ opencv2blender @ pose as two batched products for all (frame, link) pairs, transform_pos as one product per
         # link for all frames, and the vertical flip (nvdiffrast_renderer.py:47: a permutation, it commutes with the sum
         # over links and the clamp) once per frame instead of once per link.
+        # Autograd nodes are launches too: unbind (backward = ONE stack) instead of indexing per (frame, link) (backward = a
+        # zero fill + a copy + an add each), and _LinkComposite hands all links one contiguous gradient image.
         mvp_all = renderer.clip_matrices(K, Tc_c2b[None, None] @ link_poses)          # [B, L, 4, 4]
-        pos_all = [renderer.clip_positions_batched(mvp_all[:, k], getattr(self, f"vertices_{k}"))  # [B, V_k, 4] each
-                   for k in range(self.nlinks)]
+        pos_all = [renderer.clip_positions_batched(m, getattr(self, f"vertices_{k}")).unbind(0)  # B x [V_k, 4] each
+                   for k, m in enumerate(mvp_all.unbind(1))]
         for frame in range(masks_ref.shape[0]):
             silhouettes = [
                 renderer.mask_from_clip(pos_all[k][frame][None], getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}"),
                                         flip=False)
                 for k in range(self.nlinks)
             ]
-            composite = torch.flip(torch.stack(silhouettes).sum(0).clamp(max=1), dims=[0])
+            composite = _LinkComposite.apply(*silhouettes)
             per_frame_mask.append(composite)
             per_frame_loss.append(((composite - masks_ref[frame].float()) ** 2).sum())
         return torch.stack(per_frame_mask), torch.stack(per_frame_loss).mean()

@@ -95,14 +95,17 @@ class NVDiffrastRenderer:
     def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing, flip=True):
         rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution)
         if anti_aliasing:
-            vtx_color = self._cached("ones", verts, lambda: torch.ones((1,) + tuple(verts.shape), dtype=torch.float,
+            # ONE colour channel: the reference interpolates torch.ones(verts.shape) (three equal channels,
+            # nvdiffrast_renderer.py:41) and keeps channel 0; the other two are never read, their gradient is zero, and
+            # with one channel the mask below is a view of the op's output instead of a strided select
+            vtx_color = self._cached("ones", verts, lambda: torch.ones((1, verts.shape[0], 1), dtype=torch.float,
                                                                        device=verts.device))
             # (the colour is the same at every vertex, so it does not depend on the barycentrics: the gradient that would
             #  flow back through rast_out into pos_clip is exactly zero -- every term is dy * (1 - 1) -- and detaching saves
             #  two full-image backward kernels per (frame, link); the silhouette gradient comes from dr.antialias)
             color, _ = dr.interpolate(vtx_color, rast_out.detach(), faces)
             color = dr.antialias(color, rast_out, pos_clip, faces, topology_hash=self._topology(faces))
-            mask = color[0, :, :, 0]
+            mask = color.view(color.shape[1], color.shape[2])  # [1, H, W, 1]: a view both ways (indexing = fill + copy in backward)
         else:
             mask = rast_out[0, :, :, 2] > 0
         if flip:
