@@ -43,6 +43,7 @@ struct Scratch {
 // inside a torch.cuda.graphs capture of a solver step becomes a memset / memcpy graph node, and a graph holding such
 // nodes faulted on its SECOND replay on this stack (ROCm 7.0 / MI355X; kernels only: replays fine).
 int zero_words(void* dst, size_t nwords, hipStream_t stream);
+int fill_words(void* dst, size_t nwords, unsigned value, hipStream_t stream);
 int copy_words(void* dst, const void* src, size_t nwords, hipStream_t stream);
 
 struct StepHead;
@@ -76,6 +77,8 @@ struct ehr_ctx {
                             // (a fill kernel per call was a tenth of the three-op step's launches)
     unsigned long long counts_clean = ~0ull;  // == counts.moves: the buffer is known to be all zero
     ehr::Scratch ranges;    // int32 [2 * B]: the per-image triangle ranges of a range-mode call
+    ehr::Scratch rkeys;     // u64 [B * H * W]: key image of the drop-in rasterizer's direct form; ALL ONES between calls
+    unsigned long long rkeys_clean = ~0ull;  // == rkeys.moves: known to be all ones
     ehr::Scratch offsets;   // int32 [nkeys]
     ehr::Scratch entries;   // int32 [entries_cap]
     size_t entries_cap = 0; // in entries

@@ -167,7 +167,7 @@ static unsigned topo_slots(int T) {
 
 // ---- antialias ---------------------------------------------------------------------------------------------------
 
-// work buffer (forward -> backward): one SEGMENT per workgroup of the forward kernel (256 pixels): int4 header
+// work buffer (forward -> backward): one SEGMENT per workgroup of the forward kernel (a 32 x 8 tile): int4 header
 // {count, 0, 0, 0} followed by up to 512 int4 items {px, py, flags, alpha bits} -- the BLENDED pairs whose first pixel
 // the workgroup owns.  Every workgroup writes its own header, so nothing has to be zeroed beforehand.
 // flags: bits 0-1 di, bit 2 d (vertical pair), bit 3 chosen triangle is pixel1's, bits 16.. image
@@ -220,72 +220,109 @@ __device__ __forceinline__ AAHit aa_pair(const float4* __restrict__ rast, const 
     return h;
 }
 
-// The whole forward pass in ONE launch, one thread per pixel, gathering instead of scattering: a pixel's output is its
-// colour plus the blends of the (up to four) pairs it belongs to that land on it -- its own right / upper pair when
-// alpha > 0, its left / lower neighbour's pair when alpha <= 0 -- added in a fixed order (no atomics: the result is
-// bit-reproducible and equals a serial sweep's, bit for bit; the pair analysis runs twice, once from either side, on the
-// few thousand silhouette pixels of an image).  Round 3 had three launches here (zero the list's counter, discover the pairs + copy the colour, analyse and
-// scatter with float atomics).
+// The whole forward pass in ONE launch, one workgroup per 32 x 8 tile, gathering instead of scattering.
+//   1. every pixel looks at its right and upper neighbour (the tile's first column / row also at the left / lower one)
+//      and lists the pairs whose triangle ids differ in LDS;
+//   2. the pairs are analysed one per lane, all at once -- a pair is a chain of four dependent reads (ids -> triangle
+//      -> vertices -> neighbour triangles' vertices), and a pixel that analysed its four pairs itself, one after the
+//      other, held the launch for four such chains;
+//   3. every pixel adds the blends of the (up to four) pairs it belongs to that land on it -- its own right / upper pair
+//      when alpha > 0, its left / lower neighbour's pair when alpha <= 0 -- in the order a serial sweep over first
+//      pixels would (no atomics: bit-reproducible, and equal to the oracle's sweep bit for bit).
+// Pairs across a tile border are analysed by both tiles.  Round 3 had three launches here (zero the list's counter,
+// discover the pairs + copy the colour, analyse and scatter with float atomics).
+constexpr int AA_TW = 32, AA_TH = 8;
+constexpr int AA_MAXP = 2 * AA_TW * AA_TH + AA_TW + AA_TH;  // own pairs + the halo pairs of the first column and row
+
 __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
                                                      const float4* __restrict__ pos, const int32_t* __restrict__ tri,
                                                      const int32_t* __restrict__ opp, int range_mode, int B, int V, int T,
-                                                     int H, int W, int C, float* __restrict__ out,
+                                                     int H, int W, int C, int ntx, int nty, float* __restrict__ out,
                                                      int4* __restrict__ work) {
-    __shared__ int s_count;
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int s_npair, s_count;
+    __shared__ unsigned s_pair[AA_MAXP];   // px - tx0 + 1 (6 bits) | (py - ty0 + 1) << 6 (4 bits) | d << 10
+    __shared__ float s_alpha[AA_MAXP];     // 0 = nothing lands anywhere
+    __shared__ short s_slot[4][AA_TW * AA_TH];  // per pixel: slot of its R, U, L, D pair or -1
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x % (ntx * nty), b = blockIdx.x / (ntx * nty);
+    const int tx0 = (tile % ntx) * AA_TW, ty0 = (tile / ntx) * AA_TH;
+    const int lx = tid % AA_TW, ly = tid / AA_TW;
+    const int px = tx0 + lx, py = ty0 + ly;
     const size_t P = (size_t)H * W;
-    int4* const seg = work + (size_t)blockIdx.x * AA_SEG;
-    if (idx < P * B) {
-        const int b = (int)(idx / P);
-        const int rem = (int)(idx - (size_t)b * P);
-        const int py = rem / W, px = rem - py * W;
+    const bool in = px < W && py < H;
+    const size_t idx = (size_t)b * P + (size_t)py * W + px;
+    if (tid == 0) {
+        s_npair = 0;
+        s_count = 0;
+    }
+    __syncthreads();
+    // ---- 1. list the pairs
+    int sR = -1, sU = -1, sL = -1, sD = -1;
+    if (in) {
         const float t0 = rast[idx].w;
-        // the four pairs this pixel belongs to: {first pixel, d, does this pixel own it}
-        const bool hasR = px + 1 < W && rast[idx + 1].w != t0;
-        const bool hasU = py + 1 < H && rast[idx + W].w != t0;
-        const bool hasL = px > 0 && rast[idx - 1].w != t0;
-        const bool hasD = py > 0 && rast[idx - W].w != t0;
-        float alpha[4] = {0.f, 0.f, 0.f, 0.f};
-        size_t other[4] = {idx, idx, idx, idx};
-        if (hasR) {
-            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px, py, 0);
-            if (h.found && h.alpha != 0.f) {
-                seg[1 + atomicAdd(&s_count, 1)] = make_int4(px, py, (b << 16) | h.flags, __float_as_int(h.alpha));
-                if (h.alpha > 0.f) alpha[0] = h.alpha, other[0] = idx + 1;  // lands on pix0 = this pixel: a (c1 - c0)
-            }
+        if (px + 1 < W && rast[idx + 1].w != t0) {
+            sR = atomicAdd(&s_npair, 1);
+            s_pair[sR] = (unsigned)(lx + 1) | ((unsigned)(ly + 1) << 6);
         }
-        if (hasU) {
-            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px, py, 1);
-            if (h.found && h.alpha != 0.f) {
-                seg[1 + atomicAdd(&s_count, 1)] = make_int4(px, py, (b << 16) | AA_FLAG_D | h.flags, __float_as_int(h.alpha));
-                if (h.alpha > 0.f) alpha[1] = h.alpha, other[1] = idx + W;
-            }
+        if (py + 1 < H && rast[idx + W].w != t0) {
+            sU = atomicAdd(&s_npair, 1);
+            s_pair[sU] = (unsigned)(lx + 1) | ((unsigned)(ly + 1) << 6) | (1u << 10);
         }
-        if (hasL) {  // pair (left neighbour, this pixel): lands here (pix1) when alpha <= 0: a (c1 - c0) = -a (c_left - c_this)
-            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px - 1, py, 0);
-            if (h.found && !(h.alpha > 0.f)) alpha[2] = h.alpha, other[2] = idx - 1;
+        if (lx == 0 && px > 0 && rast[idx - 1].w != t0) {  // the pair (left neighbour, this pixel) belongs to the tile on the left
+            sL = atomicAdd(&s_npair, 1);
+            s_pair[sL] = (unsigned)(lx + 0) | ((unsigned)(ly + 1) << 6);
         }
-        if (hasD) {
-            const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, px, py - 1, 1);
-            if (h.found && !(h.alpha > 0.f)) alpha[3] = h.alpha, other[3] = idx - W;
+        if (ly == 0 && py > 0 && rast[idx - W].w != t0) {
+            sD = atomicAdd(&s_npair, 1);
+            s_pair[sD] = (unsigned)(lx + 1) | ((unsigned)(ly + 0) << 6) | (1u << 10);
         }
+    }
+    s_slot[0][tid] = (short)sR;
+    s_slot[1][tid] = (short)sU;
+    s_slot[2][tid] = (short)sL;
+    s_slot[3][tid] = (short)sD;
+    __syncthreads();
+    // ---- 2. analyse them, one per lane
+    const int np = s_npair;
+    int4* const seg = work + (size_t)blockIdx.x * AA_SEG;
+    for (int i = tid; i < np; i += 256) {
+        const unsigned pr = s_pair[i];
+        const int qx = tx0 + (int)(pr & 63u) - 1, qy = ty0 + (int)((pr >> 6) & 15u) - 1, d = (int)(pr >> 10);
+        const AAHit h = aa_pair(rast, pos, tri, opp, range_mode, V, T, H, W, P, b, qx, qy, d);
+        const float al = (h.found) ? h.alpha : 0.f;
+        s_alpha[i] = al;
+        // the list for the backward pass holds every blended pair once: the tile that owns its first pixel records it
+        if (al != 0.f && qx >= tx0 && qy >= ty0)
+            seg[1 + atomicAdd(&s_count, 1)] = make_int4(qx, qy, (b << 16) | (d ? AA_FLAG_D : 0) | h.flags, __float_as_int(al));
+    }
+    __syncthreads();
+    // ---- 3. gather
+    if (in) {
+        // slots of the four pairs: own R / U; the left neighbour's R pair (its slot, or this pixel's halo pair in the
+        // first column); the lower neighbour's U pair likewise
+        const int kR = sR, kU = sU;
+        const int kL = (lx > 0) ? (int)s_slot[0][tid - 1] : sL;
+        const int kD = (ly > 0) ? (int)s_slot[1][tid - AA_TW] : sD;
+        float aR = (kR >= 0) ? s_alpha[kR] : 0.f, aU = (kU >= 0) ? s_alpha[kU] : 0.f;
+        float aL = (kL >= 0) ? s_alpha[kL] : 0.f, aD = (kD >= 0) ? s_alpha[kD] : 0.f;
+        if (!(aR > 0.f)) aR = 0.f;  // own pairs land here (pix0) when alpha > 0
+        if (!(aU > 0.f)) aU = 0.f;
+        if (aL > 0.f) aL = 0.f;     // neighbours' pairs land here (pix1) when alpha <= 0
+        if (aD > 0.f) aD = 0.f;
         for (int k = 0; k < C; k++) {
             const float c = color[idx * C + k];
             float v = c;
             // every term is alpha (c1 - c0) of its pair: this pixel is pix1 of its neighbours' pairs, pix0 of its own.
             // Order = the pairs' order in a sweep over first pixels, horizontal before vertical (the oracle's, and a
             // serial implementation's): lower neighbour's vertical pair, left neighbour's horizontal one, own two.
-            if (alpha[3] != 0.f) v += alpha[3] * (c - color[other[3] * C + k]);
-            if (alpha[2] != 0.f) v += alpha[2] * (c - color[other[2] * C + k]);
-            if (alpha[0] != 0.f) v += alpha[0] * (color[other[0] * C + k] - c);
-            if (alpha[1] != 0.f) v += alpha[1] * (color[other[1] * C + k] - c);
+            if (aD != 0.f) v += aD * (c - color[(idx - W) * C + k]);
+            if (aL != 0.f) v += aL * (c - color[(idx - 1) * C + k]);
+            if (aR != 0.f) v += aR * (color[(idx + 1) * C + k] - c);
+            if (aU != 0.f) v += aU * (color[(idx + W) * C + k] - c);
             out[idx * C + k] = v;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) seg[0] = make_int4(s_count, 0, 0, 0);
+    if (tid == 0) seg[0] = make_int4(s_count, 0, 0, 0);
 }
 
 // backward: one wave per segment of the forward pass's list
@@ -397,7 +434,9 @@ int ehr_antialias_topology(const int32_t* tri, int T, int32_t* opp, void* scratc
     return EHR_OK;
 }
 
-static size_t aa_segments(int B, int H, int W) { return ((size_t)B * H * W + 255) / 256; }
+static size_t aa_segments(int B, int H, int W) {  // one per (image, 32 x 8 tile)
+    return (size_t)B * ((W + AA_TW - 1) / AA_TW) * ((H + AA_TH - 1) / AA_TH);
+}
 size_t ehr_antialias_work_bytes(int B, int H, int W) { return std::max<size_t>(aa_segments(B, H, W), 1) * AA_SEG * sizeof(int4); }
 
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
@@ -410,7 +449,8 @@ int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, c
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
     aa_fwd_kernel<<<(unsigned)aa_segments(B, H, W), 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp,
-                                                                      range_mode, B, V, T, H, W, C, out, (int4*)work);
+                                                                      range_mode, B, V, T, H, W, C, (W + AA_TW - 1) / AA_TW,
+                                                                      (H + AA_TH - 1) / AA_TH, out, (int4*)work);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

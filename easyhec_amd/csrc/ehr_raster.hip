@@ -43,8 +43,8 @@ void Scratch::release() {
     cap = 0;
 }
 
-static __global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ p, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+static __global__ void __launch_bounds__(256) zero_words_kernel(unsigned* __restrict__ p, size_t n, unsigned v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
 }
 static __global__ void __launch_bounds__(256) copy_words_kernel(unsigned* __restrict__ d, const unsigned* __restrict__ s, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
@@ -52,13 +52,14 @@ static __global__ void __launch_bounds__(256) copy_words_kernel(unsigned* __rest
 static __global__ void __launch_bounds__(256) copy_words4_kernel(uint4* __restrict__ d, const uint4* __restrict__ s, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
 }
-int zero_words(void* dst, size_t nwords, hipStream_t stream) {
+int fill_words(void* dst, size_t nwords, unsigned value, hipStream_t stream) {
     if (nwords == 0) return EHR_OK;
     const unsigned grid = (unsigned)std::min<size_t>((nwords + 255) / 256, 2048);
-    zero_words_kernel<<<grid, 256, 0, stream>>>((unsigned*)dst, nwords);
+    zero_words_kernel<<<grid, 256, 0, stream>>>((unsigned*)dst, nwords, value);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }
+int zero_words(void* dst, size_t nwords, hipStream_t stream) { return fill_words(dst, nwords, 0u, stream); }
 int copy_words(void* dst, const void* src, size_t nwords, hipStream_t stream) {
     if (nwords == 0) return EHR_OK;
     if ((nwords & 3) == 0 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0) {
@@ -69,6 +70,50 @@ int copy_words(void* dst, const void* src, size_t nwords, hipStream_t stream) {
     }
     EHR_LAUNCH_CHECK();
     return EHR_OK;
+}
+
+// One pixel's output from its winning key (depth | triangle): barycentrics, depth, id [, pixel differentials].
+template <bool WITH_DB>
+__device__ __forceinline__ void shade_pixel(const ClipSource& src, int b, u64 k, int ix, int iy, int W, int H,
+                                            float4* __restrict__ rast, float4* __restrict__ rast_db) {
+    const size_t pix = ((size_t)b * H + iy) * W + ix;
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k != ~0ull) {
+        int t = (int)(unsigned)(k & 0xffffffffu);
+        const float4* pv = src.verts(b);
+        float4 p[3] = {pv[src.tri[3 * t]], pv[src.tri[3 * t + 1]], pv[src.tri[3 * t + 2]]};
+        const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+        const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+        float fx = (float)ix * xs + xo;
+        float fy = (float)iy * ys + yo;
+        float a0, a1, a2;
+        eval_pixel(p, fx, fy, a0, a1, a2);
+        float at = (a0 + a1) + a2;
+        float iw = 1.f / at;
+        float b0 = sat01(a0 * iw);
+        float b1 = sat01(a1 * iw);
+        float zw = eval_zw(p, a0, a1, a2);
+        zw = fmaxf(fminf(zw, 1.f), -1.f);
+        out = make_float4(b0, b1, zw, tri_to_float(t + 1));
+        if (WITH_DB) {
+            float dfxdx = xs * iw;
+            float dfydy = ys * iw;
+            float da0dx = p[2].y * p[1].w - p[1].y * p[2].w;
+            float da0dy = p[1].x * p[2].w - p[2].x * p[1].w;
+            float da1dx = p[0].y * p[2].w - p[2].y * p[0].w;
+            float da1dy = p[2].x * p[0].w - p[0].x * p[2].w;
+            float da2dx = p[1].y * p[0].w - p[0].y * p[1].w;
+            float da2dy = p[0].x * p[1].w - p[1].x * p[0].w;
+            float datdx = (da0dx + da1dx) + da2dx;
+            float datdy = (da0dy + da1dy) + da2dy;
+            db.x = dfxdx * (b0 * datdx - da0dx);
+            db.y = dfydy * (b0 * datdy - da0dy);
+            db.z = dfxdx * (b1 * datdx - da1dx);
+            db.w = dfydy * (b1 * datdy - da1dy);
+        }
+    }
+    rast[pix] = out;
+    if (WITH_DB) rast_db[pix] = db;
 }
 
 // ---- drop-in rasterize tile kernel -------------------------------------------------------------------------------
@@ -138,45 +183,156 @@ __global__ void __launch_bounds__(EHR_TILE_THREADS) raster_tile_kernel(ClipSourc
     const int lx = tid % EHR_TILE_W, ly = tid / EHR_TILE_W;
     const int ix = rx0 + lx, iy = ry0 + ly;
     if (ix >= g.W || iy >= g.H) return;
-    const size_t pix = ((size_t)b * g.H + iy) * g.W + ix;
-    u64 k = key[tid];
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k != ~0ull) {
-        int t = (int)(unsigned)(k & 0xffffffffu);
+    shade_pixel<WITH_DB>(src, b, key[tid], ix, iy, g.W, g.H, rast, rast_db);
+}
+
+// ---- drop-in rasterize, direct form: small launches (a link's mesh in one image) ----------------------------------
+//
+// The queued form above is four dependent launches (count, allocate, fill, one workgroup per tile) plus 16 B per
+// (triangle, tile) of queue traffic: right for a batch of views of a whole robot, ~40 us of mostly latency for the few
+// thousand small triangles of ONE link in ONE 1280x720 image -- which is what the reference's schedule asks for 64 times
+// per optimisation step (rb_solver.py:60-66).  The direct form is two launches: triangles are depth-tested straight
+// into a 64-bit key image in global memory (the same key, the same per-pixel test, the same snapped edge functions as
+// the tile rasterizer: depth_test_write / setup_coverage / setup_edges, so the result is the same bit for bit; the
+// minimum is order independent), then one thread per pixel shades its key and re-arms it for the next call.
+//   grid = (256 triangles, band of rows, image): every workgroup clips its triangles' boxes to its band, so a triangle
+//   that covers the screen is spread over all bands and a small one costs the others a three-division row test each.
+//   A lane walks a box of up to RD_OWN pixels itself; larger ones are staged in LDS with their finished setup and
+//   walked by a whole wave, 8 x 8 pixels per step.
+constexpr int RD_OWN = 96;     // the four lanes of a triangle walk a (band-clipped) box of up to this many pixels themselves
+constexpr int RD_LIST = 128;   // larger boxes staged in LDS per workgroup, walked by a wave each, 8 x 8 pixels per step
+
+struct RdEntry {  // one (sub-)triangle's finished setup: edge functions at its box origin, the box, the parent triangle
+    i64 e[3], sx[3], sy[3];
+    int ix0, iy0, bw, bh;
+    float4 p[3];
+    int t, pad[3];
+};
+
+// own lane: rows x columns, stepping the edge functions (adds only)
+__device__ __forceinline__ void rd_walk_own(const float4 p[3], const EdgeEval& ee0, int ix0, int iy0, int bw, int bh, int t,
+                                            int W, int H, u64* __restrict__ keyb, int q) {
+    // lane q of the triangle's four takes rows q, q + 4, ...
+    i64 r0 = ee0.e[0] + q * ee0.sy[0], r1 = ee0.e[1] + q * ee0.sy[1], r2 = ee0.e[2] + q * ee0.sy[2];
+    for (int dy = q; dy < bh; dy += 4) {
+        i64 e0 = r0, e1 = r1, e2 = r2;
+        for (int dx = 0; dx < bw; dx++) {
+            if ((e0 | e1 | e2) >= 0) depth_test_write(p, t, ix0 + dx, iy0 + dy, W, H, &keyb[(size_t)(iy0 + dy) * W + ix0 + dx]);
+            e0 += ee0.sx[0];
+            e1 += ee0.sx[1];
+            e2 += ee0.sx[2];
+        }
+        r0 += 4 * ee0.sy[0];
+        r1 += 4 * ee0.sy[1];
+        r2 += 4 * ee0.sy[2];
+    }
+}
+
+__global__ void __launch_bounds__(256) raster_direct_kernel(ClipSource src, int W, int H, int band_rows,
+                                                            u64* __restrict__ key) {
+    __shared__ RdEntry lst[RD_LIST];  // (RD_LIST >= 128: 64 triangles, two sub-triangles each at most)
+    __shared__ int ln;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * band_rows, y1 = min(y0 + band_rows, H) - 1;
+    if (tid == 0) ln = 0;
+    __syncthreads();
+    int t0, t1;
+    src.range(b, t0, t1);
+    // FOUR lanes per triangle (64 triangles per workgroup): the chip is far from full on a launch of a few thousand
+    // triangles, what counts is the length of a wave's instruction chain -- the setup is computed four times over, the
+    // rows of a box are dealt to the four lanes, and a wave has a quarter of the staged boxes to walk
+    const int q = tid & 3;
+    const int t = t0 + blockIdx.x * 64 + (tid >> 2);
+    u64* const keyb = key + (size_t)b * W * H;
+    int v0 = 0, v1 = 0, v2 = 0, link = 0;
+    if (t < t1 && src.indices(t, v0, v1, v2, link)) {
         const float4* pv = src.verts(b);
-        float4 p[3] = {pv[src.tri[3 * t]], pv[src.tri[3 * t + 1]], pv[src.tri[3 * t + 2]]};
-        const float xs = 2.f / (float)g.W, xo = 1.f / (float)g.W - 1.f;
-        const float ys = 2.f / (float)g.H, yo = 1.f / (float)g.H - 1.f;
-        float fx = (float)ix * xs + xo;
-        float fy = (float)iy * ys + yo;
-        float a0, a1, a2;
-        eval_pixel(p, fx, fy, a0, a1, a2);
-        float at = (a0 + a1) + a2;
-        float iw = 1.f / at;
-        float b0 = sat01(a0 * iw);
-        float b1 = sat01(a1 * iw);
-        float zw = eval_zw(p, a0, a1, a2);
-        zw = fmaxf(fminf(zw, 1.f), -1.f);
-        out = make_float4(b0, b1, zw, tri_to_float(t + 1));
-        if (WITH_DB) {
-            float dfxdx = xs * iw;
-            float dfydy = ys * iw;
-            float da0dx = p[2].y * p[1].w - p[1].y * p[2].w;
-            float da0dy = p[1].x * p[2].w - p[2].x * p[1].w;
-            float da1dx = p[0].y * p[2].w - p[2].y * p[0].w;
-            float da1dy = p[2].x * p[0].w - p[0].x * p[2].w;
-            float da2dx = p[1].y * p[0].w - p[0].y * p[1].w;
-            float da2dy = p[0].x * p[1].w - p[1].x * p[0].w;
-            float datdx = (da0dx + da1dx) + da2dx;
-            float datdy = (da0dy + da1dy) + da2dy;
-            db.x = dfxdx * (b0 * datdx - da0dx);
-            db.y = dfydy * (b0 * datdy - da0dy);
-            db.z = dfxdx * (b1 * datdx - da1dx);
-            db.w = dfydy * (b1 * datdy - da1dy);
+        const float4 p[3] = {pv[v0], pv[v1], pv[v2]};
+        // cheap band test first (every band's workgroup sees every triangle): rows of the three vertices, one pixel of
+        // margin for the snapping; only for triangles in front of the eye, the others go through the clipper below
+        bool maybe = true;
+        if (p[0].w > 0.f && p[1].w > 0.f && p[2].w > 0.f) {
+            const float hh = 0.5f * (float)H;
+            const float r0 = p[0].y / p[0].w * hh + hh, r1 = p[1].y / p[1].w * hh + hh, r2 = p[2].y / p[2].w * hh + hh;
+            const float lo = fminf(r0, fminf(r1, r2)), hi = fmaxf(r0, fmaxf(r1, r2));
+            maybe = !(hi < (float)y0 - 1.f) && !(lo > (float)y1 + 2.f);  // (NaN: stays true)
+        }
+        if (maybe) {
+            const ClipPoly c = clip_near_poly(p);
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (s + 2 >= c.n) continue;
+                const Coverage cv = (s == 0) ? setup_coverage(c.q0, c.q1, c.q2, W, H) : setup_coverage(c.q0, c.q2, c.q3, W, H);
+                if (!cv.valid) continue;
+                const int iy0 = max(cv.iy0, y0), iy1 = min(cv.iy1, y1);
+                if (iy0 > iy1) continue;
+                const EdgeEval ee = setup_edges(cv, cv.ix0, iy0, W, H);
+                const int bw = cv.ix1 - cv.ix0 + 1, bh = iy1 - iy0 + 1;
+                int k = -1;
+                if (bw * bh > RD_OWN) {
+                    if (q == 0) k = atomicAdd(&ln, 1);
+                    k = __shfl(k, lane & ~3, 64);
+                    if (k >= RD_LIST) k = -1;  // list full: walked here after all (exact, only slower)
+                }
+                if (k >= 0 && q != 0) continue;  // (staged by lane 0 of the four)
+                if (k >= 0) {
+                    RdEntry& r = lst[k];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        r.e[i] = ee.e[i];
+                        r.sx[i] = ee.sx[i];
+                        r.sy[i] = ee.sy[i];
+                        r.p[i] = p[i];
+                    }
+                    r.ix0 = cv.ix0;
+                    r.iy0 = iy0;
+                    r.bw = bw;
+                    r.bh = bh;
+                    r.t = t;
+                } else {
+                    rd_walk_own(p, ee, cv.ix0, iy0, bw, bh, t, W, H, keyb, q);
+                }
+            }
         }
     }
-    rast[pix] = out;
-    if (WITH_DB) rast_db[pix] = db;
+    __syncthreads();
+    const int n = min(ln, RD_LIST);
+    const int lx = lane & 7, ly = lane >> 3;
+    for (int j = wave; j < n; j += 4) {
+        const RdEntry& r = lst[j];
+        const float4 p[3] = {r.p[0], r.p[1], r.p[2]};
+        const int t2 = r.t, ix0 = r.ix0, iy0 = r.iy0, bw = r.bw, bh = r.bh;
+        const i64 sx0 = r.sx[0], sx1 = r.sx[1], sx2 = r.sx[2], sy0 = r.sy[0], sy1 = r.sy[1], sy2 = r.sy[2];
+        i64 r0 = r.e[0] + lx * sx0 + ly * sy0, r1 = r.e[1] + lx * sx1 + ly * sy1, r2 = r.e[2] + lx * sx2 + ly * sy2;
+        for (int cy = 0; cy < bh; cy += 8) {
+            i64 e0 = r0, e1 = r1, e2 = r2;
+            for (int cx = 0; cx < bw; cx += 8) {
+                const int dx = cx + lx, dy = cy + ly;
+                if (dx < bw && dy < bh && (e0 | e1 | e2) >= 0)
+                    depth_test_write(p, t2, ix0 + dx, iy0 + dy, W, H, &keyb[(size_t)(iy0 + dy) * W + ix0 + dx]);
+                e0 += 8 * sx0;
+                e1 += 8 * sx1;
+                e2 += 8 * sx2;
+            }
+            r0 += 8 * sy0;
+            r1 += 8 * sy1;
+            r2 += 8 * sy2;
+        }
+    }
+}
+
+template <bool WITH_DB>
+__global__ void __launch_bounds__(256) raster_shade_kernel(ClipSource src, int B, int W, int H, u64* __restrict__ key,
+                                                           float4* __restrict__ rast, float4* __restrict__ rast_db) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, P = (size_t)W * H;
+    if (idx >= P * B) return;
+    const int b = (int)(idx / P);
+    const int rem = (int)(idx - (size_t)b * P);
+    const int iy = rem / W, ix = rem - iy * W;
+    const u64 k = key[idx];
+    if (k != ~0ull) key[idx] = ~0ull;  // re-armed for the next call: the key image is all ones between calls
+    shade_pixel<WITH_DB>(src, b, k, ix, iy, W, H, rast, rast_db);
 }
 
 // ---- rasterize backward ------------------------------------------------------------------------------------------
@@ -288,6 +444,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     (void)hipSetDevice(c->device);
     c->counts.release();
     c->ranges.release();
+    c->rkeys.release();
     c->offsets.release();
     c->entries.release();
     c->sc_counts.release();
@@ -320,7 +477,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
 size_t ehr_ctx_scratch_bytes(ehr_ctx* c) {
     if (!c) return 0;
     size_t n = 0;
-    for (const Scratch* s : {&c->counts, &c->ranges, &c->offsets, &c->entries, &c->vb_clus, &c->vb_heavy, &c->vb_idx, &c->vb_boxes, &c->vb_units,
+    for (const Scratch* s : {&c->counts, &c->ranges, &c->rkeys, &c->offsets, &c->entries, &c->vb_clus, &c->vb_heavy, &c->vb_idx, &c->vb_boxes, &c->vb_units,
                              &c->vb_acc, &c->vb_posc, &c->vb_jobs, &c->vb_spill, &c->vb_refsum, &c->sc_counts, &c->sc_offsets,
                              &c->sc_entries, &c->sc_posc, &c->sc_clus, &c->sc_misc})
         n += s->cap;
@@ -376,6 +533,39 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     src.L = 1;
     src.image_stride = ranges_host ? 0 : V;
 
+    // Small launches (one link's mesh in one image: the reference's 64 calls per step) take the direct form: two kernels,
+    // no queues, nothing for the host to size or wait for.  EHR_RASTER_DIRECT_MAX (triangles x images; 0 = never) is a
+    // test / tuning hook, read per call.
+    {
+        const char* e = getenv("EHR_RASTER_DIRECT_MAX");
+        const size_t direct_max = e ? (size_t)std::max(0ll, atoll(e)) : ((size_t)1 << 17);
+        if ((size_t)B * (size_t)tmax <= direct_max && (size_t)B * H * W <= ((size_t)1 << 28) && B <= 65535) {
+            const size_t npix = (size_t)B * H * W;
+            if ((rc = ctx->rkeys.reserve(npix * sizeof(u64)))) return rc;
+            if (ctx->rkeys_clean != ctx->rkeys.moves) {
+                if ((rc = fill_words(ctx->rkeys.ptr, ctx->rkeys.cap / sizeof(unsigned), 0xffffffffu, stream))) return rc;
+            }
+            ctx->rkeys_clean = ~0ull;  // (until the shade kernel is enqueued)
+            u64* key = (u64*)ctx->rkeys.ptr;
+            if (tmax > 0) {
+                const int nbx = (tmax + 63) / 64;
+                static const int rd_blocks = getenv("EHR_RD_BLOCKS") ? atoi(getenv("EHR_RD_BLOCKS")) : 8192;  // (tuning hook; bands are at least 8 rows)
+                int Z = std::max(1, std::min(rd_blocks / std::max(1, nbx * B), (H + 7) / 8));
+                const int band_rows = (H + Z - 1) / Z;
+                Z = (H + band_rows - 1) / band_rows;
+                raster_direct_kernel<<<dim3(nbx, Z, B), 256, 0, stream>>>(src, W, H, band_rows, key);
+                EHR_LAUNCH_CHECK();
+            }
+            const unsigned sgrid = (unsigned)((npix + 255) / 256);
+            if (rast_db)
+                raster_shade_kernel<true><<<sgrid, 256, 0, stream>>>(src, B, W, H, key, (float4*)rast, (float4*)rast_db);
+            else
+                raster_shade_kernel<false><<<sgrid, 256, 0, stream>>>(src, B, W, H, key, (float4*)rast, nullptr);
+            EHR_LAUNCH_CHECK();
+            ctx->rkeys_clean = ctx->rkeys.moves;
+            return EHR_OK;
+        }
+    }
     // counts | cursors | meta are all zero between calls (raster_tile_kernel, the last kernel below, zeroes what a call
     // dirtied); only a fresh or moved buffer, or one a failed call left behind, is cleared here.
     if (ctx->counts_clean != ctx->counts.moves) {

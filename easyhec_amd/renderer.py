@@ -93,7 +93,9 @@ class NVDiffrastRenderer:
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
     def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing, flip=True):
-        rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution)
+        # (grad_db=False: the reference takes the default and throws rast_db away -- `rast_out, _ = ...`,
+        #  nvdiffrast_renderer.py:39 -- so the 16 B per pixel are not written here)
+        rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution, grad_db=False)
         if anti_aliasing:
             # ONE colour channel: the reference interpolates torch.ones(verts.shape) (three equal channels,
             # nvdiffrast_renderer.py:41) and keeps channel 0; the other two are never read, their gradient is zero, and

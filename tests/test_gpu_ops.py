@@ -22,6 +22,19 @@ def env():
     return dr, dr.RasterizeCudaContext(), torch.device("cuda:0")
 
 
+@pytest.fixture(params=["direct", "queued"])
+def raster_path(request):
+    """Both forms of the drop-in rasterizer (ehr_raster.hip): the direct one (small launches: two kernels, a key image in
+    global memory) and the queued one (count / allocate / fill / one workgroup per tile).  Same bits either way."""
+    old = os.environ.get("EHR_RASTER_DIRECT_MAX")
+    os.environ["EHR_RASTER_DIRECT_MAX"] = "0" if request.param == "queued" else "1000000000"
+    yield request.param
+    if old is None:
+        del os.environ["EHR_RASTER_DIRECT_MAX"]
+    else:
+        os.environ["EHR_RASTER_DIRECT_MAX"] = old
+
+
 def t(a, dev, grad=False):
     x = torch.tensor(np.ascontiguousarray(a), device=dev)
     if grad:
@@ -31,7 +44,7 @@ def t(a, dev, grad=False):
 
 @pytest.mark.parametrize("H,W,n,shared", [(64, 64, 50, True), (72, 104, 400, True), (250, 333, 3000, True),
                                           (128, 160, 40, False), (8, 8, 5, True), (720, 1280, 20000, True)])
-def test_rasterize_interpolate_antialias_parity(env, oracle, H, W, n, shared):
+def test_rasterize_interpolate_antialias_parity(env, oracle, raster_path, H, W, n, shared):
     dr, ctx, dev = env
     rng = np.random.default_rng(H * 1000 + n)
     pos, tri = helpers.random_mesh(rng, n, shared=shared, size=0.6 if not shared else 0.25)
@@ -85,7 +98,7 @@ def test_rasterize_survives_a_frame_that_outgrows_the_queue_storage():
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    env2 = dict(os.environ, EHR_RASTER_MIN_ENTRIES="64")
+    env2 = dict(os.environ, EHR_RASTER_MIN_ENTRIES="64", EHR_RASTER_DIRECT_MAX="0")  # (the queued form is the one with storage)
     out = subprocess.run([sys.executable, os.path.join(here, "raster_growth_worker.py")], env=env2, capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -97,7 +110,7 @@ def test_rasterize_survives_a_frame_that_outgrows_the_queue_storage():
     assert res[4]["covered"] > 10 * res[0]["covered"]  # the zoomed frames really are much larger
 
 
-def test_range_mode_and_batches(env, oracle):
+def test_range_mode_and_batches(env, oracle, raster_path):
     dr, ctx, dev = env
     rng = np.random.default_rng(9)
     pos, tri = helpers.random_mesh(rng, 120)
@@ -118,7 +131,7 @@ def test_range_mode_and_batches(env, oracle):
     assert (aa.cpu().numpy() == oracle.antialias(c.cpu().numpy(), refb, posb, tri)).all()
 
 
-def test_rasterize_calls_of_changing_shape_on_one_context(env, oracle):
+def test_rasterize_calls_of_changing_shape_on_one_context(env, oracle, raster_path):
     """A drop-in rasterize call starts without a fill kernel: its last kernel leaves the context's queue counters zero
     for the next call.  Calls of different resolution, batch size and mode interleaved on ONE context must each equal the
     oracle -- a counter word left dirty by one layout would corrupt the next (the per-image ranges of a range-mode call
@@ -142,7 +155,28 @@ def test_rasterize_calls_of_changing_shape_on_one_context(env, oracle):
         assert (r.cpu().numpy() == ref).all(), (kind, H, W)
 
 
-def test_edge_cases(env, oracle):
+def test_rasterizer_forms_alternate_on_one_context(env, oracle):
+    """The two forms keep separate state on a context (queue counters all zero / key image all ones between calls);
+    alternating them call by call must not disturb either."""
+    dr, dev = env[0], env[2]
+    ctx = dr.RasterizeCudaContext()
+    rng = np.random.default_rng(5)
+    pos, tri = helpers.random_mesh(rng, 500)
+    old = os.environ.get("EHR_RASTER_DIRECT_MAX")
+    try:
+        for i, (H, W) in enumerate([(64, 96), (64, 96), (120, 200), (64, 96), (120, 200), (120, 200)]):
+            os.environ["EHR_RASTER_DIRECT_MAX"] = "0" if i % 2 else "1000000000"
+            ref, dbr = oracle.rasterize(pos[None], tri, [H, W])
+            r, db = dr.rasterize(ctx, t(pos[None], dev), t(tri, dev), [H, W])
+            assert (r.cpu().numpy() == ref).all() and (db.cpu().numpy() == dbr).all(), (i, H, W)
+    finally:
+        if old is None:
+            os.environ.pop("EHR_RASTER_DIRECT_MAX", None)
+        else:
+            os.environ["EHR_RASTER_DIRECT_MAX"] = old
+
+
+def test_edge_cases(env, oracle, raster_path):
     dr, ctx, dev = env
     H, W = 40, 72
     # clipped / behind-camera / far / degenerate / NaN / out-of-range indices, plus one triangle covering many tiles
