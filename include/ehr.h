@@ -51,9 +51,13 @@ size_t ehr_ctx_scratch_bytes(ehr_ctx* ctx);
  * instance mode (ranges_host == NULL): pos [B,V,4], every image draws all T triangles.
  * range mode: pos [V,4], image b draws triangles ranges_host[2b] .. +ranges_host[2b+1] (HOST int32 [B,2]).
  * rast [B,H,W,4] = (u, v, z/w, triangle_id+1); rast_db [B,H,W,4] = (du/dx, du/dy, dv/dx, dv/dy) or NULL.
- * Synchronises only while it is sizing its queue storage (first calls of a shape): in steady state the size of a frame
- * reaches the host asynchronously and is looked at by the next call; a frame that needs more than twice what the previous one
- * did is returned as NaN (never silently incomplete) and the storage grows for the next. */
+ * Two forms, same bits.  Small launches (B x T <= 131072: one link's mesh in one image, the reference's call) are
+ * depth-tested straight into a key image in global memory and shaded by a second kernel: no queues, never a host wait.
+ * Larger ones go through per-tile queues (count, allocate, fill, one workgroup per tile); that form synchronises only
+ * while it is sizing its queue storage (first calls of a shape): in steady state the size of a frame reaches the host
+ * asynchronously and is looked at by the next call, and a frame that outgrows the storage is still rendered exactly (the
+ * tiles whose queues did not fit find their triangles themselves; slower, never incomplete) before the storage grows.
+ * Neither form enqueues a fill: the context's counters / key image are left clean by the call's last kernel. */
 int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
                       int T, int H, int W, float* rast, float* rast_db, void* stream);
 
@@ -77,7 +81,9 @@ size_t ehr_topology_scratch_bytes(int T);
 int ehr_antialias_topology(const int32_t* tri, int T, int32_t* opp, void* scratch, size_t scratch_bytes, void* stream);
 
 /* replaces dr.antialias -- nvdiffrast_renderer.py:43.  color/out [B,H,W,C]; pos [B,V,4] or [V,4] (range_mode).
- * work: ehr_antialias_work_bytes(B,H,W) bytes, filled by fwd and consumed by grad (nvdiffrast's work buffer). */
+ * work: ehr_antialias_work_bytes(B,H,W) bytes, filled by fwd and consumed by grad (nvdiffrast's work buffer); it needs
+ * no initialisation.  out must not alias color (every pixel reads its neighbours' colours).  The forward result is
+ * deterministic: every pixel adds the blends that land on it in the order of a serial sweep over pixel pairs. */
 size_t ehr_antialias_work_bytes(int B, int H, int W);
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                       int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work, void* stream);
