@@ -207,6 +207,38 @@ def side_workload(name, dev, steps, warmup, min_ms=30.0):
     return out
 
 
+def drop_in_step(p, dev, steps=20):
+    """The same optimisation step the way a maintainer gets it by only swapping the import:
+    RBSolver.forward through dr.rasterize / dr.interpolate / dr.antialias per (view, link) -- or the fused op -- under torch
+    autograd with torch.optim.Adam, recorded once in a torch.cuda.CUDAGraph (RBSolverTrainer(graph=True)) and replayed.
+    Same views, intrinsics and reference masks as the headline.  Informational: the headline is the launch chain."""
+    from easyhec_amd.config import Cfg
+    from easyhec_amd.rb_solver import RBSolver
+    from easyhec_amd.trainer import RBSolverTrainer
+    tr0 = p["trainer"]
+    res = {}
+    for fusedflag in (False, True):
+        cfg = Cfg()
+        cfg.model.rbsolver.H, cfg.model.rbsolver.W = p["H"], p["W"]
+        cfg.model.rbsolver.init_Tc_c2b = p["Tc_init"].tolist()
+        cfg.model.rbsolver.use_fused = fusedflag
+        model = RBSolver(cfg, meshes=p["robot"].meshes).to(dev)
+        batch = {k: tr0.batch[k] for k in ("mask", "link_poses", "K")}
+        tr = RBSolverTrainer(cfg, model, batch, graph=True)
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        res[("fused_op_autograd" if fusedflag else "three_ops") + "_graph_ms_per_step"] = round(ms, 3)
+        res[("fused_op_autograd" if fusedflag else "three_ops") + "_loss"] = round(float(tr.last_loss), 3)
+        del tr, model
+    return res
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: libraries that chat on stdout (RCCL prints a version banner when a
     # communicator is created) go to stderr for the whole run
@@ -224,6 +256,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="reference-shaped torch autograd step instead of the HIP launch chain")
     ap.add_argument("--workload", default=WORKLOAD, help="side measurements only; the headline is the default")
     ap.add_argument("--no-with-mask", action="store_true", help="skip the with-mask leg (profiling runs: one launch form per kernel)")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the drop-in (three ops under autograd, graph replay) step, ~20 s")
     ap.add_argument("--no-side", action="store_true", help="skip the side workloads (the other BASELINE configs, ~0.5 s each)")
     ap.add_argument("--graph", action="store_true", help="replay the launch chain as a natively captured hipGraph (saves host time only)")
     args = ap.parse_args()
@@ -322,6 +355,13 @@ def main():
             except Exception as e:  # a side measurement must never cost the headline line
                 side[name] = {"error": f"{type(e).__name__}: {e}"}
 
+    drop_in = None
+    if world == 1 and rank == 0 and not args.no_drop_in and args.workload == WORKLOAD and not args.eager:
+        try:
+            drop_in = drop_in_step(p, dev)
+        except Exception as e:  # informational: must never cost the headline line
+            drop_in = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         frames = p["n_views"] * args.steps
         fps = frames / elapsed
@@ -404,6 +444,8 @@ def main():
             out["with_mask_value"] = round(p["n_views"] / (with_mask_ms * 1e-3), 1)
         if side is not None:
             out["side"] = side
+        if drop_in is not None:
+            out["drop_in"] = drop_in
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms
             out["allreduce_8float_us"] = round(allreduce_us, 2)
