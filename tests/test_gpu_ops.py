@@ -155,6 +155,56 @@ def test_rasterize_calls_of_changing_shape_on_one_context(env, oracle, raster_pa
         assert (r.cpu().numpy() == ref).all(), (kind, H, W)
 
 
+@pytest.mark.parametrize("H,W,seed", [(720, 1280, 0), (333, 517, 1), (64, 2000, 2), (1100, 90, 3)])
+def test_rasterizer_forms_on_slivers_big_and_clipped_triangles(env, oracle, H, W, seed):
+    """What the direct form's work distribution has to get right: long thin triangles (boxes far larger than their
+    coverage), triangles that fill the screen (spread over the bands of rows), triangles crossing the eye plane (clipped
+    into two), many micro-triangles -- all in one mesh, several overlapping in depth.  Both forms == the oracle, bit for bit
+    (ids, barycentrics, depth, pixel differentials), in instance mode with two images."""
+    dr, dev = env[0], env[2]
+    ctx = dr.RasterizeCudaContext()
+    rng = np.random.default_rng(100 + seed)
+    parts = []
+    pos_small, tri_small = helpers.random_mesh(rng, 1500)
+    parts.append((pos_small, tri_small))
+    # slivers: two close points and one far away
+    sl = []
+    for _ in range(300):
+        a = rng.uniform(-1.1, 1.1, size=2)
+        b = a + rng.uniform(-0.01, 0.01, size=2)
+        c = rng.uniform(-1.3, 1.3, size=2)
+        for xy in (a, b, c):
+            w = rng.uniform(0.7, 1.5)
+            sl.append([xy[0] * w, xy[1] * w, rng.uniform(-0.6, 0.6) * w, w])
+    parts.append((np.array(sl, np.float32), np.arange(900, dtype=np.int32).reshape(-1, 3)))
+    # screen-filling triangles at several depths, and triangles crossing the eye plane / the near plane
+    big = [[-3, -3, 0.7, 1], [3, -3, 0.7, 1], [0, 3, 0.7, 1], [-2.5, 2, 0.3, 1], [2.5, 2, 0.3, 1], [0, -4, 0.9, 1],
+           [-0.8, -0.8, 0.1, 1.0], [0.8, -0.7, 0.1, 1.0], [0.1, 2.0, -1.5, -0.4],
+           [-1.5, 0.2, -0.9, 0.5], [1.5, 0.3, 0.4, 1.2], [0.0, -1.2, 0.2, 0.9]]
+    parts.append((np.array(big, np.float32), np.arange(12, dtype=np.int32).reshape(-1, 3)))
+    pos, tri, off = [], [], 0
+    for p_, t_ in parts:
+        pos.append(p_)
+        tri.append(t_ + off)
+        off += p_.shape[0]
+    pos, tri = np.concatenate(pos), np.concatenate(tri)
+    tri = tri[rng.permutation(tri.shape[0])]
+    posb = np.stack([pos, pos * np.array([-1, 1, 1, 1], np.float32)])
+    ref, dbr = oracle.rasterize(posb, tri, [H, W])
+    assert (ref[..., 3] > 0).mean() > 0.5
+    old = os.environ.get("EHR_RASTER_DIRECT_MAX")
+    try:
+        for form in ("1000000000", "0"):
+            os.environ["EHR_RASTER_DIRECT_MAX"] = form
+            r, db = dr.rasterize(ctx, t(posb, dev), t(tri, dev), [H, W])
+            assert (r.cpu().numpy() == ref).all() and (db.cpu().numpy() == dbr).all(), (form, H, W)
+    finally:
+        if old is None:
+            os.environ.pop("EHR_RASTER_DIRECT_MAX", None)
+        else:
+            os.environ["EHR_RASTER_DIRECT_MAX"] = old
+
+
 def test_rasterizer_forms_alternate_on_one_context(env, oracle):
     """The two forms keep separate state on a context (queue counters all zero / key image all ones between calls);
     alternating them call by call must not disturb either."""
