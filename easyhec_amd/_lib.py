@@ -79,6 +79,10 @@ def lib():
     return _lib
 
 
+EHR_ERR_OVERFLOW = -3  # include/ehr.h
+EHR_ERR_RETRY = -4
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().ehr_last_error().decode("utf-8", "replace")

@@ -140,8 +140,13 @@ int ehr_fused_status(ehr_ctx* ctx) {
     int m4[4] = {0, 0, 0, 0};
     int rc0 = vbuf_meta_read(ctx, m4);
     if (rc0) return rc0;
-    if (m4[EHR_META_OVERFLOW])
+    if (m4[EHR_META_OVERFLOW] & 4) ctx->vb_slow_needed = true;  // (VB_FLAG_NEED_SLOW; a captured chain must be re-captured)
+    if (m4[EHR_META_OVERFLOW] & ~4)
         return fail(EHR_ERR_OVERFLOW, "fused path: an accumulator or the blended-pair spill pool overflowed");
+    if (m4[EHR_META_OVERFLOW] & 4)
+        return fail(EHR_ERR_RETRY, "fused path: the step met triangles for the general-triangle pass (near-plane clipping or "
+                    "more than 512 pixels wide), which the solver step had not been launching; it is switched on now: run the "
+                    "step again (its NaN left the optimiser state untouched; re-capture a captured chain)");
     return EHR_OK;
 }
 

@@ -76,6 +76,7 @@ struct ehr_ctx {
                             // calls: the last kernel of a drop-in rasterize call zeroes every word the call dirtied
                             // (a fill kernel per call was a tenth of the three-op step's launches)
     unsigned long long counts_clean = ~0ull;  // == counts.moves: the buffer is known to be all zero
+    bool vb_slow_needed = false;  // a solver step met a triangle for the general path: vb_slow_kernel is launched from now on
     ehr::Scratch ranges;    // int32 [2 * B]: the per-image triangle ranges of a range-mode call
     ehr::Scratch rkeys;     // u64 [B * H * W]: key image of the drop-in rasterizer's direct form; ALL ONES between calls
     unsigned long long rkeys_clean = ~0ull;  // == rkeys.moves: known to be all ones

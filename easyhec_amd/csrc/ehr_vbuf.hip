@@ -1243,6 +1243,23 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
 // triangle id of every region pixel (jid) and a descriptor (jdesc; -1 and jn = -1 when nothing was drawn); the resolve
 // kernel takes it from there.  No workgroup barriers after the prologue except in the heavy-job phase; thousands of
 // independent waves hide each other's latency.
+// A job that met a triangle for the general path goes on the list vb_slow_kernel works off.  The solver-step form of the
+// chain does not launch that kernel until a step has needed it (slow_list == NULL: an empty launch costs the step 1.7 us
+// and a robot in front of the camera never has such a triangle): then the job is marked empty and the step REPORTS it --
+// overflow bit 4, so loss and gradient come out NaN and the optimiser state stays as it was; ehr_fused_status() returns
+// EHR_ERR_RETRY and switches the pass on for the context's later calls.
+#define VB_FLAG_NEED_SLOW 4
+__device__ __forceinline__ void vb_put_aside(int4* __restrict__ slow_list, int* __restrict__ meta, int* __restrict__ jn,
+                                             int* __restrict__ jdesc, int job, int u, int tx, int ty) {
+    if (slow_list) {
+        slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
+    } else {
+        atomicOr(&meta[EHR_META_OVERFLOW], VB_FLAG_NEED_SLOW);
+        jn[job] = -1;
+        jdesc[job] = -1;
+    }
+}
+
 #ifndef VB_JOB_WAVES
 #define VB_JOB_WAVES 4
 #endif
@@ -1403,7 +1420,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         if (any_drawn == 1) vb_publish(A, S0.key, S0.cov, job, u, tx, ty, wave, 4);  // every wave its share of the words
         if (wave == 0) {
             if (any_drawn & 2) {  // put aside for vb_slow_kernel
-                if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
+                if (lane == 0) vb_put_aside(slow_list, meta, jn, jdesc, job, u, tx, ty);
             } else if (any_drawn) {
             } else if (lane == 0) {
                 jn[job] = -1;
@@ -1552,7 +1569,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
             continue;
         }
         if (drawn < 0) {  // a triangle for the general path (near-plane clipping, huge extent): put the job aside
-            if (lane == 0) slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
+            if (lane == 0) vb_put_aside(slow_list, meta, jn, jdesc, job, u, tx, ty);
             continue;
         }
         if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
@@ -2700,13 +2717,18 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         if (time_it) EHR_HIP(hipEventRecord(ev[1], stream));
         // stage 1: jobs = (view, link, tile) -> coverage and the triangle ids the silhouette analysis will ask for
         const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
+        // stage 1a (below) is launched by the stateless render call always, by the solver step only once a step needed it
+        const bool with_slow = !tail || ctx->vb_slow_needed;
         vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg,
-                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov, slow_list, heavy_t, med_t);
+                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov,
+                                                    with_slow ? slow_list : nullptr, heavy_t, med_t);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
         static const int slow_grid = getenv("EHR_VB_SLOW_GRID") ? atoi(getenv("EHR_VB_SLOW_GRID")) : 32;  // tuning knob
-        vb_slow_kernel<<<std::max(1, slow_grid), 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
-        EHR_LAUNCH_CHECK();
+        if (with_slow) {
+            vb_slow_kernel<<<std::max(1, slow_grid), 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
+            EHR_LAUNCH_CHECK();
+        }
         if (time_it) EHR_HIP(hipEventRecord(ev[2], stream));
         // stage 1b: drawn jobs -> per-link values and blended pairs
         const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;

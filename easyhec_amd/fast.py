@@ -178,25 +178,33 @@ class FusedPoseStep:
         self._graph = True
 
     def recover_from_overflow(self):
-        """Call when a step's loss came back NaN.  Synchronises.  If the context reports an overflow and the plan was
-        slot-limited, plans again with a slot for every (view, link, tile), re-binds the reference masks, re-captures the
-        graph if there was one, and returns True: the steps since the overflow changed nothing (dof, Adam moments and step
+        """Call when a step's loss came back NaN.  Synchronises.  If the context reports that the step needed the
+        general-triangle pass (EHR_ERR_RETRY: the context launches it from now on) the graph, if any, is re-captured; if it
+        reports an overflow and the plan was slot-limited, plans again with a slot for every (view, link, tile), re-binds
+        the reference masks and re-captures.  Returns what it did (a non-empty string) in both cases, False if the context
+        reports nothing: the steps since the overflow changed nothing (dof, Adam moments and step
         counter stay untouched on a NaN), so the caller simply goes on stepping.  Raises on any other overflow."""
-        try:
-            fused.check_status(self.glctx)
-        except RuntimeError:
-            if self.slack == 0.0:
-                raise
-        else:
+        with torch.cuda.device(self.glctx.device):
+            rc = _lib.lib().ehr_fused_status(self.glctx.handle)
+        if rc == 0:
             return False
         had_graph = bool(self._graph)
+        if rc == _lib.EHR_ERR_RETRY:
+            # the step met triangles for the general-triangle pass, which the chain had not been launching: the context
+            # has switched it on; a captured chain is recorded again with it
+            if had_graph:
+                self.release_graph()
+                self.capture()
+            return "general-triangle pass"
+        if self.slack == 0.0:
+            _lib.check(rc, "fused render")
         self.release_graph()
         self.slack = 0.0
         fused._ensure_plan(self.glctx, self.scene, self.B, self.H, self.W, slack=0.0)
         fused.bind_ref(self.glctx, self.scene, self.ref)
         if had_graph:
             self.capture()
-        return True
+        return "job slots"
 
     def release_graph(self):
         if self._graph:

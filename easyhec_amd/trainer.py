@@ -200,9 +200,12 @@ class RBSolverTrainer:
                 if lv != lv and self.fast is not None:
                     # the chain reports an internal overflow as NaN (and leaves dof / Adam state untouched): either the
                     # slot-limited plan was too small -- planned again with every slot, the solve goes on -- or it says why
-                    if self.fast.recover_from_overflow():
+                    what = self.fast.recover_from_overflow()
+                    if what:
                         if log is not None:
-                            log(f"step {self.global_steps}: job slots overflowed; planned again with a slot per (view, link, tile)")
+                            log(f"step {self.global_steps}: job slots overflowed; planned again with a slot per (view, link, tile)"
+                                if what == "job slots" else
+                                f"step {self.global_steps}: triangles at the near plane; the general-triangle pass joins the chain")
                         continue
                     from . import fused
                     fused.check_status(self.fast.glctx)

@@ -32,6 +32,7 @@ extern "C" {
 #define EHR_ERR_INVALID (-1)   /* bad argument */
 #define EHR_ERR_HIP (-2)       /* a HIP runtime call failed */
 #define EHR_ERR_OVERFLOW (-3)  /* internal work buffer overflow (reported, never silent) */
+#define EHR_ERR_RETRY (-4)     /* the step was reported as NaN for a reason the library has already fixed: run it again */
 
 typedef struct ehr_ctx ehr_ctx;
 
@@ -121,7 +122,7 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
 int ehr_render_mask_loss(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
                          const int32_t* vert_link, const int32_t* opp, const float* mvp, const float* ref, int B,
                          int L, int V, int T, int H, int W, float* mask, float* loss, float* grad_mvp, void* stream);
-int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0 or EHR_ERR_OVERFLOW */
+int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0, EHR_ERR_OVERFLOW or EHR_ERR_RETRY (see ehr_solver_step) */
 
 /* Binds a reference-mask batch ref [B,H,W] (the planned shape) to the plan.  The reference masks of a solve do not
  * change (rb_solver.py:70 compares every step with the same dps['mask']), so the part of the frame loss that comes from
@@ -167,8 +168,12 @@ int ehr_pose_backward(const float* grad_mvp, const float* loss, const float* K, 
 int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* red, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
 
-/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 5 launches (vertex + raster records, jobs, general-triangle jobs -- normally none --, resolve,
- * composite + finish):
+/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 4 launches (vertex + raster records, jobs, resolve,
+ * composite + finish; a fifth one, the general-triangle pass for jobs with a triangle that crosses the near plane or is
+ * wider than 512 pixels, joins the chain once a step has needed it: that step is reported as NaN like an overflow -- loss,
+ * gradient NaN, optimiser state untouched --, ehr_fused_status() then returns EHR_ERR_RETRY and switches the pass on for
+ * the context's later calls; run the step again, and re-capture the chain if it was captured in a graph.  A robot in
+ * front of the camera never has such a triangle; the stateless ehr_render_mask_loss always launches the pass):
  * ehr_pose_forward is merged into the vertex kernel (which also does the per-step housekeeping) and ehr_pose_backward +
  * ehr_pose_adam into the finish stage of the composite kernel.  Same arithmetic and outputs as calling the pieces one by one:
  * mvp [B,L,16], tc_jac [7,16], loss_b [B], grad_mvp [B,L,16], red [8], loss_out [1], grad_out [6] are all written.

@@ -536,6 +536,59 @@ def test_default_launch_chain_recovers_from_a_slot_overflow(env, xarm7):
     assert torch.equal(ends[0][0], ends[1][0])                # ... to the same pose, bit for bit
 
 
+def test_solver_step_switches_the_general_triangle_pass_on_when_a_step_needs_it(env, xarm7):
+    """the solver step's chain does not launch the (normally empty) general-triangle pass.  A
+    camera so close that triangles cross the near plane needs it: the first step reports that (NaN loss, dof and Adam
+    untouched; ehr_fused_status -> EHR_ERR_RETRY), the pass joins the chain -- also the captured one -- and the solve ends
+    exactly where a solve on a context that had the pass from the start ends."""
+    fused, _, scene, dev = env
+    from easyhec_amd import _lib
+    from easyhec_amd.config import Cfg
+    from easyhec_amd.rb_solver import RBSolver
+    from easyhec_amd.trainer import RBSolverTrainer
+    from easyhec_amd.config import XARM7_K_1280x720
+    from easyhec_amd.synthetic import camera_Tc_c2b, make_views, scaled_K
+    H, W, B = 240, 320, 2
+    K = scaled_K(XARM7_K_1280x720, 0.25, W, H, True)
+    K[:2, :2] *= 12.0                            # a 12x zoom from 45 cm: triangles of several hundred pixels, wider than the
+    _, lp = make_views(xarm7, B, seed=4)         # 512 the 32-bit edge functions of the job kernel's rasterizer cover
+    Tc = camera_Tc_c2b(radius=0.45, lift=0.2)
+    cfg = Cfg()
+    cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
+    cfg.model.rbsolver.init_Tc_c2b = np.asarray(Tc).tolist()
+    cfg.solver.log_interval = 1
+    ref = torch.zeros((B, H, W), device=dev)
+    ref[:, 8:200, 10:300] = 1.0
+    batch = {"mask": ref, "link_poses": torch.tensor(lp, dtype=torch.float32, device=dev),
+             "K": torch.tensor(np.array(K), dtype=torch.float32, device=dev)[None].repeat(B, 1, 1)}
+    ends = []
+    for graph in (False, True, None):   # None: the pass switched on before the first step
+        model = RBSolver(cfg, meshes=xarm7.meshes).to(dev)
+        tr = RBSolverTrainer(cfg, model, batch, fast=True, graph=bool(graph))
+        tr.fast.slack = 0.0             # (every job slot: this test is about the other report)
+        fused._ensure_plan(tr.fast.glctx, tr.fast.scene, B, H, W, slack=0.0)
+        fused.bind_ref(tr.fast.glctx, tr.fast.scene, tr.fast.ref)
+        if graph:
+            tr.fast.release_graph()
+            tr.fast.capture()
+        logs = []
+        if graph is None:
+            tr.step()                                                   # reported ...
+            torch.cuda.synchronize()
+            assert _lib.lib().ehr_fused_status(tr.fast.glctx.handle) == _lib.EHR_ERR_RETRY
+            assert _lib.lib().ehr_fused_status(tr.fast.glctx.handle) == _lib.EHR_ERR_RETRY   # (until a step has run with it)
+            assert int(tr.fast.step_t) == 0                            # ... and nothing moved
+            hist = tr.fit(num_steps=5, log=logs.append)
+            assert not any("general-triangle" in l for l in logs), logs
+        else:
+            hist = tr.fit(num_steps=6, log=logs.append)
+            assert any("general-triangle pass joins" in l for l in logs), logs
+        assert all(np.isfinite(l) for _, l in hist[-5:]), hist
+        ends.append((model.dof.detach().clone(), int(tr.fast.step_t)))
+    assert [e[1] for e in ends] == [5, 5, 5]
+    assert torch.equal(ends[0][0], ends[1][0]) and torch.equal(ends[0][0], ends[2][0])
+
+
 @pytest.mark.parametrize("H,W,scale,B", [(720, 1280, 1.0, 8), (100, 150, 0.12, 3)])
 def test_bound_reference_is_bit_identical(env, xarm7, H, W, scale, B):
     """ehr_fused_bind_ref caches, per tile, the fixed-point sum(ref^2) the composite stage would add for a tile no link
