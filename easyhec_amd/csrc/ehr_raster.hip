@@ -395,7 +395,7 @@ using namespace ehr;
 
 extern "C" {
 
-int ehr_version(void) { return 4; }
+int ehr_version(void) { return 5; }
 
 const char* ehr_last_error(void) { return g_last_error.c_str(); }
 

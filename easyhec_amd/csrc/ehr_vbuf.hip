@@ -7,7 +7,7 @@
 // project to micro-triangles (median bounding box 8 px, a fifth of the non-empty boxes cover no pixel centre at all), for
 // which building and draining per-tile queues cost more than the coverage tests themselves.  Instead ehr_fused_plan
 // groups every link's triangles ONCE into clusters of 64 spatially close ones (recursive median split of the centroids
-// in object space, valid for every pose), and a step is five launches per chunk of views:
+// in object space, valid for every pose), and a step is four or five launches per chunk of views:
 //
 //   vb_vertex_kernel    [pose forward] + clip-space vertices (posc) + one wave per cluster: transforms the cluster's
 //                       triangles, snaps them, tests small boxes exactly (a triangle that covers no pixel centre is
@@ -22,7 +22,8 @@
 //                       are depth tested (ds_min_u64 on ordered(z/w) << 32 | triangle: order independent, hence the
 //                       oracle's z-buffer bit for bit wherever anyone will look).  Last step's heaviest jobs go first
 //                       on whole workgroups, its long ones as the waves' static first jobs.
-//   vb_slow_kernel      (normally empty) jobs that met a triangle for the general path: near-plane clipping, 64-bit edges.
+//   vb_slow_kernel      jobs that met a triangle for the general path: near-plane clipping, 64-bit edges (normally none; the
+//                       solver step launches it only once a step has needed it, see vb_put_aside).
 //   vb_resolve_kernel   one wave per drawn job: covered/uncovered pixel pairs by bit arithmetic on the coverage bitmap,
 //                       silhouette analysis of the hits, the link's 256 antialiased values + the blended pairs -> job slot.
 //   vb_composite_kernel one wave per tile that holds a job (every tile without a bound reference mask): sums the links'

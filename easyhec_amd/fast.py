@@ -120,8 +120,8 @@ class FusedPoseStep:
         m, sc = self.model, self.scene
         dof = m.dof.data
         hist = m.history_ops
-        # one C call = 5 launches: [pose fwd + vertices + raster records] -> jobs -> general-triangle jobs (normally
-        # none) -> resolve -> composite [+ in its last workgroup: accumulators + pose bwd (+ Adam)]
+        # one C call = 4 launches: [pose fwd + vertices + raster records] -> jobs [-> general-triangle jobs, once a step
+        # has needed them] -> resolve -> composite [+ in its last workgroup: accumulators + pose bwd (+ Adam)]
         _lib.check(lib.ehr_solver_step(
             self.glctx.handle, _lib.ptr(sc.verts), _lib.ptr(sc.tris), _lib.ptr(sc.tri_link), _lib.ptr(sc.vert_link),
             _lib.ptr(sc.opp), _lib.ptr(self.K), _lib.ptr(self.link_poses), _lib.ptr(self.ref), self.B, self.L,
