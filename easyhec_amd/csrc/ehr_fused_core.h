@@ -78,22 +78,43 @@ __device__ __forceinline__ void finish_body(const BinGeom& g, int B, const long 
         for (int k = 0; k < nls; k++) s += acc_load(&facc[(size_t)b * acc_stride + 12 * L + k * lstride]);
         return fix_get(s);
     };
-    if (nls == 32) {  // one slot per lane, half a wave per view: a single round trip instead of 32 dependent adds
-        for (int base = 0; base < min(B, 256); base += 8) {
-            const int b = base + (tid >> 5), k = tid & 31;
-            long long s = (b < B) ? acc_load(&facc[(size_t)b * acc_stride + 12 * L + k * lstride]) : 0;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            if (k == 0 && b < B && b < 256) vloss[b] = fix_get(s + (vtot ? vtot[b] : 0ll));
-        }
-    } else if (tid < B) {
-        vloss[tid] = view_loss_slow(tid);
-    }
+    // Frame losses.  nls == 32: one slot per lane, half a wave per view -- a single round trip instead of 32 dependent
+    // adds -- and the lane that ends up with a view's sum stores loss[b] and keeps it as ITS share of sum_b loss_b: no
+    // hand-over through LDS, no barrier, so the reads below (gradient accumulators, link poses, Jacobian) travel with
+    // these instead of after them.
     const bool bad = __hip_atomic_load(&meta[EHR_META_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    __syncthreads();
-    auto view_loss = [&](int b) { return b < 256 ? vloss[b] : view_loss_slow(b); };
     const float nanv = __int_as_float(0x7fc00000);  // overflow => NaN, never a silently wrong loss
-    for (int i = tid; i < B; i += 256) loss[i] = bad ? nanv : view_loss(i);
+    double la_mine = 0.0;
+    if (nls == 32) {
+        const int k = tid & 31;
+        for (int base = 0; base < B; base += 32) {  // four groups of 8 views per round trip
+            long long s4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int b = base + 8 * j + (tid >> 5);
+                s4[j] = (b < B) ? acc_load(&facc[(size_t)b * acc_stride + 12 * L + k * lstride]) : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int b = base + 8 * j + (tid >> 5);
+                if (base + 8 * j >= B) break;  // (workgroup-uniform)
+                long long s = s4[j];
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                if (k == 0 && b < B) {
+                    const float lv = bad ? nanv : fix_get(s + (vtot ? vtot[b] : 0ll));
+                    loss[b] = lv;
+                    la_mine += (double)lv;
+                }
+            }
+        }
+    } else {
+        for (int b = tid; b < B; b += 256) {
+            const float lv = bad ? nanv : view_loss_slow(b);
+            loss[b] = lv;
+            la_mine += (double)lv;
+        }
+    }
     auto grad16 = [&](int bl, float* G) {
         // rows x, y, w of the 4x4 gradient; the z row never receives gradient on this path
         const int b = bl / L, l = bl - b * L;
@@ -128,8 +149,8 @@ __device__ __forceinline__ void finish_body(const BinGeom& g, int B, const long 
 #pragma unroll
                 for (int e = 0; e < 16; e++) grad_mvp[(size_t)i * 16 + e] = G[e];
         },
-        [&](int b) { return bad ? nanv : view_loss(b); }, tail.K, tail.link_poses, tail.tc_jac, B, L, g.H, g.W, tail.n,
-        tail.f, tail.red, S, red_lds);
+        [&](int) { return 0.f; }, tail.K, tail.link_poses, tail.tc_jac, B, L, g.H, g.W, tail.n, tail.f, tail.red, S, red_lds,
+        &la_mine);
     __syncthreads();
     if (!tail.defer_adam)
         pose_adam_apply(st, tail.dof, tail.m, tail.v, tail.step, red_lds, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,

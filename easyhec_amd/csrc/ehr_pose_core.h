@@ -186,7 +186,8 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
                                                       const float* __restrict__ link_poses,
                                                       const float* __restrict__ tc_jac, int B, int L, int H, int W,
                                                       float n, float f, float* __restrict__ red, double (*S)[17],
-                                                      float* red_lds) {
+                                                      float* red_lds, const double* la_pre = nullptr) {
+    // (la_pre: this thread's share of sum_b loss_b, already known to the caller -- get_loss is not called then)
     // Jacobian rows are needed last but depend on nothing computed here: fetch them first (into LDS, not registers:
     // this body also runs inside the composite kernel, which is compiled for 80 registers)
     __shared__ float Js[6][16];
@@ -202,9 +203,13 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     double la = 0.0;
     for (int i = threadIdx.x >> 2; i < B * L; i += blockDim.x >> 2) {
+        // (the link pose is requested BEFORE the gradients: get_g may read them with atomic loads, behind which the
+        //  compiler does not move an ordinary load -- a round trip of its own otherwise)
+        float lp[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) lp[k] = link_poses[(size_t)i * 16 + k];
         float G[16];
         get_g(i, G);
-        const float* lp = link_poses + (size_t)i * 16;
         float M[4];
         for (int c = 0; c < 4; c++) {
             float s = 0.f;
@@ -217,7 +222,10 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
             acc[c] += (double)s;
         }
     }
-    for (int i = threadIdx.x; i < B; i += blockDim.x) la += (double)get_loss(i);
+    if (la_pre)
+        la = *la_pre;
+    else
+        for (int i = threadIdx.x; i < B; i += blockDim.x) la += (double)get_loss(i);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // lanes with the same r hold the same row: butterfly over the lane bits above the row index, then the four waves
 #pragma unroll
