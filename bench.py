@@ -236,6 +236,12 @@ def drop_in_step(p, dev, steps=20):
         res[("fused_op_autograd" if fusedflag else "three_ops") + "_graph_ms_per_step"] = round(ms, 3)
         res[("fused_op_autograd" if fusedflag else "three_ops") + "_loss"] = round(float(tr.last_loss), 3)
         del tr, model
+    # SURVEY 8d's secondary byte count: the reference's traffic SHAPE through the three ops is 212-228 B per pixel of every
+    # (view, link) image (fwd + bwd); the rate below is that count over the measured step -- what the reference's own
+    # ops would have to sustain to match it, not bytes this library moves (it writes no rast_db, one colour channel, ...)
+    nbytes = 220.0 * p["n_views"] * len(p["robot"].meshes) * p["H"] * p["W"]
+    res["three_ops_reference_shape_bytes_per_step"] = int(nbytes)
+    res["three_ops_reference_shape_gbs"] = round(nbytes / (res["three_ops_graph_ms_per_step"] * 1e-3) / 1e9, 1)
     return res
 
 
