@@ -1,6 +1,7 @@
-"""Randomised parity sweep (test infrastructure, run by hand on the GPU box; not collected by pytest): the fused op and the scoring op against the CPU oracle on random
-resolutions, zooms, camera distances (down to a few centimetres from the robot) and joint configurations -- masks and
-counts bit-exact, losses / gradients within the suite's tolerances.  python tests/fuzz_parity.py [--cases 120] [--seed 0]"""
+"""Randomised parity sweep (test infrastructure, run by hand on the GPU box; not collected by pytest): the fused op, the scoring op and
+the drop-in ops (both forms of dr.rasterize, dr.antialias forward) against the CPU oracle on random resolutions, zooms,
+camera distances (down to a few centimetres from the robot) and joint configurations -- masks, counts, rasterizer
+outputs and antialiased images bit-exact, losses / gradients within the suite's tolerances.  python tests/fuzz_parity.py [--cases 120] [--seed 0]"""
 import argparse
 import os
 import sys
@@ -33,6 +34,7 @@ def main():
     ctx = dr.RasterizeCudaContext()
     t0 = time.time()
     worst = dict(loss=0.0, grad=0.0)
+    nops = 0
     for case in range(a.cases):
         name = "xarm7" if rng.uniform() < 0.75 else "franka"
         rb, scene = robots[name], scenes[name]
@@ -69,7 +71,27 @@ def main():
             s_ref, c_ref = oracle.mask_variance(verts, tris, vl, mv, H, W, return_counts=True)
             _, sc, cn = se.mask_variance(ctx, scene, torch.tensor(mv, device=dev), H, W, return_counts=True)
             assert (cn.cpu().numpy() == c_ref).all() and (sc.cpu().numpy() == s_ref).all(), tag + ": scoring op differs"
-    print(f"fuzz ok: {a.cases} cases in {time.time() - t0:.1f} s, worst loss rel {worst['loss']:.1e}, grad rel {worst['grad']:.1e}")
+        if case % 4 == 1:   # the drop-in ops on one link of the same view: both forms of dr.rasterize, dr.antialias forward
+            l = int(rng.integers(len(rb.meshes)))
+            v, f = rb.meshes[l]
+            pos = oracle.transform_pos(mvp[0, l], v)                       # [1, V, 4]
+            r_ref, db_ref = oracle.rasterize(pos, f, [H, W])
+            tp, tf = torch.tensor(pos, device=dev), torch.tensor(f, device=dev)
+            old = os.environ.get("EHR_RASTER_DIRECT_MAX")
+            for form in ("1000000000", "0"):
+                os.environ["EHR_RASTER_DIRECT_MAX"] = form
+                r, db = dr.rasterize(ctx, tp, tf, [H, W])
+                assert (r.cpu().numpy() == r_ref).all() and (db.cpu().numpy() == db_ref).all(), tag + f": dr.rasterize form {form} link {l}"
+            if old is None:
+                os.environ.pop("EHR_RASTER_DIRECT_MAX", None)
+            else:
+                os.environ["EHR_RASTER_DIRECT_MAX"] = old
+            col = (r_ref[..., 3:4] > 0).astype(np.float32)
+            aa = dr.antialias(torch.tensor(col, device=dev), r, tp, tf)
+            assert (aa.cpu().numpy() == oracle.antialias(col, r_ref, pos, f)).all(), tag + f": dr.antialias link {l}"
+            nops += 1
+    print(f"fuzz ok: {a.cases} cases in {time.time() - t0:.1f} s, worst loss rel {worst['loss']:.1e}, grad rel {worst['grad']:.1e}; "
+          f"{nops} of them also through the drop-in ops (both rasterizer forms, antialias forward: bit-equal)")
 
 
 if __name__ == "__main__":
