@@ -26,7 +26,7 @@ int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_fused_plan: ctx is NULL");
     if (B <= 0 || L <= 0 || L > MAX_LINKS || V < 0 || T < 0 || H <= 0 || W <= 0 || H > 32768 || W > 32768)
         return fail(EHR_ERR_INVALID, "ehr_fused_plan: bad sizes (1 <= L <= %d)", MAX_LINKS);
-    if (!(slack >= 1.f)) slack = 0.f;  // default: a slot for every (view, link, tile)
+    if (!(slack > 0.f)) slack = 0.f;  // default (also NaN): a slot for every (view, link, tile)
     if (ctx->gexec) {  // a captured chain holds the old plan's pointers and shape
         EHR_HIP(hipGraphExecDestroy(ctx->gexec));
         ctx->gexec = nullptr;

@@ -2446,13 +2446,14 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     // raster records, job slots (3.5 KB each) -- is bounded to 24 GB of the 288 (EHR_VB_SCRATCH_MB) however many views a
     // call brings: a chunk costs a pass of the chain with its own tails, so chunks are as large as they may be (the reference
     // batches all frames of a data set in one step, configs/xarm7/example.yaml: batch_size 100).  A job = a (link, tile)
-    // pair whose boxes touch; by default one slot per (link, tile) is provided, so nothing can overflow; `slack` >= 1
-    // provides `slack` jobs per view tile instead (less scratch, larger chunks); a view that needs more (every pixel
-    // under more than `slack` link boxes on average) is reported (loss = NaN, ehr_fused_status).
+    // pair whose boxes touch; by default (`slack` <= 0) one slot per (link, tile) is provided, so nothing can overflow;
+    // `slack` > 0 provides `slack` jobs per view tile instead (a fraction is fine: a robot's links touch a twentieth of
+    // the tiles of a typical frame; less scratch, larger chunks); a view that needs more (every pixel under more than
+    // `slack` link boxes on average) is reported (loss = NaN, ehr_fused_status).
     BinGeom gp = make_geom(H, W, L);
     const size_t slot_bytes = 256 * sizeof(float) + VB_JOB_ITEMS * sizeof(VbItem) + VB_WORDS * sizeof(u64) + 2 * sizeof(int) +
                               VB_RN * sizeof(unsigned) + sizeof(int) + sizeof(int4);
-    const double jobs_per_view = ((slack >= 1.f) ? std::min((double)L, (double)slack) : (double)L) * gp.nt;
+    const double jobs_per_view = std::max(1.0, ((slack > 0.f) ? std::min((double)L, (double)slack) : (double)L) * gp.nt);
     const double view_bytes = jobs_per_view * slot_bytes + (double)NC * (64 * 40 + 8) + (double)std::max(V, 1) * 16 +
                               (double)L * gp.nt * 4;
     static const double budget = getenv("EHR_VB_SCRATCH_MB") ? atof(getenv("EHR_VB_SCRATCH_MB")) * 1048576.0 : 24576.0 * 1048576.0;

@@ -73,12 +73,18 @@ class FusedPoseStep:
         self.loss = torch.zeros((1,), device=dev)
         self.grad = torch.zeros((6,), device=dev)
         self.mask = torch.empty((self.B, self.H, self.W), device=dev)
-        # job slots: `slack` per view tile instead of one per (view, link, tile) -- 100 MB instead of 0.8 GB of scratch at 8
-        # views 720p x 8 links; the workloads here use a sixth of that.  A view that needs more (every pixel under more
-        # than `slack` link boxes on average) is REPORTED -- NaN loss, dof and Adam state untouched -- and
+        # job slots: `slack` per view tile (default: half as many slots as a view has tiles) instead of one per (view,
+        # link, tile) -- 50 MB instead of 0.8 GB of scratch at 8 views 720p x 8 links; the workloads here use a tenth of
+        # that (a robot's links touch ~5 % of a frame's tiles).  A view that needs more (every pixel under more than
+        # `slack` link boxes on average: a close-up) is REPORTED -- NaN loss, dof and Adam state untouched -- and
         # :meth:`recover_from_overflow` plans again with a slot for every (view, link, tile).  EHR_VB_SLACK overrides (0 = all).
+        # (Small images: at least 256 slots per view -- a link's box touches a few tiles however small the frame is.)
         import os
-        self.slack = float(os.environ.get("EHR_VB_SLACK", 1.0)) if slack is None else float(slack)
+        if slack is None and "EHR_VB_SLACK" not in os.environ:
+            ntiles = ((self.W + 31) // 32) * ((self.H + 7) // 8)
+            self.slack = max(0.5, 256.0 / ntiles)
+        else:
+            self.slack = float(os.environ["EHR_VB_SLACK"]) if slack is None else float(slack)
         fused._ensure_plan(self.glctx, self.scene, self.B, self.H, self.W, slack=self.slack)
         # the reference masks are constants of the solve: cache the loss of the tiles no link touches once
         # (ehr_fused_bind_ref; bit-identical results).  self.ref is this object's private copy, never written to.

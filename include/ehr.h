@@ -112,10 +112,10 @@ int ehr_antialias_grad(const float* color, const float* rast, const float* pos, 
  * Any number of views: a call's views go through the launch chain in chunks (one chunk up to 512 / L views; fewer per
  * chunk when the chunk's scratch -- clip-space vertices, raster records, 3.5 KB per (view, link, tile) job slot: 0.1 GB per
  * 1280x720 view of an 8-link robot -- would exceed 24 GB, EHR_VB_SCRATCH_MB), all inside the one call.  The hot calls never synchronise or allocate, so they can be
- * captured in a hipGraph; a new plan invalidates a captured graph.  `slack` < 1 (default): one job slot per (view, link,
+ * captured in a hipGraph; a new plan invalidates a captured graph.  `slack` <= 0 (default): one job slot per (view, link,
  * tile), nothing can overflow except the fixed-point accumulators (|sum| > 2^31) and a 16 MB spill pool for tiles with
- * more than 64 blended pairs per link; `slack` >= 1 provides only `slack` job slots per view tile (less scratch, larger
- * chunks).  An overflow makes loss[] NaN (never a silently wrong image), leaves the optimiser state untouched, and
+ * more than 64 blended pairs per link; `slack` > 0 provides only `slack` job slots per view tile (fractions allowed:
+ * 0.5 = half as many slots as the view has tiles; less scratch, larger chunks).  An overflow makes loss[] NaN (never a silently wrong image), leaves the optimiser state untouched, and
  * ehr_fused_status() returns EHR_ERR_OVERFLOW after synchronising. */
 int ehr_fused_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float slack, const float* verts,
                    const int32_t* tris, const int32_t* tri_link, const int32_t* opp);
