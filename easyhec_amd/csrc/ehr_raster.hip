@@ -534,12 +534,13 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     src.image_stride = ranges_host ? 0 : V;
 
     // Small launches (one link's mesh in one image: the reference's 64 calls per step) take the direct form: two kernels,
-    // no queues, nothing for the host to size or wait for.  EHR_RASTER_DIRECT_MAX (triangles x images; 0 = never) is a
+    // no queues, nothing for the host to size or wait for (its key image, 8 B per pixel of the call, stays with the context:
+    // calls of more than 64 M pixels take the queued form).  EHR_RASTER_DIRECT_MAX (triangles x images; 0 = never) is a
     // test / tuning hook, read per call.
     {
         const char* e = getenv("EHR_RASTER_DIRECT_MAX");
         const size_t direct_max = e ? (size_t)std::max(0ll, atoll(e)) : ((size_t)1 << 17);
-        if ((size_t)B * (size_t)tmax <= direct_max && (size_t)B * H * W <= ((size_t)1 << 28) && B <= 65535) {
+        if ((size_t)B * (size_t)tmax <= direct_max && (size_t)B * H * W <= ((size_t)1 << 26) && B <= 65535) {
             const size_t npix = (size_t)B * H * W;
             if ((rc = ctx->rkeys.reserve(npix * sizeof(u64)))) return rc;
             if (ctx->rkeys_clean != ctx->rkeys.moves) {
