@@ -202,16 +202,16 @@ __device__ __forceinline__ AAHit aa_pair(const float4* __restrict__ rast, const 
         cy += d;
     }
     if (t < 0 || t >= T) return h;
+    // (the triangle's corners and its neighbours' opposite corners are requested together: both follow from t alone)
     const int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    const int ov[3] = {opp[3 * t], opp[3 * t + 1], opp[3 * t + 2]};
     if ((unsigned)vi[0] >= (unsigned)V || (unsigned)vi[1] >= (unsigned)V || (unsigned)vi[2] >= (unsigned)V) return h;
     const float4* pb = pos + (range_mode ? 0 : (size_t)b * V);
     float4 p[3], o[3];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        p[k] = pb[vi[k]];
-        const int ov = opp[3 * t + k];
-        o[k] = ((unsigned)ov < (unsigned)V) ? pb[ov] : p[k];
-    }
+    for (int k = 0; k < 3; k++) p[k] = pb[vi[k]];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pb[ov[k]] : p[k];
     const AAPair a = aa_analyze(p, o, cx, cy, d, chose0, W, H);
     if (!a.found) return h;
     h.found = true;
