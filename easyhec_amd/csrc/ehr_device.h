@@ -341,4 +341,37 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Twelve wave sums at once, 14 shuffles instead of 72: at every level a lane keeps half of the values it still holds and
+// hands the other half to its partner (12 -> 6 -> 3 -> 2 | 1 -> 1), so the sums end up spread over the lanes -- lane l
+// holds the sum of element  e(l) = 6 b32 + 3 b16 + (b8 ? 2 : b4)  (b = bits of l).  The pairings are wave_sum's (offsets
+// 32, 16, ..., 1, own value + partner's), so every sum equals wave_sum(v[e]) bit for bit.
+__device__ __forceinline__ int wave_sum12_element(int lane) {
+    return 6 * ((lane >> 5) & 1) + 3 * ((lane >> 4) & 1) + ((lane & 8) ? 2 : ((lane >> 2) & 1));
+}
+__device__ __forceinline__ float wave_sum12(const float v[12], int lane) {
+    const bool b32 = lane & 32, b16 = lane & 16, b8 = lane & 8, b4 = lane & 4;
+    float a[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float keep = b32 ? v[6 + i] : v[i], send = b32 ? v[i] : v[6 + i];
+        a[i] = keep + __shfl_xor(send, 32, 64);
+    }
+    float b[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float keep = b16 ? a[3 + i] : a[i], send = b16 ? a[i] : a[3 + i];
+        b[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    // 3 -> (2 | 1): lanes with bit 8 clear keep b[0], b[1]; the others b[2]
+    const float r0 = __shfl_xor(b8 ? b[0] : b[2], 8, 64);  // clear lanes receive b[0], set lanes b[2]
+    const float r1 = __shfl_xor(b[1], 8, 64);              // (only the clear lanes use it)
+    const float c0 = (b8 ? b[2] : b[0]) + r0, c1 = b[1] + r1;
+    // clear lanes: 2 -> 1 over bit 4; set lanes: their one value summed over bit 4
+    const float keep = b8 ? c0 : (b4 ? c1 : c0), send = b8 ? c0 : (b4 ? c0 : c1);
+    float d = keep + __shfl_xor(send, 4, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 1, 64);
+    return d;
+}
+
 }  // namespace ehr

@@ -2151,13 +2151,9 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
 #pragma unroll
                 for (int c = 0; c < 4; c++) G[4 * rr + c] += g1[rr] * h1[c] + g2[rr] * h2[c];
         }
-        float mine = 0.f;
-#pragma unroll
-        for (int k = 0; k < 12; k++) {
-            const float s = wave_sum(G[k]);
-            if (lane == k) mine = s;
-        }
-        if (lane < 12) fix_add(&vacc[12 * l + lane], mine, meta);
+        // the twelve sums in 14 shuffles (bit-equal to twelve wave_sum calls); one lane per element adds its sum
+        const float mine = wave_sum12(G, lane);
+        if ((lane & 3) == 0 && (lane & 12) != 12) fix_add(&vacc[12 * l + wave_sum12_element(lane)], mine, meta);
     }
     }
     // ---- the workgroup whose atomics are performed last runs the finish stage.  Every wave first waits until its own
