@@ -228,12 +228,17 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
         for (int i = threadIdx.x; i < B; i += blockDim.x) la += (double)get_loss(i);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // lanes with the same r hold the same row: butterfly over the lane bits above the row index, then the four waves
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        double v = acc[c];
-#pragma unroll
-        for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane < 4) S[wave][4 * lane + c] = v;
+    // (the four columns in 5 shuffles instead of 16: a lane keeps half of its values at the first two levels and hands
+    //  the other half to its partner -- the pairings, hence the sums, are the plain butterfly's, bit for bit; column
+    //  c = 2 b32 + b16 of row r ends up in lane r + 16 b16 + 32 b32)
+    {
+        const bool b32 = lane & 32, b16 = lane & 16;
+        const double a0 = (b32 ? acc[2] : acc[0]) + __shfl_xor(b32 ? acc[0] : acc[2], 32, 64);
+        const double a1 = (b32 ? acc[3] : acc[1]) + __shfl_xor(b32 ? acc[1] : acc[3], 32, 64);
+        double v = (b16 ? a1 : a0) + __shfl_xor(b16 ? a0 : a1, 16, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 4, 64);
+        if ((lane & 12) == 0) S[wave][4 * (lane & 3) + 2 * (b32 ? 1 : 0) + (b16 ? 1 : 0)] = v;
     }
     {
         const double s = wave_sum_f64(la);
