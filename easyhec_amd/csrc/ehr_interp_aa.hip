@@ -1,11 +1,13 @@
 // ehr_interp_aa.hip -- drop-in dr.interpolate (nvdiffrast_renderer.py:42) and dr.antialias (:43), fwd + bwd,
 // plus the edge-topology build that replaces dr.antialias_construct_topology_hash.
 //
-// PROVENANCE: the discover -> analyse -> gradient split with an int4 work buffer mirrors the kernel trio of nvdiffrast's
-// antialias.cu (AntialiasFwdDiscontinuityKernel / AntialiasFwdAnalysisKernel / AntialiasGradKernel), and the per-pair
-// arithmetic is ehr_device.h's aa_analyze / aa_pos_grad (see the provenance note there: written from knowledge of that
-// code, which is under the NVIDIA Source Code License; not present in /root/reference).  The topology here is a sorted
-// edge table, not nvdiffrast's hash.
+// PROVENANCE: the per-pair arithmetic is ehr_device.h's aa_analyze / aa_pos_grad (see the provenance note there: written
+// from knowledge of nvdiffrast's antialias.cu, which is under the NVIDIA Source Code License; not present in
+// /root/reference), and the int4 work items handed from the forward to the backward pass follow that file's work buffer.
+// The kernel structure is this repo's own since round 4: nvdiffrast (and rounds 1-3 here) discover the pixel pairs, analyse
+// them and scatter the blends with float atomics in three launches; here ONE launch per 32 x 8 tile lists the pairs in LDS,
+// analyses them one per lane and lets every pixel gather its blends in a serial sweep's order (no atomics, bit-exact against
+// the oracle).  The topology is a sorted edge table, not nvdiffrast's hash.
 #include <algorithm>
 
 #include "ehr_device.h"
