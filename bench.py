@@ -191,6 +191,9 @@ def side_workload(name, dev, steps, warmup, min_ms=30.0):
 
     for _ in range(warmup):
         tr.step()
+    if tr.fast is not None and not np.isfinite(float(tr.last_loss)) and tr.fast.recover_from_overflow():
+        for _ in range(warmup):
+            tr.step()
     el, blocks = timed_blocks(tr.step, steps, barrier, min_ms)
     fused.check_status(p["glctx"])
     st = stage_times(p, steps)
@@ -305,6 +308,12 @@ def main():
     used_graph = tr.fast is not None and bool(tr.fast._graph)
     for _ in range(args.warmup):
         step()
+    # A step the launch chain REPORTS (NaN loss: its slot-limited plan overflowed, or the view needs the general-triangle
+    # pass the chain does not launch by default) leaves the optimiser untouched; recover once, before anything is timed,
+    # exactly as RBSolverTrainer.fit does (never needed on the BASELINE workloads; all ranks decide alike: same loss).
+    if tr.fast is not None and not np.isfinite(float(tr.last_loss)) and tr.fast.recover_from_overflow():
+        for _ in range(args.warmup):
+            step()
     # The timed block is exactly --steps steps between two barriers (driver contract).  One block of a 0.1 ms step is a
     # thin sample (20 steps = 2 ms), so blocks are repeated -- each bracketed the same way, the optimisation simply
     # continues -- until at least --min-ms of timed work has accumulated; the reported time per step is the mean over all
