@@ -94,6 +94,8 @@ __device__ __forceinline__ void finish_body(const BinGeom& g, int B, const long 
                 const int b = base + 8 * j + (tid >> 5);
                 s4[j] = (b < B) ? acc_load(&facc[(size_t)b * acc_stride + 12 * L + k * lstride]) : 0;
             }
+            // (Adam's bias corrections while the slots are on their way: they need the step count only)
+            if (TAIL && base == 0 && !tail.defer_adam) pose_adam_bias(st, tail.lr, tail.b1, tail.b2);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int b = base + 8 * j + (tid >> 5);
@@ -150,7 +152,7 @@ __device__ __forceinline__ void finish_body(const BinGeom& g, int B, const long 
                 for (int e = 0; e < 16; e++) grad_mvp[(size_t)i * 16 + e] = G[e];
         },
         [&](int) { return 0.f; }, tail.K, tail.link_poses, tail.tc_jac, B, L, g.H, g.W, tail.n, tail.f, tail.red, S, red_lds,
-        &la_mine);
+        &la_mine, nls == 32);
     __syncthreads();
     if (!tail.defer_adam)
         pose_adam_apply(st, tail.dof, tail.m, tail.v, tail.step, red_lds, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,

@@ -186,8 +186,10 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
                                                       const float* __restrict__ link_poses,
                                                       const float* __restrict__ tc_jac, int B, int L, int H, int W,
                                                       float n, float f, float* __restrict__ red, double (*S)[17],
-                                                      float* red_lds, const double* la_pre = nullptr) {
-    // (la_pre: this thread's share of sum_b loss_b, already known to the caller -- get_loss is not called then)
+                                                      float* red_lds, const double* la_pre = nullptr,
+                                                      bool la_lanes_0_32 = false) {
+    // (la_pre: this thread's share of sum_b loss_b, already known to the caller -- get_loss is not called then;
+    //  la_lanes_0_32: only lanes 0 and 32 of a wave hold a share, the wave's sum is one shuffle instead of six)
     // Jacobian rows are needed last but depend on nothing computed here: fetch them first (into LDS, not registers:
     // this body also runs inside the composite kernel, which is compiled for 80 registers)
     __shared__ float Js[6][16];
@@ -241,7 +243,7 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
         if ((lane & 12) == 0) S[wave][4 * (lane & 3) + 2 * (b32 ? 1 : 0) + (b16 ? 1 : 0)] = v;
     }
     {
-        const double s = wave_sum_f64(la);
+        const double s = la_lanes_0_32 ? la + __shfl_xor(la, 32, 64) : wave_sum_f64(la);
         if (lane == 0) S[wave][16] = s;
     }
     __syncthreads();
@@ -277,10 +279,23 @@ __device__ __forceinline__ void pose_backward_block(const float* __restrict__ gr
 struct AdamState {  // one thread's share of the optimiser state, fetched ahead of use
     float p, m, v;
     int t;
+    float step_size, rsq_bc2;  // lr / (1 - b1^t) and sqrt(1 - b2^t): pose_adam_bias, computable as soon as t is known
+    bool has_bias;
 };
+// The bias corrections depend on the step count alone: two powf and a square root that a caller waiting for memory
+// anyway (the fused step's finish stage) takes off the end of its chain.  Same expressions as in pose_adam_apply.
+__device__ __forceinline__ void pose_adam_bias(AdamState& st, float lr, float b1, float b2) {
+    const float bc1 = 1.f - powf(b1, (float)st.t);
+    const float bc2 = 1.f - powf(b2, (float)st.t);
+    st.step_size = lr / bc1;
+    st.rsq_bc2 = sqrtf(bc2);
+    st.has_bias = true;
+}
 __device__ __forceinline__ AdamState pose_adam_fetch(const float* dof, const float* m, const float* v, const int* step) {
     AdamState st;
     st.p = st.m = st.v = 0.f;
+    st.step_size = st.rsq_bc2 = 0.f;
+    st.has_bias = false;
     st.t = step[0] + 1;
     if (threadIdx.x < 6) {
         st.p = dof[threadIdx.x];
@@ -310,10 +325,17 @@ __device__ __forceinline__ void pose_adam_apply(const AdamState& st, float* __re
         float vi = b2 * st.v + (1.f - b2) * g * g;
         m[i] = mi;
         v[i] = vi;
-        float bc1 = 1.f - powf(b1, (float)t);
-        float bc2 = 1.f - powf(b2, (float)t);
-        float step_size = lr / bc1;
-        float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+        float step_size, rsq_bc2;
+        if (st.has_bias) {
+            step_size = st.step_size;
+            rsq_bc2 = st.rsq_bc2;
+        } else {
+            const float bc1 = 1.f - powf(b1, (float)t);
+            const float bc2 = 1.f - powf(b2, (float)t);
+            step_size = lr / bc1;
+            rsq_bc2 = sqrtf(bc2);
+        }
+        float denom = sqrtf(vi) / rsq_bc2 + eps;
         dof[i] = p - step_size * (mi / denom);
     }
     if (i < 6 && !ok && grad_out) grad_out[i] = __int_as_float(0x7fc00000);

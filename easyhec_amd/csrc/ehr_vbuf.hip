@@ -1973,6 +1973,12 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     const bool sparse = tsum != nullptr;
     for (int i = tid; i <= U; i += 256) s_jbase[i] = jbase[i];
     for (int i = tid; i < U; i += 256) s_utile[i] = jutile[i];
+    // The links' screen boxes start "empty" in the next step.  Nobody reads them after the job kernel's prologue, so the
+    // call's last composite launch re-arms them here, a store per thread of its first workgroups, instead of in the
+    // finish stage at its end (where it was 32 stores per thread on the step's critical path).
+    if (do_finish && lbox_all)
+        for (int i = (int)blockIdx.x * 256 + tid; i < 16 * B_all * g.L; i += (int)gridDim.x * 256)
+            lbox_all[i] = (i & 2) ? INT_MIN : INT_MAX;  // 16 ints (one line) per box: min x, min y, max x, max y, padding
     __syncthreads();
     // work items: every tile of every view, or (bound reference) the JOBS -- a job stands for its tile if no link before
     // its own has a job there, so that every tile with a job comes up exactly once and the others never
@@ -2178,7 +2184,7 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     __shared__ double S[4][17];
     __shared__ float red_lds[8];
 #ifndef VB_NO_FINISH
-    finish_body<TAIL>(g, B_all, facc_all, sparse ? vtot_all : nullptr, loss, grad_mvp, meta, tail, nls, lbox_all, VB_LOSS_STRIDE,
+    finish_body<TAIL>(g, B_all, facc_all, sparse ? vtot_all : nullptr, loss, grad_mvp, meta, tail, nls, nullptr, VB_LOSS_STRIDE,
                       gpix_all[0], S, red_lds);
 #endif
 }
