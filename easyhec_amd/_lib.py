@@ -26,6 +26,9 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "ehr_interpolate_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_void_p, c_void_p, c_void_p]),
+    "ehr_interpolate_da_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
+    "ehr_interpolate_da_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
+                                [c_void_p, c_void_p, c_void_p]),
     "ehr_topology_scratch_bytes": (c_size_t, [c_int]),
     "ehr_antialias_topology": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ehr_antialias_work_bytes": (c_size_t, [c_int, c_int, c_int]),

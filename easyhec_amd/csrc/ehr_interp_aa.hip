@@ -160,6 +160,90 @@ __global__ void topo_init_kernel(EdgeSlot* tab, unsigned n) {
     }
 }
 
+// ---- attribute pixel differentials (dr.interpolate(..., rast_db=, diff_attrs=); not on EasyHeC's path) -----------------
+// out_da [B,H,W,2D]: (d attr_j / dX, d attr_j / dY) for j = diff_idx[i] (NULL = all attributes) at channels 2i, 2i+1:
+// attr = u a0 + v a1 + (1-u-v) a2  =>  d attr / dX = du/dX (a0 - a2) + dv/dX (a1 - a2), with rast_db = (du/dX, du/dY,
+// dv/dX, dv/dY).  Same products and sums as the oracle's ehro_interpolate_da_fwd.
+__global__ void __launch_bounds__(256) interp_da_fwd_kernel(const float* __restrict__ attr, const float4* __restrict__ rast,
+                                                            const float4* __restrict__ rast_db,
+                                                            const int32_t* __restrict__ tri,
+                                                            const int32_t* __restrict__ diff_idx, int B, int Ba, int V, int T,
+                                                            int A, int D, size_t P, float* __restrict__ out_da) {
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P * B) return;
+    const int b = (int)(pix / P);
+    const int t = float_to_tri(rast[pix].w) - 1;
+    float* o = out_da + pix * 2 * D;
+    bool ok = t >= 0 && t < T;
+    int v0 = 0, v1 = 0, v2 = 0;
+    if (ok) {
+        v0 = tri[3 * t];
+        v1 = tri[3 * t + 1];
+        v2 = tri[3 * t + 2];
+        ok = (unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V;
+    }
+    const float4 db = ok ? rast_db[pix] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* ab = attr + (Ba == 1 ? 0 : (size_t)b * V * A);
+    for (int k = 0; k < D; k++) {
+        const int j = diff_idx ? diff_idx[k] : k;
+        float ox = 0.f, oy = 0.f;
+        if (ok && (unsigned)j < (unsigned)A) {
+            const float a2 = ab[(size_t)v2 * A + j];
+            const float d0 = ab[(size_t)v0 * A + j] - a2, d1 = ab[(size_t)v1 * A + j] - a2;
+            const float mx0 = db.x * d0, mx1 = db.z * d1, my0 = db.y * d0, my1 = db.w * d1;
+            ox = mx0 + mx1;
+            oy = my0 + my1;
+        }
+        o[2 * k] = ox;
+        o[2 * k + 1] = oy;
+    }
+}
+
+__global__ void __launch_bounds__(256) interp_da_grad_kernel(const float* __restrict__ attr, const float4* __restrict__ rast,
+                                                             const float4* __restrict__ rast_db,
+                                                             const int32_t* __restrict__ tri,
+                                                             const int32_t* __restrict__ diff_idx,
+                                                             const float* __restrict__ dy_da, int B, int Ba, int V, int T,
+                                                             int A, int D, size_t P, float* __restrict__ grad_attr,
+                                                             float4* __restrict__ grad_db) {
+    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= P * B) return;
+    const int b = (int)(pix / P);
+    const int t = float_to_tri(rast[pix].w) - 1;
+    bool ok = t >= 0 && t < T;
+    int v0 = 0, v1 = 0, v2 = 0;
+    if (ok) {
+        v0 = tri[3 * t];
+        v1 = tri[3 * t + 1];
+        v2 = tri[3 * t + 2];
+        ok = (unsigned)v0 < (unsigned)V && (unsigned)v1 < (unsigned)V && (unsigned)v2 < (unsigned)V;
+    }
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        const float4 db = rast_db[pix];
+        const size_t aoff = (Ba == 1 ? 0 : (size_t)b * V * A);
+        for (int k = 0; k < D; k++) {
+            const int j = diff_idx ? diff_idx[k] : k;
+            if ((unsigned)j >= (unsigned)A) continue;
+            const float gx = dy_da[pix * 2 * D + 2 * k], gy = dy_da[pix * 2 * D + 2 * k + 1];
+            if (gx == 0.f && gy == 0.f) continue;
+            const float a2 = attr[aoff + (size_t)v2 * A + j];
+            const float d0 = attr[aoff + (size_t)v0 * A + j] - a2, d1 = attr[aoff + (size_t)v1 * A + j] - a2;
+            g.x += gx * d0;
+            g.y += gy * d0;
+            g.z += gx * d1;
+            g.w += gy * d1;
+            if (grad_attr) {
+                const float c0 = gx * db.x + gy * db.y, c1 = gx * db.z + gy * db.w;
+                atomicAdd(&grad_attr[aoff + (size_t)v0 * A + j], c0);
+                atomicAdd(&grad_attr[aoff + (size_t)v1 * A + j], c1);
+                atomicAdd(&grad_attr[aoff + (size_t)v2 * A + j], -(c0 + c1));
+            }
+        }
+    }
+    if (grad_db) grad_db[pix] = g;
+}
+
 static unsigned topo_slots(int T) {
     unsigned need = (unsigned)std::max(3 * (size_t)std::max(T, 1) * 2, (size_t)64);
     unsigned n = 64;
@@ -411,6 +495,35 @@ int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tr
     if (n == 0) return EHR_OK;
     interp_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(
         attr, (const float4*)rast, tri, dy, B, Ba, V, T, A, P, grad_attr, (float4*)grad_rast);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+int ehr_interpolate_da_fwd(const float* attr, const float* rast, const float* rast_db, const int32_t* tri,
+                           const int32_t* diff_idx, int B, int Ba, int V, int T, int A, int D, int H, int W, float* out_da,
+                           void* stream_) {
+    if (!attr || !rast || !rast_db || !tri || !out_da) return fail(EHR_ERR_INVALID, "ehr_interpolate_da_fwd: NULL tensor");
+    if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_da_fwd: attr batch %d must be 1 or %d", Ba, B);
+    if (D < 0 || (!diff_idx && D != A)) return fail(EHR_ERR_INVALID, "ehr_interpolate_da_fwd: D must equal A when diff_idx is NULL");
+    size_t P = (size_t)H * W, n = P * B;
+    if (n == 0 || D == 0) return EHR_OK;
+    interp_da_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(
+        attr, (const float4*)rast, (const float4*)rast_db, tri, diff_idx, B, Ba, V, T, A, D, P, out_da);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+int ehr_interpolate_da_grad(const float* attr, const float* rast, const float* rast_db, const int32_t* tri,
+                            const int32_t* diff_idx, const float* dy_da, int B, int Ba, int V, int T, int A, int D, int H,
+                            int W, float* grad_attr, float* grad_rast_db, void* stream_) {
+    if (!attr || !rast || !rast_db || !tri || !dy_da) return fail(EHR_ERR_INVALID, "ehr_interpolate_da_grad: NULL tensor");
+    if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_da_grad: attr batch %d must be 1 or %d", Ba, B);
+    if (D < 0 || (!diff_idx && D != A)) return fail(EHR_ERR_INVALID, "ehr_interpolate_da_grad: D must equal A when diff_idx is NULL");
+    size_t P = (size_t)H * W, n = P * B;
+    if (n == 0 || (!grad_attr && !grad_rast_db)) return EHR_OK;
+    interp_da_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(
+        attr, (const float4*)rast, (const float4*)rast_db, tri, diff_idx, dy_da, B, Ba, V, T, A, D, P, grad_attr,
+        (float4*)grad_rast_db);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

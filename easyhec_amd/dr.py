@@ -172,24 +172,70 @@ class _InterpolateFunc(torch.autograd.Function):
         return g_attr, g_rast, None
 
 
+class _InterpolateDaFunc(torch.autograd.Function):
+    """Attribute pixel differentials: out_da = d attr / d(X, Y) from rast_db (interpolate's second output)."""
+
+    @staticmethod
+    def forward(ctx, attr, rast, rast_db, tri, idx):
+        B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+        Ba, V, A = attr.shape
+        D = A if idx is None else int(idx.shape[0])
+        out = torch.empty((B, H, W, 2 * D), dtype=torch.float32, device=rast.device)
+        with torch.cuda.device(rast.device):
+            _lib.check(_lib.lib().ehr_interpolate_da_fwd(_lib.ptr(attr), _lib.ptr(rast), _lib.ptr(rast_db), _lib.ptr(tri),
+                                                         _lib.ptr(idx), B, Ba, V, tri.shape[0], A, D, H, W, _lib.ptr(out),
+                                                         _stream()), "interpolate (differentials)")
+        ctx.save_for_backward(attr, rast, rast_db, tri, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        attr, rast, rast_db, tri, idx = ctx.saved_tensors
+        B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+        Ba, V, A = attr.shape
+        D = A if idx is None else int(idx.shape[0])
+        g_attr = torch.zeros_like(attr) if ctx.needs_input_grad[0] else None
+        g_db = torch.empty_like(rast_db) if ctx.needs_input_grad[2] else None
+        if g_attr is not None or g_db is not None:
+            dy = dy.contiguous()
+            with torch.cuda.device(rast.device):
+                _lib.check(_lib.lib().ehr_interpolate_da_grad(_lib.ptr(attr), _lib.ptr(rast), _lib.ptr(rast_db), _lib.ptr(tri),
+                                                              _lib.ptr(idx), _lib.ptr(dy), B, Ba, V, tri.shape[0], A, D, H,
+                                                              W, _lib.ptr(g_attr), _lib.ptr(g_db), _stream()),
+                           "interpolate (differentials) backward")
+        return g_attr, None, g_db, None, None  # (the differentials do not depend on (u, v): nothing for rast)
+
+
 def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
     """``dr.interpolate``: attr [B or 1, V, A] (or [V, A] in range mode), rast from :func:`rasterize`, tri [T,3].
-    Returns ``(out [B,H,W,A], out_da)``; ``out_da`` is an empty tensor (attribute pixel derivatives are not on
-    EasyHeC's path: nvdiffrast_renderer.py:42 passes neither ``rast_db`` nor ``diff_attrs``)."""
+    Returns ``(out [B,H,W,A], out_da)``.  ``out_da`` is empty unless ``diff_attrs`` ('all' or a list of attribute indices)
+    and ``rast_db`` (rasterize's second output) are given: then it holds the attributes' pixel differentials
+    [B,H,W,2*len(diff_attrs)] = (d/dX, d/dY) per listed attribute.  (EasyHeC passes neither: nvdiffrast_renderer.py:42.)"""
     _check_dev("attr", attr, torch.float32)
     _check_dev("rast", rast, torch.float32)
     _check_dev("tri", tri, torch.int32)
-    if diff_attrs is not None or rast_db is not None:
-        raise NotImplementedError("interpolate: attribute pixel differentials (rast_db / diff_attrs) are not "
-                                  "implemented; the EasyHeC path never requests them")
     _require(rast.dim() == 4 and rast.shape[3] == 4, "rast must have shape [>0, >0, >0, 4]")
     _require(tri.dim() == 2 and tri.shape[1] == 3, "tri must have shape [>0, 3]")
     if attr.dim() == 2:
         attr = attr[None]
     _require(attr.dim() == 3, "attr must have shape [>0, >0, >0] or [>0, >0]")
     _require(attr.shape[0] in (1, rast.shape[0]), "attr batch must be 1 or match rast")
-    out = _InterpolateFunc.apply(attr.contiguous(), rast.contiguous(), tri.contiguous())
-    out_da = torch.empty((out.shape[0], out.shape[1], out.shape[2], 0), dtype=torch.float32, device=out.device)
+    attr, rast, tri = attr.contiguous(), rast.contiguous(), tri.contiguous()
+    out = _InterpolateFunc.apply(attr, rast, tri)
+    if diff_attrs is None:
+        return out, torch.empty((out.shape[0], out.shape[1], out.shape[2], 0), dtype=torch.float32, device=out.device)
+    _require(rast_db is not None, "interpolate: diff_attrs needs rast_db (the second output of rasterize)")
+    _check_dev("rast_db", rast_db, torch.float32)
+    _require(rast_db.shape == rast.shape, "rast_db must have the shape of rast (rasterize with grad_db=True)")
+    A = attr.shape[2]
+    if isinstance(diff_attrs, str):
+        _require(diff_attrs == "all", "diff_attrs must be 'all' or a list of attribute indices")
+        idx = None
+    else:
+        lst = [int(i) for i in diff_attrs]
+        _require(len(lst) > 0 and all(0 <= i < A for i in lst), "diff_attrs: attribute indices out of range")
+        idx = None if lst == list(range(A)) else torch.tensor(lst, dtype=torch.int32).to(rast.device)
+    out_da = _InterpolateDaFunc.apply(attr, rast, rast_db.contiguous(), tri, idx)
     return out, out_da
 
 

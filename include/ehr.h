@@ -75,6 +75,19 @@ int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri
 int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba, int V,
                          int T, int A, int H, int W, float* grad_attr, float* grad_rast, void* stream);
 
+/* dr.interpolate's second output, the attribute pixel differentials (interpolate(attr, rast, tri, rast_db, diff_attrs);
+ * EasyHeC does not ask for them -- nvdiffrast_renderer.py:42 passes neither -- they complete the op's signature).
+ * rast_db [B,H,W,4] from ehr_rasterize_fwd; diff_idx [D] int32 DEVICE attribute indices, NULL = all (then D == A);
+ * out_da [B,H,W,2D] = (d attr_j / dX, d attr_j / dY) for j = diff_idx[i] at channels 2i, 2i+1; 0 where no triangle.
+ * grad: grad_attr [Ba,V,A] is ACCUMULATED into (may be NULL), grad_rast_db [B,H,W,4] overwritten (may be NULL); rast
+ * itself receives no gradient from the differentials. */
+int ehr_interpolate_da_fwd(const float* attr, const float* rast, const float* rast_db, const int32_t* tri,
+                           const int32_t* diff_idx, int B, int Ba, int V, int T, int A, int D, int H, int W, float* out_da,
+                           void* stream);
+int ehr_interpolate_da_grad(const float* attr, const float* rast, const float* rast_db, const int32_t* tri,
+                            const int32_t* diff_idx, const float* dy_da, int B, int Ba, int V, int T, int A, int D, int H,
+                            int W, float* grad_attr, float* grad_rast_db, void* stream);
+
 /* replaces dr.antialias_construct_topology_hash(tri).  Writes opp [T,3] int32: for triangle t and edge k
  * (k=0: v1-v2, k=1: v2-v0, k=2: v0-v1) the third vertex of the other triangle sharing that edge, or -1.
  * scratch: ehr_topology_scratch_bytes(T) bytes of device memory. */

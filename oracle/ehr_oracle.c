@@ -452,6 +452,88 @@ int ehro_interpolate_grad(const float* attr, const float* rast, const int32_t* t
     return 0;
 }
 
+/* dr.interpolate's attribute pixel differentials (nvdiffrast's interpolate(attr, rast, tri, rast_db, diff_attrs); not
+ * on EasyHeC's path -- nvdiffrast_renderer.py:42 passes neither -- but part of the op's signature).
+ * rast_db [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY) from the rasterizer; diff_idx [D] attribute indices (NULL = all A,
+ * then D == A); out_da [B,H,W,2D]: (d attr_j / dX, d attr_j / dY) for j = diff_idx[i] at channels 2i, 2i+1.
+ * attr = u a0 + v a1 + (1-u-v) a2  =>  d attr/dX = du/dX (a0 - a2) + dv/dX (a1 - a2).  0 where no triangle. */
+int ehro_interpolate_da_fwd(const float* attr, const float* rast, const float* rast_db, const int32_t* tri,
+                            const int32_t* diff_idx, int B, int Ba, int V, int T, int A, int D, int H, int W,
+                            float* out_da) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        size_t aoff = (Ba == 1 ? 0 : (size_t)b * V * A);
+        for (size_t i = 0; i < P; i++) {
+            size_t pix = (size_t)b * P + i;
+            float* o = out_da + pix * 2 * D;
+            for (int k = 0; k < 2 * D; k++) o[k] = 0.f;
+            int t = float_to_tri(rast[4 * pix + 3]) - 1;
+            if (t < 0 || t >= T) continue;
+            int v0 = tri[3 * t], v1 = tri[3 * t + 1], v2 = tri[3 * t + 2];
+            if (v0 < 0 || v0 >= V || v1 < 0 || v1 >= V || v2 < 0 || v2 >= V) continue;
+            const float* db = rast_db + 4 * pix;
+            for (int k = 0; k < D; k++) {
+                int j = diff_idx ? diff_idx[k] : k;
+                if (j < 0 || j >= A) continue;
+                float a0 = attr[aoff + (size_t)v0 * A + j], a1 = attr[aoff + (size_t)v1 * A + j],
+                      a2 = attr[aoff + (size_t)v2 * A + j];
+                float d0 = a0 - a2, d1 = a1 - a2;
+                float mx0 = db[0] * d0, mx1 = db[2] * d1, my0 = db[1] * d0, my1 = db[3] * d1;
+                o[2 * k] = mx0 + mx1;
+                o[2 * k + 1] = my0 + my1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* backward of the above: dy_da [B,H,W,2D] -> grad_attr [Ba,V,A] (ACCUMULATED, caller zeroes) and grad_rast_db [B,H,W,4]
+ * (overwritten; may be NULL).  The differentials do not depend on (u, v): rast itself receives nothing from them. */
+int ehro_interpolate_da_grad(const float* attr, const float* rast, const float* rast_db, const int32_t* tri,
+                             const int32_t* diff_idx, const float* dy_da, int B, int Ba, int V, int T, int A, int D,
+                             int H, int W, float* grad_attr, float* grad_rast_db) {
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        size_t aoff = (Ba == 1 ? 0 : (size_t)b * V * A);
+        for (size_t i = 0; i < P; i++) {
+            size_t pix = (size_t)b * P + i;
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            int t = float_to_tri(rast[4 * pix + 3]) - 1;
+            int ok = t >= 0 && t < T;
+            int v0 = 0, v1 = 0, v2 = 0;
+            if (ok) {
+                v0 = tri[3 * t]; v1 = tri[3 * t + 1]; v2 = tri[3 * t + 2];
+                ok = !(v0 < 0 || v0 >= V || v1 < 0 || v1 >= V || v2 < 0 || v2 >= V);
+            }
+            if (ok) {
+                const float* db = rast_db + 4 * pix;
+                for (int k = 0; k < D; k++) {
+                    int j = diff_idx ? diff_idx[k] : k;
+                    if (j < 0 || j >= A) continue;
+                    float gx = dy_da[pix * 2 * D + 2 * k], gy = dy_da[pix * 2 * D + 2 * k + 1];
+                    float a0 = attr[aoff + (size_t)v0 * A + j], a1 = attr[aoff + (size_t)v1 * A + j],
+                          a2 = attr[aoff + (size_t)v2 * A + j];
+                    float d0 = a0 - a2, d1 = a1 - a2;
+                    g[0] += gx * d0;
+                    g[1] += gy * d0;
+                    g[2] += gx * d1;
+                    g[3] += gy * d1;
+                    float c0 = gx * db[0] + gy * db[1];  /* d / d(a0 - a2) */
+                    float c1 = gx * db[2] + gy * db[3];  /* d / d(a1 - a2) */
+                    grad_attr[aoff + (size_t)v0 * A + j] += c0;
+                    grad_attr[aoff + (size_t)v1 * A + j] += c1;
+                    grad_attr[aoff + (size_t)v2 * A + j] -= c0 + c1;
+                }
+            }
+            if (grad_rast_db) {
+                float* o = grad_rast_db + 4 * pix;
+                o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3];
+            }
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* antialias                                                                                        */
 /* ------------------------------------------------------------------------------------------------ */

@@ -107,6 +107,34 @@ def interpolate_grad(attr, rast, tri, dy):
     return ga, gr
 
 
+def interpolate_da(attr, rast, rast_db, tri, diff_attrs="all"):
+    """dr.interpolate's second output: attribute pixel differentials [B,H,W,2D] for the attribute indices ``diff_attrs``
+    ('all' or a list); rast_db from :func:`rasterize`."""
+    attr, rast, rast_db, tri = _f32(attr), _f32(rast), _f32(rast_db), _i32(tri)
+    B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+    Ba, V, A = attr.shape
+    idx = None if isinstance(diff_attrs, str) else _i32(np.asarray(diff_attrs))
+    D = A if idx is None else idx.shape[0]
+    out = np.empty((B, H, W, 2 * D), np.float32)
+    _chk(lib().ehro_interpolate_da_fwd(_fp(attr), _fp(rast), _fp(rast_db), _ip(tri), None if idx is None else _ip(idx),
+                                       B, Ba, V, tri.shape[0], A, D, H, W, _fp(out)), "interpolate_da_fwd")
+    return out
+
+
+def interpolate_da_grad(attr, rast, rast_db, tri, dy_da, diff_attrs="all"):
+    attr, rast, rast_db, tri, dy_da = _f32(attr), _f32(rast), _f32(rast_db), _i32(tri), _f32(dy_da)
+    B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+    Ba, V, A = attr.shape
+    idx = None if isinstance(diff_attrs, str) else _i32(np.asarray(diff_attrs))
+    D = A if idx is None else idx.shape[0]
+    ga = np.zeros_like(attr)
+    gdb = np.empty_like(rast_db)
+    _chk(lib().ehro_interpolate_da_grad(_fp(attr), _fp(rast), _fp(rast_db), _ip(tri), None if idx is None else _ip(idx),
+                                        _fp(dy_da), B, Ba, V, tri.shape[0], A, D, H, W, _fp(ga), _fp(gdb)),
+         "interpolate_da_grad")
+    return ga, gdb
+
+
 def topology(tri):
     """Opposite vertex per (triangle, edge); -1 = boundary edge (nvdiffrast's topology hash, as a table)."""
     tri = _i32(tri)

@@ -192,6 +192,59 @@ def test_interpolate_matches_barycentric_sum_and_grad(oracle):
     assert np.abs(ga - e).max() < 1e-4
 
 
+def test_interpolate_pixel_differentials(oracle):
+    """interpolate's second output (diff_attrs): d attr / d(X, Y) per pixel.  Known answers: an attribute that equals the
+    vertex's own pixel coordinate interpolates, under perspective, to the pixel coordinate itself -- its differential is
+    (1, 0) for x and (0, 1) for y at every covered pixel; the neighbouring pixel's interpolated value differs by the
+    differential to first order; the backward pass is the transpose of a linear map."""
+    H, W = 40, 48
+    pos = np.array([[-0.8, -0.7, 0.1, 1.0], [0.9, -0.6, 0.4, 1.6], [0.1, 0.8, -0.3, 0.7], [0.7, 0.9, 0.2, 1.1]], np.float32)
+    tri = np.array([[0, 1, 2], [2, 1, 3]], np.int32)
+    rast, db = oracle.rasterize(pos[None], tri, [H, W])
+    cov = rast[0, :, :, 3] > 0
+    assert cov.sum() > 300
+    px = (pos[:, 0] / pos[:, 3] * 0.5 + 0.5) * W   # continuous pixel coordinates of the vertices (pixel i covers [i, i+1))
+    py = (pos[:, 1] / pos[:, 3] * 0.5 + 0.5) * H
+    rng = np.random.default_rng(3)
+    attr = np.stack([px, py, rng.normal(size=4), rng.normal(size=4)], axis=1)[None].astype(np.float32)
+    # NOTE: screen position is linear in (u, v) only for SCREEN-space barycentrics; nvdiffrast's (u, v) are perspective
+    # correct, under which  attr_j = x_j  does not interpolate to x.  Use clip-space w = 1 for the affine known answer.
+    pos1 = pos.copy()
+    pos1[:, :3] /= pos1[:, 3:4]
+    pos1[:, 3] = 1.0
+    rast1, db1 = oracle.rasterize(pos1[None], tri, [H, W])
+    cov1 = rast1[0, :, :, 3] > 0
+    da1 = oracle.interpolate_da(attr, rast1, db1, tri, "all")
+    assert da1.shape == (1, H, W, 8)
+    assert np.abs(da1[0][cov1][:, 0] - 1).max() < 2e-4 and np.abs(da1[0][cov1][:, 1]).max() < 2e-4   # d x / d(X, Y)
+    assert np.abs(da1[0][cov1][:, 2]).max() < 2e-4 and np.abs(da1[0][cov1][:, 3] - 1).max() < 2e-4   # d y / d(X, Y)
+    assert (da1[0][~cov1] == 0).all()
+    # perspective case: first-order agreement with the neighbouring pixel of the same triangle
+    out = oracle.interpolate(attr, rast, tri)
+    da = oracle.interpolate_da(attr, rast, db, tri, [2, 3])
+    ids = rast[0, :, :, 3]
+    n = 0
+    for y in range(H - 1):
+        for x in range(W - 1):
+            if ids[y, x] > 0 and ids[y, x] == ids[y, x + 1] == ids[y + 1, x]:
+                for i, j in enumerate((2, 3)):
+                    assert abs((out[0, y, x + 1, j] - out[0, y, x, j]) - da[0, y, x, 2 * i]) < 2e-2 * (1 + abs(da[0, y, x, 2 * i]))
+                    assert abs((out[0, y + 1, x, j] - out[0, y, x, j]) - da[0, y, x, 2 * i + 1]) < 2e-2 * (1 + abs(da[0, y, x, 2 * i + 1]))
+                n += 1
+    assert n > 200
+    # a list selects and orders channels of 'all'
+    full = oracle.interpolate_da(attr, rast, db, tri, "all")
+    assert (da == full[..., [4, 5, 6, 7]]).all()
+    assert (oracle.interpolate_da(attr, rast, db, tri, [3, 0]) == full[..., [6, 7, 0, 1]]).all()
+    # backward = transpose: <dy, J a> == <J^T dy, a> for the map attr -> out_da and rast_db -> out_da
+    dy = rng.normal(size=full.shape).astype(np.float32)
+    ga, gdb = oracle.interpolate_da_grad(attr, rast, db, tri, dy, "all")
+    lhs = float((dy.astype(np.float64) * full).sum())
+    assert abs(lhs - float((ga.astype(np.float64) * attr).sum())) < 1e-3 * (1 + abs(lhs))
+    assert abs(lhs - float((gdb.astype(np.float64) * db).sum())) < 1e-3 * (1 + abs(lhs))
+    assert (gdb[0][~cov] == 0).all()
+
+
 def test_rasterize_grad_matches_finite_differences(oracle):
     rng = np.random.default_rng(7)
     pos = np.array([[-0.7, -0.6, 0.1, 1.0], [0.8, -0.5, 0.2, 1.3], [0.0, 0.7, -0.1, 0.9]], np.float32)
