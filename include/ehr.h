@@ -37,7 +37,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 5 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color) */
+int ehr_version(void);                 /* ABI version, currently 5 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
