@@ -5,6 +5,7 @@
 
 #include "ehr_host.h"
 #include "ehr_raster_core.h"
+#include "ehr_pose_core.h"  // Dual<N>: forward-mode scalars (the rast_db backward below)
 
 namespace ehr {
 
@@ -387,6 +388,80 @@ __global__ void __launch_bounds__(256) raster_grad_kernel(const float4* __restri
     atomicAdd(&gp[4 * vi2 + 0], gp2x); atomicAdd(&gp[4 * vi2 + 1], gp2y); atomicAdd(&gp[4 * vi2 + 3], gp2w);
 }
 
+// d(rast_db)/d(pos) contracted with ddb: the shading's expressions for (du/dX, du/dY, dv/dX, dv/dY) (shade_pixel) are
+// re-evaluated in forward-mode arithmetic over the nine inputs (x, y, w of the triangle's vertices); like the (u, v) half
+// above, the barycentrics' clamp is not differentiated.  EasyHeC discards rast_db; this completes the op.
+__global__ void __launch_bounds__(256) raster_grad_db_kernel(const float4* __restrict__ pos, const int32_t* __restrict__ tri,
+                                                             const float4* __restrict__ rast,
+                                                             const float4* __restrict__ ddb, int range_mode, int B, int V,
+                                                             int T, int H, int W, float* __restrict__ grad_pos) {
+    typedef Dual<9> D9;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t P = (size_t)H * W;
+    if (idx >= P * B) return;
+    const int b = (int)(idx / P);
+    const int rem = (int)(idx - (size_t)b * P);
+    const int iy = rem / W, ix = rem - iy * W;
+    const int t = float_to_tri(rast[idx].w) - 1;
+    if (t < 0 || t >= T) return;
+    const float4 g4 = ddb[idx];
+    if (g4.x == 0.f && g4.y == 0.f && g4.z == 0.f && g4.w == 0.f) return;
+    const int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    if ((unsigned)vi[0] >= (unsigned)V || (unsigned)vi[1] >= (unsigned)V || (unsigned)vi[2] >= (unsigned)V) return;
+    const size_t voff = range_mode ? 0 : (size_t)b * V;
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    D9 X[3], Y[3], Wd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float4 q = pos[voff + vi[k]];
+        X[k] = dconst<9>(q.x);
+        X[k].d[3 * k] = 1.f;
+        Y[k] = dconst<9>(q.y);
+        Y[k].d[3 * k + 1] = 1.f;
+        Wd[k] = dconst<9>(q.w);
+        Wd[k].d[3 * k + 2] = 1.f;
+    }
+    const D9 fx = dconst<9>((float)ix * xs + xo), fy = dconst<9>((float)iy * ys + yo);
+    D9 px[3], py[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        px[k] = X[k] - fx * Wd[k];
+        py[k] = Y[k] - fy * Wd[k];
+    }
+    const D9 a0 = px[1] * py[2] - py[1] * px[2];
+    const D9 a1 = px[2] * py[0] - py[2] * px[0];
+    const D9 a2 = px[0] * py[1] - py[0] * px[1];
+    const D9 at = (a0 + a1) + a2;
+    const D9 iw = dconst<9>(1.f) / at;
+    const D9 b0 = a0 * iw, b1 = a1 * iw;
+    const D9 dfx = dconst<9>(xs) * iw, dfy = dconst<9>(ys) * iw;
+    const D9 da0x = Y[2] * Wd[1] - Y[1] * Wd[2], da0y = X[1] * Wd[2] - X[2] * Wd[1];
+    const D9 da1x = Y[0] * Wd[2] - Y[2] * Wd[0], da1y = X[2] * Wd[0] - X[0] * Wd[2];
+    const D9 da2x = Y[1] * Wd[0] - Y[0] * Wd[1], da2y = X[0] * Wd[1] - X[1] * Wd[0];
+    const D9 datx = (da0x + da1x) + da2x, daty = (da0y + da1y) + da2y;
+    D9 o[4];
+    o[0] = dfx * (b0 * datx - da0x);
+    o[1] = dfy * (b0 * daty - da0y);
+    o[2] = dfx * (b1 * datx - da1x);
+    o[3] = dfy * (b1 * daty - da1y);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    float* gp = grad_pos + 4 * voff;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float gx = 0.f, gy = 0.f, gw = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            gx += g[c] * o[c].d[3 * k];
+            gy += g[c] * o[c].d[3 * k + 1];
+            gw += g[c] * o[c].d[3 * k + 2];
+        }
+        atomicAdd(&gp[4 * vi[k] + 0], gx);
+        atomicAdd(&gp[4 * vi[k] + 1], gy);
+        atomicAdd(&gp[4 * vi[k] + 3], gw);
+    }
+}
+
 }  // namespace ehr
 
 using namespace ehr;
@@ -647,6 +722,19 @@ int ehr_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, 
     raster_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)pos, tri, (const float4*)rast,
                                                                         (const float4*)dy, range_mode, B, V, T, H, W,
                                                                         grad_pos);
+    EHR_LAUNCH_CHECK();
+    return EHR_OK;
+}
+
+int ehr_rasterize_grad_db(const float* pos, const int32_t* tri, const float* rast, const float* ddb, int range_mode, int B,
+                          int V, int T, int H, int W, float* grad_pos, void* stream_) {
+    if (!pos || !tri || !rast || !ddb || !grad_pos) return fail(EHR_ERR_INVALID, "ehr_rasterize_grad_db: NULL tensor");
+    hipStream_t stream = (hipStream_t)stream_;
+    size_t n = (size_t)B * H * W;
+    if (n == 0) return EHR_OK;
+    raster_grad_db_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)pos, tri, (const float4*)rast,
+                                                                           (const float4*)ddb, range_mode, B, V, T, H, W,
+                                                                           grad_pos);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

@@ -97,7 +97,8 @@ class _RasterizeFunc(torch.autograd.Function):
             db = torch.empty((B, H, W, 0), dtype=torch.float32, device=pos.device)
         ctx.save_for_backward(pos, tri, rast)
         ctx.range_mode = ranges is not None
-        ctx.mark_non_differentiable(db)
+        if not grad_db:
+            ctx.mark_non_differentiable(db)
         # no gradient reaches `rast` on EasyHeC's path (the colour is constant, antialias returns none for it): without this
         # autograd would materialise a zero image and run the backward kernel on it, per (view, link)
         ctx.set_materialize_grads(False)
@@ -105,17 +106,23 @@ class _RasterizeFunc(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, ddb):
-        if dy is None:
+        if dy is None and ddb is None:
             return None, None, None, None, None, None
         pos, tri, rast = ctx.saved_tensors
         B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
         V, T = pos.shape[-2], tri.shape[0]
         g = torch.zeros_like(pos)
-        dy = dy.contiguous()
         with torch.cuda.device(pos.device):
-            _lib.check(_lib.lib().ehr_rasterize_grad(_lib.ptr(pos), _lib.ptr(tri), _lib.ptr(rast), _lib.ptr(dy),
-                                                     int(ctx.range_mode), B, V, T, H, W, _lib.ptr(g), _stream()),
-                       "rasterize backward")
+            if dy is not None:   # through (u, v)
+                dy = dy.contiguous()
+                _lib.check(_lib.lib().ehr_rasterize_grad(_lib.ptr(pos), _lib.ptr(tri), _lib.ptr(rast), _lib.ptr(dy),
+                                                         int(ctx.range_mode), B, V, T, H, W, _lib.ptr(g), _stream()),
+                           "rasterize backward")
+            if ddb is not None:  # through the pixel differentials of (u, v) (nobody on EasyHeC's path asks for this)
+                ddb = ddb.contiguous()
+                _lib.check(_lib.lib().ehr_rasterize_grad_db(_lib.ptr(pos), _lib.ptr(tri), _lib.ptr(rast), _lib.ptr(ddb),
+                                                            int(ctx.range_mode), B, V, T, H, W, _lib.ptr(g), _stream()),
+                           "rasterize backward (rast_db)")
         return None, g, None, None, None, None
 
 
@@ -123,8 +130,8 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     """``dr.rasterize``: pos [B,V,4] (instance mode) or [V,4] with ``ranges`` [B,2] int32 CPU tensor (range mode);
     tri [T,3] int32; resolution (H, W).  Returns ``(rast [B,H,W,4] = (u, v, z/w, triangle_id + 1), rast_db)``.
 
-    ``rast_db`` holds the screen-space derivatives of (u, v) when ``grad_db`` is set (its backward is not
-    propagated: EasyHeC never consumes it, nvdiffrast_renderer.py:39 discards it)."""
+    ``rast_db`` holds the screen-space derivatives of (u, v) when ``grad_db`` is set; gradients flow back to ``pos``
+    through both outputs (EasyHeC never consumes rast_db: nvdiffrast_renderer.py:39 discards it)."""
     _require(isinstance(glctx, RasterizeCudaContext), "glctx must be a RasterizeCudaContext")
     _check_dev("pos", pos, torch.float32)
     _check_dev("tri", tri, torch.int32)

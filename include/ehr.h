@@ -37,7 +37,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 5 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*) */
+int ehr_version(void);                 /* ABI version, currently 5 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*, ehr_rasterize_grad_db) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
@@ -66,6 +66,10 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
  * grad_pos (pos's shape) is ACCUMULATED into: the caller zero-fills it. */
 int ehr_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, const float* dy, int range_mode, int B,
                        int V, int T, int H, int W, float* grad_pos, void* stream);
+/* ... and w.r.t. pos through rast_db: ddb = grad of rast_db [B,H,W,4]; grad_pos is ACCUMULATED into.  (EasyHeC discards
+ * rast_db, nvdiffrast_renderer.py:39; this completes the op.) */
+int ehr_rasterize_grad_db(const float* pos, const int32_t* tri, const float* rast, const float* ddb, int range_mode, int B,
+                          int V, int T, int H, int W, float* grad_pos, void* stream);
 
 /* replaces dr.interpolate -- nvdiffrast_renderer.py:42.  attr [Ba,V,A] with Ba == B or 1; out [B,H,W,A]. */
 int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int B, int Ba, int V, int T, int A,

@@ -382,6 +382,86 @@ int ehro_rasterize_grad(const float* pos, const int32_t* tri, const float* rast,
     return 0;
 }
 
+/* dr.rasterize backward, second half: d(rast_db)/d(pos).  ddb = gradient w.r.t. rast_db [B,H,W,4] = (du/dX, du/dY,
+ * dv/dX, dv/dY); grad_pos is ACCUMULATED into.  (EasyHeC discards rast_db -- nvdiffrast_renderer.py:39 -- this completes
+ * the op.)  The forward expressions of ehro_rasterize_fwd's shading are re-evaluated in forward-mode arithmetic over the
+ * nine inputs (x, y, w of the three vertices); like the (u, v) half, the barycentrics' clamp to [0, 1] is not
+ * differentiated. */
+typedef struct {
+    float v, d[9];
+} dual9;
+static dual9 d9c(float c) { dual9 r; r.v = c; for (int i = 0; i < 9; i++) r.d[i] = 0.f; return r; }
+static dual9 d9var(float c, int k) { dual9 r = d9c(c); r.d[k] = 1.f; return r; }
+static dual9 d9add(dual9 a, dual9 b) { dual9 r; r.v = a.v + b.v; for (int i = 0; i < 9; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+static dual9 d9sub(dual9 a, dual9 b) { dual9 r; r.v = a.v - b.v; for (int i = 0; i < 9; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+static dual9 d9mul(dual9 a, dual9 b) { dual9 r; r.v = a.v * b.v; for (int i = 0; i < 9; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+static dual9 d9div(dual9 a, dual9 b) {
+    dual9 r; float inv = 1.f / b.v; r.v = a.v * inv;
+    for (int i = 0; i < 9; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+    return r;
+}
+int ehro_rasterize_grad_db(const float* pos, const int32_t* tri, const float* rast, const float* ddb, int range_mode,
+                           int B, int V, int T, int H, int W, float* grad_pos) {
+    const float xs = 2.f / (float)W, xo = 1.f / (float)W - 1.f;
+    const float ys = 2.f / (float)H, yo = 1.f / (float)H - 1.f;
+    size_t P = (size_t)H * W;
+    for (int b = 0; b < B; b++) {
+        const float* pb = range_mode ? pos : pos + (size_t)b * V * 4;
+        float* gb = range_mode ? grad_pos : grad_pos + (size_t)b * V * 4;
+        for (int iy = 0; iy < H; iy++)
+            for (int ix = 0; ix < W; ix++) {
+                size_t pix = (size_t)b * P + (size_t)iy * W + ix;
+                int t = float_to_tri(rast[4 * pix + 3]) - 1;
+                if (t < 0 || t >= T) continue;
+                const float* g = ddb + 4 * pix;
+                if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f && g[3] == 0.f) continue;
+                int vi[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+                if (vi[0] < 0 || vi[0] >= V || vi[1] < 0 || vi[1] >= V || vi[2] < 0 || vi[2] >= V) continue;
+                dual9 X[3], Y[3], Wd[3];
+                for (int k = 0; k < 3; k++) {
+                    const float* q = pb + 4 * (size_t)vi[k];
+                    X[k] = d9var(q[0], 3 * k);
+                    Y[k] = d9var(q[1], 3 * k + 1);
+                    Wd[k] = d9var(q[3], 3 * k + 2);
+                }
+                dual9 fx = d9c((float)ix * xs + xo), fy = d9c((float)iy * ys + yo);
+                dual9 px[3], py[3];
+                for (int k = 0; k < 3; k++) {
+                    px[k] = d9sub(X[k], d9mul(fx, Wd[k]));
+                    py[k] = d9sub(Y[k], d9mul(fy, Wd[k]));
+                }
+                dual9 a0 = d9sub(d9mul(px[1], py[2]), d9mul(py[1], px[2]));
+                dual9 a1 = d9sub(d9mul(px[2], py[0]), d9mul(py[2], px[0]));
+                dual9 a2 = d9sub(d9mul(px[0], py[1]), d9mul(py[0], px[1]));
+                dual9 at = d9add(d9add(a0, a1), a2);
+                dual9 iw = d9div(d9c(1.f), at);
+                dual9 b0 = d9mul(a0, iw), b1 = d9mul(a1, iw);
+                dual9 dfx = d9mul(d9c(xs), iw), dfy = d9mul(d9c(ys), iw);
+                dual9 da0x = d9sub(d9mul(Y[2], Wd[1]), d9mul(Y[1], Wd[2])), da0y = d9sub(d9mul(X[1], Wd[2]), d9mul(X[2], Wd[1]));
+                dual9 da1x = d9sub(d9mul(Y[0], Wd[2]), d9mul(Y[2], Wd[0])), da1y = d9sub(d9mul(X[2], Wd[0]), d9mul(X[0], Wd[2]));
+                dual9 da2x = d9sub(d9mul(Y[1], Wd[0]), d9mul(Y[0], Wd[1])), da2y = d9sub(d9mul(X[0], Wd[1]), d9mul(X[1], Wd[0]));
+                dual9 datx = d9add(d9add(da0x, da1x), da2x), daty = d9add(d9add(da0y, da1y), da2y);
+                dual9 o[4];
+                o[0] = d9mul(dfx, d9sub(d9mul(b0, datx), da0x));
+                o[1] = d9mul(dfy, d9sub(d9mul(b0, daty), da0y));
+                o[2] = d9mul(dfx, d9sub(d9mul(b1, datx), da1x));
+                o[3] = d9mul(dfy, d9sub(d9mul(b1, daty), da1y));
+                for (int k = 0; k < 3; k++) {
+                    float gx = 0.f, gy = 0.f, gw = 0.f;
+                    for (int c = 0; c < 4; c++) {
+                        gx += g[c] * o[c].d[3 * k];
+                        gy += g[c] * o[c].d[3 * k + 1];
+                        gw += g[c] * o[c].d[3 * k + 2];
+                    }
+                    gb[4 * vi[k] + 0] += gx;
+                    gb[4 * vi[k] + 1] += gy;
+                    gb[4 * vi[k] + 3] += gw;
+                }
+            }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* interpolate                                                                                      */
 /* ------------------------------------------------------------------------------------------------ */

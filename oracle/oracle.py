@@ -85,6 +85,17 @@ def rasterize_grad(pos, tri, rast, dy, range_mode=False):
     return g
 
 
+def rasterize_grad_db(pos, tri, rast, ddb, range_mode=False):
+    """d(rast_db)/d(pos) contracted with ddb (the gradient w.r.t. rasterize's second output)."""
+    pos, tri, rast, ddb = _f32(pos), _i32(tri), _f32(rast), _f32(ddb)
+    B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+    V = pos.shape[-2]
+    g = np.zeros_like(pos)
+    _chk(lib().ehro_rasterize_grad_db(_fp(pos), _ip(tri), _fp(rast), _fp(ddb), int(range_mode), B, V, tri.shape[0], H, W,
+                                      _fp(g)), "rasterize_grad_db")
+    return g
+
+
 def interpolate(attr, rast, tri):
     """dr.interpolate (nvdiffrast_renderer.py:42).  attr [1 or B,V,A]."""
     attr, rast, tri = _f32(attr), _f32(rast), _i32(tri)

@@ -81,7 +81,7 @@ def main():
             for form in ("1000000000", "0"):
                 os.environ["EHR_RASTER_DIRECT_MAX"] = form
                 r, db = dr.rasterize(ctx, tp, tf, [H, W])
-                assert (r.cpu().numpy() == r_ref).all() and (db.cpu().numpy() == db_ref).all(), tag + f": dr.rasterize form {form} link {l}"
+                assert (r.cpu().numpy() == r_ref).all() and (db.detach().cpu().numpy() == db_ref).all(), tag + f": dr.rasterize form {form} link {l}"
             if old is None:
                 os.environ.pop("EHR_RASTER_DIRECT_MAX", None)
             else:

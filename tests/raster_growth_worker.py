@@ -31,7 +31,7 @@ def main():
         r_ref, db_ref = oracle.rasterize(p[None], tri, [H, W])
         r, db = dr.rasterize(ctx, torch.tensor(p[None], device=dev), tt, [H, W])
         torch.cuda.synchronize()
-        rn, dbn = r.cpu().numpy(), db.cpu().numpy()
+        rn, dbn = r.cpu().numpy(), db.detach().cpu().numpy()
         res.append({"scale": scale, "rast_equal": bool((rn == r_ref).all()), "db_equal": bool((dbn == db_ref).all()),
                     "nan": bool(np.isnan(rn).any()), "covered": int((rn[..., 3] > 0).sum())})
     print("RESULT " + json.dumps(res))

@@ -52,7 +52,7 @@ def test_rasterize_interpolate_antialias_parity(env, oracle, raster_path, H, W, 
     tp, tt = t(pos[None], dev, True), t(tri, dev)
     r, db = dr.rasterize(ctx, tp, tt, [H, W])
     assert (r.detach().cpu().numpy() == r_ref).all()       # ids, barycentrics, depth: bit-exact
-    assert (db.cpu().numpy() == db_ref).all()
+    assert (db.detach().cpu().numpy() == db_ref).all()
     attr = rng.uniform(0, 1, size=(1, pos.shape[0], 3)).astype(np.float32)
     ta = t(attr, dev, True)
     c, da = dr.interpolate(ta, r, tt)
@@ -80,7 +80,7 @@ def test_ops_golden_fixture(env):
     H, W = g["rast"].shape[1:3]
     tp, tt, ta = t(g["pos"][None], dev, True), t(g["tri"], dev), t(g["attr"], dev, True)
     r, db = dr.rasterize(ctx, tp, tt, [H, W])
-    assert (r.detach().cpu().numpy() == g["rast"]).all() and (db.cpu().numpy() == g["db"]).all()
+    assert (r.detach().cpu().numpy() == g["rast"]).all() and (db.detach().cpu().numpy() == g["db"]).all()
     c, _ = dr.interpolate(ta, r, tt)
     assert (c.detach().cpu().numpy() == g["col"]).all()
     aa = dr.antialias(c, r, tp, tt)
@@ -123,7 +123,7 @@ def test_range_mode_and_batches(env, oracle, raster_path):
     posb = np.stack([pos, pos * np.array([1, -1, 1, 1], np.float32), pos[::-1].copy()])
     refb, dbb = oracle.rasterize(posb, tri, [H, W])
     rb, db = dr.rasterize(ctx, t(posb, dev), t(tri, dev), [H, W])
-    assert (rb.cpu().numpy() == refb).all() and (db.cpu().numpy() == dbb).all()
+    assert (rb.cpu().numpy() == refb).all() and (db.detach().cpu().numpy() == dbb).all()
     attr = rng.uniform(size=(3, pos.shape[0], 2)).astype(np.float32)
     c, _ = dr.interpolate(t(attr, dev), rb, t(tri, dev))
     assert (c.cpu().numpy() == oracle.interpolate(attr, refb, tri)).all()
@@ -197,7 +197,7 @@ def test_rasterizer_forms_on_slivers_big_and_clipped_triangles(env, oracle, H, W
         for form in ("1000000000", "0"):
             os.environ["EHR_RASTER_DIRECT_MAX"] = form
             r, db = dr.rasterize(ctx, t(posb, dev), t(tri, dev), [H, W])
-            assert (r.cpu().numpy() == ref).all() and (db.cpu().numpy() == dbr).all(), (form, H, W)
+            assert (r.cpu().numpy() == ref).all() and (db.detach().cpu().numpy() == dbr).all(), (form, H, W)
     finally:
         if old is None:
             os.environ.pop("EHR_RASTER_DIRECT_MAX", None)
@@ -239,6 +239,34 @@ def test_interpolate_pixel_differentials_match_the_oracle(env, oracle):
     assert empty.shape[-1] == 0
 
 
+def test_rasterize_backward_through_rast_db(env, oracle, raster_path):
+    """dr.rasterize's second output is differentiable too: d(rast_db)/d(pos) against the oracle's forward-mode
+    restatement (itself pinned by finite differences, tests/test_oracle_raster.py), alone and together with the (u, v) half."""
+    dr, ctx, dev = env
+    rng = np.random.default_rng(23)
+    pos, tri = helpers.random_mesh(rng, 200)
+    H, W = 56, 88
+    r_ref, db_ref = oracle.rasterize(pos[None], tri, [H, W])
+    gy = np.zeros_like(r_ref)
+    gy[..., :2] = rng.normal(size=r_ref.shape[:3] + (2,))
+    gdb = rng.normal(size=db_ref.shape).astype(np.float32)
+    g_uv = oracle.rasterize_grad(pos[None], tri, r_ref, gy)
+    g_db = oracle.rasterize_grad_db(pos[None], tri, r_ref, gdb)
+    tp = t(pos[None], dev, True)
+    r, db = dr.rasterize(ctx, tp, t(tri, dev), [H, W])
+    assert db.requires_grad
+    (db * t(gdb, dev)).sum().backward(retain_graph=True)
+    got = tp.grad.cpu().numpy().copy()
+    assert np.abs(got - g_db).max() <= 1e-4 * max(1.0, np.abs(g_db).max())
+    assert (got[..., 2] == 0).all()
+    tp.grad = None
+    ((r * t(gy, dev)).sum() + (db * t(gdb, dev)).sum()).backward()
+    both = tp.grad.cpu().numpy()
+    assert np.abs(both - (g_uv + g_db)).max() <= 1e-4 * max(1.0, np.abs(g_uv + g_db).max())
+    _, db0 = dr.rasterize(ctx, t(pos[None], dev, True), t(tri, dev), [H, W], grad_db=False)
+    assert db0.shape[-1] == 0 and not db0.requires_grad
+
+
 def test_rasterizer_forms_alternate_on_one_context(env, oracle):
     """The two forms keep separate state on a context (queue counters all zero / key image all ones between calls);
     alternating them call by call must not disturb either."""
@@ -252,7 +280,7 @@ def test_rasterizer_forms_alternate_on_one_context(env, oracle):
             os.environ["EHR_RASTER_DIRECT_MAX"] = "0" if i % 2 else "1000000000"
             ref, dbr = oracle.rasterize(pos[None], tri, [H, W])
             r, db = dr.rasterize(ctx, t(pos[None], dev), t(tri, dev), [H, W])
-            assert (r.cpu().numpy() == ref).all() and (db.cpu().numpy() == dbr).all(), (i, H, W)
+            assert (r.cpu().numpy() == ref).all() and (db.detach().cpu().numpy() == dbr).all(), (i, H, W)
     finally:
         if old is None:
             os.environ.pop("EHR_RASTER_DIRECT_MAX", None)
@@ -271,7 +299,7 @@ def test_edge_cases(env, oracle, raster_path):
     tri = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8], [0, 1, 9], [10, 11, 12], [0, 1, 99], [0, 0, 1]], np.int32)
     ref, dbr = oracle.rasterize(pos[None], tri, [H, W])
     r, db = dr.rasterize(ctx, t(pos[None], dev), t(tri, dev), [H, W])
-    assert (r.cpu().numpy() == ref).all() and (db.cpu().numpy() == dbr).all()
+    assert (r.cpu().numpy() == ref).all() and (db.detach().cpu().numpy() == dbr).all()
     assert (ref[..., 3] > 0).mean() > 0.9
     col = (ref[..., 3:4] > 0).astype(np.float32)
     aa = dr.antialias(t(col, dev), r, t(pos[None], dev), t(tri, dev))

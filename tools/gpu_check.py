@@ -40,7 +40,7 @@ for (H, W, nt) in [(64, 64, 50), (120, 200, 400), (256, 256, 3000)]:
     torch.cuda.synchronize()
     cmp("tri id", r[..., 3].detach().cpu().numpy(), r_ref[..., 3])
     cmp("uvz", r[..., :3].detach().cpu().numpy(), r_ref[..., :3], 1e-6)
-    cmp("db", db.cpu().numpy(), db_ref, 1e-3)
+    cmp("db", db.detach().cpu().numpy(), db_ref, 1e-3)
     attr = rng.uniform(0, 1, size=(1, pos.shape[1], 3)).astype(np.float32)
     ta = torch.tensor(attr, device=dev, requires_grad=True)
     c, _ = dr.interpolate(ta, r, tt)
