@@ -20,6 +20,15 @@ def _f(x):
     return ctypes.c_float(float(x))
 
 
+def ranks_agree(ok, pg, dev):
+    """True iff EVERY rank of the process group passes ``ok`` = True (one all-reduce(min) of a flag; collective: every
+    rank must call it)."""
+    on_dev = dist.get_backend(pg) == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+    return bool(int(flag.item()) == 1)
+
+
 class FusedPoseStep:
     def __init__(self, model, batch, lr=0.003, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0005, near=0.001, far=10.0,
                  process_group=None, rccl=None, slack=None):
@@ -47,13 +56,25 @@ class FusedPoseStep:
         # process group makes a single-rank communicator (the same launch sequence on one GPU).
         self.rccl = bool(rccl) if rccl is not None else (self.distributed and dist.get_backend(self.pg) == "nccl")
         if self.rccl:
+            ok, why = True, ""
             try:
                 self._init_comm()
             except RuntimeError as e:
                 if rccl:  # asked for explicitly: fail loudly
                     raise
+                ok, why = False, str(e)
+            if self.distributed and rccl is None:
+                # the ranks must agree on the exchange they use: one rank on torch.distributed and the others on the
+                # library's communicator would wait for each other for ever
+                if ok and not ranks_agree(ok, self.pg, self.dev):
+                    ok, why = False, "another rank could not set it up"
+                    with torch.cuda.device(self.dev):
+                        _lib.lib().ehr_comm_destroy(self.glctx.handle)
+                elif not ok:
+                    ranks_agree(False, self.pg, self.dev)
+            if not ok:
                 import sys
-                print(f"[easyhec_amd] library-owned RCCL exchange unavailable ({e}); using torch.distributed.all_reduce",
+                print(f"[easyhec_amd] library-owned RCCL exchange unavailable ({why}); using torch.distributed.all_reduce",
                       file=sys.stderr)
                 self.rccl = False
         # optimiser state (torch.optim.Adam names): a fresh Adam (step 0, zero moments) unless load_state_dict restores

@@ -29,6 +29,12 @@ def _worker(rank, world, port, n_views, steps, out):
     model = make()
     tr = RBSolverTrainer(cfg, model, local, fast=True)
     assert tr.fast.distributed
+    # the agreement the ranks reach before they pick their exchange (fast.ranks_agree: all-reduce(min) of a flag)
+    from easyhec_amd.fast import ranks_agree
+    dev = torch.device("cuda", 0)
+    assert ranks_agree(True, None, dev) is True
+    assert ranks_agree(rank != 1, None, dev) is False      # one rank failed: every rank hears about it
+    assert ranks_agree(False, None, dev) is False
     losses = []
     try:
         for _ in range(steps):

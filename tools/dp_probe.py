@@ -40,6 +40,8 @@ def main():
     if world == 1:  # the trainer only takes the data-parallel form for world > 1: build it explicitly on the same problem
         fast = FusedPoseStep(p["model"], tr.batch, lr=tr.cfg.solver.max_lr, weight_decay=tr.cfg.solver.weight_decay, rccl=True)
     assert fast.rccl, "the library-owned RCCL exchange was not selected"
+    from easyhec_amd.fast import ranks_agree
+    assert ranks_agree(True, None, dev) and not ranks_agree(False, None, dev)   # (on the nccl backend: a device flag)
     fast.capture()
 
     def run(step, n):
