@@ -119,13 +119,19 @@ class FusedPoseStep:
         world = dist.get_world_size(self.pg) if self.distributed else 1
         rank = dist.get_rank(self.pg) if self.distributed else 0
         idbuf = (ctypes.c_ubyte * 128)()
+        err = None
         if rank == 0:
-            _lib.check(lib.ehr_comm_unique_id(idbuf), "ehr_comm_unique_id")
+            try:
+                _lib.check(lib.ehr_comm_unique_id(idbuf), "ehr_comm_unique_id")
+            except RuntimeError as e:   # the other ranks are waiting in the broadcast below: they get an all-zero id
+                err, idbuf = e, (ctypes.c_ubyte * 128)()
         if world > 1:
             on_dev = dist.get_backend(self.pg) == "nccl"
             t = torch.tensor(list(idbuf), dtype=torch.uint8, device=self.dev if on_dev else "cpu")
             dist.broadcast(t, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
             idbuf = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+        if err is not None or not any(idbuf):
+            raise RuntimeError(f"no ncclUniqueId from rank 0 ({err})")
         with torch.cuda.device(self.dev):
             _lib.check(lib.ehr_comm_init(self.glctx.handle, idbuf, world, rank), "ehr_comm_init")
             # self-check before the solve depends on it: one all-reduce of a known vector on the new communicator must
