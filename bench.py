@@ -311,9 +311,13 @@ def main():
     # A step the launch chain REPORTS (NaN loss: its slot-limited plan overflowed, or the view needs the general-triangle
     # pass the chain does not launch by default) leaves the optimiser untouched; recover once, before anything is timed,
     # exactly as RBSolverTrainer.fit does (never needed on the BASELINE workloads; all ranks decide alike: same loss).
-    if tr.fast is not None and not np.isfinite(float(tr.last_loss)) and tr.fast.recover_from_overflow():
-        for _ in range(args.warmup):
-            step()
+    if tr.fast is not None and not np.isfinite(float(tr.last_loss)):
+        recovered = torch.tensor([1 if tr.fast.recover_from_overflow() else 0], dtype=torch.int32, device=dev)
+        if world > 1:  # (the cause is local to a rank's views, the extra steps below hold a collective each: decide together)
+            dist.all_reduce(recovered, op=dist.ReduceOp.MAX)
+        if int(recovered.item()):
+            for _ in range(args.warmup):
+                step()
     # The timed block is exactly --steps steps between two barriers (driver contract).  One block of a 0.1 ms step is a
     # thin sample (20 steps = 2 ms), so blocks are repeated -- each bracketed the same way, the optimisation simply
     # continues -- until at least --min-ms of timed work has accumulated; the reported time per step is the mean over all
