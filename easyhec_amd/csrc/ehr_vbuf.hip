@@ -237,8 +237,11 @@ __device__ __forceinline__ bool vb_depth_safe(const float4& p0, const float4& p1
            (zmin - delta >= (pos ? 1e-5f : -1.f + 1e-5f));
 }
 
+#ifndef VB_VERTEX_WAVES
+#define VB_VERTEX_WAVES 5  // (five workgroups per CU stay resident: the launch deals the work accordingly)
+#endif
 template <bool HEAD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, VB_VERTEX_WAVES)
 vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ vert_link,
                  const int32_t* __restrict__ tris, VbClusters cl, StepHead head, float* __restrict__ mvp, int V, int nvb,
                  BinGeom g, float4* __restrict__ posc, VbRecs rc, int* __restrict__ lbox, int* __restrict__ zacc,
@@ -306,9 +309,30 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     if (item < nitems) load_geometry(item);
     __shared__ int lacc[32][4];  // pixel box of every link as far as this workgroup's clusters go
     if (tid < 128) lacc[tid >> 2][tid & 3] = (tid & 2) ? -1 : INT_MAX;
+    // HEAD: the view's link poses and the intrinsics are requested NOW, together with dof, and parked in LDS: behind the
+    // barrier below they were a second cold round trip on every workgroup's chain (dof -> exponential -> barrier -> link
+    // poses -> matrices)
+    __shared__ float LP[32][16];
+    __shared__ float Kc[9];
+    float dofv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (HEAD) {
+        // (uniform: scalar loads into scalar registers, requested first; the exponential below waits for these alone)
+#pragma unroll
+        for (int k = 0; k < 6; k++) dofv[k] = head.dof[k];
+        float lpv[2] = {0.f, 0.f};
+        float kv = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (tid + 256 * j < L * 16) lpv[j] = head.link_poses[(size_t)b * L * 16 + tid + 256 * j];
+        if (tid >= 64 && tid < 73) kv = head.K[tid - 64];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            if (tid + 256 * j < L * 16) LP[(tid + 256 * j) >> 4][(tid + 256 * j) & 15] = lpv[j];
+        if (tid >= 64 && tid < 73) Kc[tid - 64] = kv;
+    }
     if (HEAD && tid < 6) {
         Dual<1> T6[16];
-        se3_exp_dual<1>(head.dof, 1e-4f, T6, tid);
+        se3_exp_dual<1>(dofv, 1e-4f, T6, tid);
         if (tid == 0)
             for (int i = 0; i < 16; i++) Tc[i] = T6[i].v;
         if (first) {
@@ -319,7 +343,7 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             if (tid == 0 && head.history && head.hist_row) {  // rb_solver.py:50-51: the pose goes to the next free row
                 const int row = head.hist_row[0];
                 if (row >= 0 && row < head.history_rows) {
-                    for (int k = 0; k < 6; k++) head.history[6 * row + k] = head.dof[k];
+                    for (int k = 0; k < 6; k++) head.history[6 * row + k] = dofv[k];
                     head.hist_row[0] = row + 1;
                 }
             }
@@ -357,8 +381,8 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     if (HEAD) {
         if (tid < L) {
             float P[16], C[16];
-            projection(head.K, H, W, head.n, head.f, P);
-            mvp_from_pose(Tc, P, head.link_poses + ((size_t)b * L + tid) * 16, C);
+            projection(Kc, H, W, head.n, head.f, P);
+            mvp_from_pose(Tc, P, LP[tid], C);
             for (int k = 0; k < 16; k++) M[tid][k] = C[k];
             if (bx == 0)
                 for (int k = 0; k < 16; k++) mvp[((size_t)b * L + tid) * 16 + k] = C[k];
@@ -1261,38 +1285,339 @@ __device__ __forceinline__ void vb_put_aside(int4* __restrict__ slow_list, int* 
     }
 }
 
+// Kernel-wide arguments of the resolve stage (what vb_resolve_job needs besides the job itself).
+struct VbResolveArgs {
+    const float4* posc;   // [B][V] clip-space vertices
+    const int4* tri4;     // [T] padded index table
+    const int4* opp4;     // [T] opposite vertices (edge topology)
+    int* jn;              // job slots: number of blended pairs (-1: the link contributes nothing to the tile)
+    float* jval;          //            the link's 256 antialiased values
+    VbItem* jitems;       //            blended pairs for the backward pass
+    int* jspill;
+    VbItem* spill;
+    int* meta;
+    int V, T, W, H, spill_cap, want_grad, dbg;
+};
+
+// The resolve stage of ONE drawn job, by one wave, from LDS: `ids` = triangle id of every region pixel (all-ones =
+// uncovered, VB_ID_COVERED = covered but never depth tested: no uncovered neighbour), C = the region's coverage bitmap
+// (bit i = region pixel i; wave-uniform).  Covered/uncovered pixel pairs by wave-uniform bit arithmetic, silhouette
+// analysis of the compacted hits (restates nvdiffrast's antialias mesh kernel), gather of the link's antialiased value per
+// pixel in the oracle's order.  Leaves in the job's slot the 256 values (jval), the blended pairs the backward pass needs
+// (jitems) and their number (jn; -1 = the link contributes nothing here).  pairA [2 * VB_RN] and hits [2 * VB_RN] are the
+// wave's LDS work areas.  Called by the job kernel right after a job's depth tests (the ids never leave LDS) and by
+// vb_resolve_kernel for the jobs vb_slow_kernel drew.
+__device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const unsigned* ids, float* pairA,
+                                               unsigned short* hits, const u64 (&C)[VB_WORDS], size_t slot, int b,
+                                               int rx0, int ry0) {
+    const int lane = lane_id();
+    const float4* const posc = Q.posc;
+    const int4* const tri4 = Q.tri4;
+    const int4* const opp4 = Q.opp4;
+    int* const jn = Q.jn;
+    float* const jval = Q.jval;
+    VbItem* const jitems = Q.jitems;
+    int* const jspill = Q.jspill;
+    VbItem* const spill = Q.spill;
+    int* const meta = Q.meta;
+    const int V = Q.V, T = Q.T, W = Q.W, H = Q.H, spill_cap = Q.spill_cap, want_grad = Q.want_grad, dbg = Q.dbg;
+#define KT(i) (ids[i])
+    const int r = lane >> 3, c4 = (lane & 7) * 4;
+    const int myq = (r + 1) * VB_RW + (c4 + 1);
+    const float4* const pv = posc + (size_t)b * V;
+    int nitems = 0;       // wave-uniform
+    int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
+    VB_WAVE_SYNC();
+    for (int i = lane; i < 2 * VB_RN; i += 64) pairA[i] = 0.f;
+    // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
+    u64 Iw[VB_WORDS];
+#pragma unroll
+    for (int k = 0; k < VB_WORDS; k++) {
+        const unsigned i = 64u * k + lane;
+        const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
+        const int x = rx0 + qx, y = ry0 + qy;
+        Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
+    }
+    u64 Vh[VB_WORDS], Vv[VB_WORDS];
+    {
+        // compile-time bitmaps (forced: a constexpr call with a loop index is otherwise evaluated at run time)
+        constexpr u64 KH[VB_WORDS] = {vb_word_h(0), vb_word_h(1), vb_word_h(2), vb_word_h(3), vb_word_h(4), vb_word_h(5)};
+        constexpr u64 KV[VB_WORDS] = {vb_word_v(0), vb_word_v(1), vb_word_v(2), vb_word_v(3), vb_word_v(4), vb_word_v(5)};
+        static_assert(VB_WORDS == 6, "tables above");
+        u64 s1[VB_WORDS], s34[VB_WORDS];
+        vb_shr<1>(Iw, s1);
+        vb_shr<VB_RW>(Iw, s34);
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            Vh[k] = Iw[k] & s1[k] & KH[k];
+            Vv[k] = Iw[k] & s34[k] & KV[k];
+        }
+    }
+    // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
+    //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
+    u64 Hw[2 * VB_WORDS];
+    int nh = 0;
+    {
+        u64 s1[VB_WORDS], s34[VB_WORDS];
+        vb_shr<1>(C, s1);
+        vb_shr<VB_RW>(C, s34);
+#pragma unroll
+        for (int k = 0; k < VB_WORDS; k++) {
+            Hw[k] = (C[k] ^ s1[k]) & Vh[k];
+            Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
+            nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
+        }
+    }
+    VB_WAVE_SYNC();
+    float val[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) val[j] = (KT(myq + j) != 0xffffffffu) ? 1.f : 0.f;
+    if (dbg & 2) nh = 0;
+    if (nh != 0) {
+        // ---- dense hit list, ordered by (direction, region index)
+        {
+            int base = 0;
+#pragma unroll
+            for (int s = 0; s < 2 * VB_WORDS; s++) {
+                const u64 w = Hw[s];
+                if (w) {
+                    if ((w >> lane) & 1)
+                        hits[base + vb_mbcnt(w)] = (unsigned short)(((s % VB_WORDS) * 64 + lane) | ((s / VB_WORDS) << 15));
+                    base += __popcll(w);
+                }
+            }
+        }
+        VB_WAVE_SYNC();
+        // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
+        for (int hbase = 0; hbase < nh; hbase += 64) {
+            const int h = hbase + lane;
+            VbItem it;
+            it.packed = 0;
+            it.v1 = 0;
+            it.v2 = 0;
+            it.alpha = 0.f;
+            bool keep = false;
+            if (h < nh) {
+                const int hq = hits[h];
+                const int d = hq >> 15, q = hq & 0x7fff;
+                const int qy = q / VB_RW, qx = q - qy * VB_RW;
+                const int nq = q + (d ? VB_RW : 1);
+                const unsigned k0 = KT(q), k1 = KT(nq);
+                const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
+                const int t = min((int)(chose0 ? k0 : k1) & 0x7fffffff, T - 1);  // (always a triangle id: the pixel has an uncovered neighbour)
+                int px = rx0 + qx, py = ry0 + qy;
+                if (!chose0) {
+                    px += 1 - d;
+                    py += d;
+                }
+                float4 p[3], o[3];
+                const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
+                const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
+#pragma unroll
+                for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
+#pragma unroll
+                for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
+                const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
+                if (a.found) {
+                    pairA[d * VB_RN + q] = a.alpha;
+                    // keep for the backward pass if the destination pixel is interior to this tile
+                    const int oq = (a.alpha > 0.f) ? q : nq;
+                    const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+                    const bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
+                    if (oi && a.alpha != 0.f) {
+                        it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
+                        it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
+                        it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
+                        it.alpha = a.alpha;
+                        keep = want_grad != 0;
+                    }
+                }
+            }
+            const u64 km = __ballot(keep);
+            if (km) {
+                const int at = nitems + vb_mbcnt(km);
+                const int nnew = nitems + __popcll(km);
+                if (nnew > VB_JOB_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this job
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
+                    spill_base = __builtin_amdgcn_readfirstlane(base);
+                }
+                // items this job can keep: its slot, then its block of the spill pool as far as the pool reaches
+                int room = VB_JOB_ITEMS;
+                if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
+                if (keep) {
+                    if (at < VB_JOB_ITEMS)
+                        jitems[slot * VB_JOB_ITEMS + at] = it;
+                    else if (at < room)
+                        spill[spill_base + (at - VB_JOB_ITEMS)] = it;
+                    else
+                        meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
+                }
+                nitems = min(nnew, room);  // never more than were stored: the composite kernel reads exactly these
+            }
+        }
+        VB_WAVE_SYNC();
+        // ---- gather the antialiased value of this link at my pixels (fixed order: down, left, right, up pair)
+        {
+            float cn[6], cd[4], cu[4];
+#pragma unroll
+            for (int j = 0; j < 6; j++) cn[j] = (KT(myq - 1 + j) != 0xffffffffu) ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cd[j] = (KT(myq - VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+                cu[j] = (KT(myq + VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float c = cn[j + 1];
+                float v = c;
+                float a;
+                a = pairA[VB_RN + myq + j - VB_RW];
+                if (a < 0.f) v += a * (c - cd[j]);
+                a = pairA[myq + j - 1];
+                if (a < 0.f) v += a * (c - cn[j]);
+                a = pairA[myq + j];
+                if (a > 0.f) v += a * (cn[j + 2] - c);
+                a = pairA[VB_RN + myq + j];
+                if (a > 0.f) v += a * (cu[j] - c);
+                val[j] = v;
+            }
+        }
+    }
+    // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
+    const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
+    if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
+    if (lane == 0) {
+        jn[slot] = nz ? nitems : -1;
+        if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
+    }
+#undef KT
+}
+
+// The job kernel's call: the job's coverage rows (cov) and depth/id buffer (key) are complete in LDS; the ids move to the
+// (now idle) deferred list, the key buffer becomes the pair table, and the wave resolves the job it has just drawn.
+// Nothing of the job's region goes through global memory, and the resolve stage needs no launch of its own: it was a
+// 10 us kernel of one dependent chain per job behind a boundary; here the chain runs while other waves still rasterize.
+// (Resolve and rasterizer never overlap inside a wave: the live ranges of the two are disjoint, unlike round 2's fusion.)
+__device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWaveLds& S, u64* key, const u64* cov, size_t slot,
+                                                    int b, int rx0, int ry0) {
+    const int lane = lane_id();
+    static_assert(2 * VB_RN <= VB_DL, "ids + hit list live in the deferred list's storage");
+    VB_WAVE_SYNC();
+    u64 C[VB_WORDS];
+    unsigned idw[VB_WORDS];
+#pragma unroll
+    for (int k = 0; k < VB_WORDS; k++) {
+        const unsigned i = 64u * k + lane;
+        const unsigned row = i / VB_RW, col = i - row * VB_RW;
+        const bool in = i < (unsigned)VB_RN;
+        const bool cv = in && ((cov[in ? row : 0] >> col) & 1ull);
+        const unsigned id = in ? (unsigned)key[i] : 0xffffffffu;  // low word = triangle id; all-ones stays all-ones
+        C[k] = __ballot(cv);
+        // covered pixels whose triangle was never asked for (no uncovered neighbour) carry a marker instead of an id
+        idw[k] = (id != 0xffffffffu) ? id : (cv ? VB_ID_COVERED : 0xffffffffu);
+    }
+    VB_WAVE_SYNC();  // every lane has read its keys: the buffer is free
+    unsigned* const ids = S.dl;
+#pragma unroll
+    for (int k = 0; k < VB_WORDS; k++) {
+        const unsigned i = 64u * k + lane;
+        if (i < (unsigned)VB_RN) ids[i] = idw[k];
+    }
+    vb_resolve_job(Q, ids, reinterpret_cast<float*>(key), reinterpret_cast<unsigned short*>(S.dl + VB_RN), C, slot, b, rx0, ry0);
+    VB_WAVE_SYNC();
+}
+
 #ifndef VB_JOB_WAVES
 #define VB_JOB_WAVES 4
 #endif
+#ifndef VB_INLINE_RESOLVE
+#define VB_INLINE_RESOLVE 1   // 0: the round-4 chain (jobs publish ids + coverage, vb_resolve_kernel resolves every slot)
+#endif
+// The job kernel's parameters, ONE struct in the kernarg segment.  VB_PARAM_BLOCK = 1: the kernel does not name its
+// parameter; it reads the fields through the kernarg segment pointer, made opaque to the optimiser at every use
+// (vb_job_params), so that a field is a scalar load where it is needed instead of one of ~60 scalar registers filled at
+// kernel entry and kept -- i.e. spilled to vector-register lanes and reloaded -- across the whole job loop (round 4: 237
+// spilled SGPRs in this kernel).  VB_PARAM_BLOCK = 0: ordinary by-value use of the same struct (the A/B reference).
+#ifndef VB_PARAM_BLOCK
+#define VB_PARAM_BLOCK 1
+#endif
+struct VbJobParams {
+    BinGeom g;
+    int B;
+    VbClusters cl;
+    VbRecs rc;
+    const int* lbox;
+    int* jn;
+    unsigned* jid;
+    int* jdesc;
+    int* jbase;
+    unsigned* jutile;
+    int jcap;
+    int* meta;
+    int dbg;
+    VbHeavy hv;
+    long long* timeline;
+    const float4* posc;
+    int V;
+    VbSlotIdx si;
+    u64* jcov;
+    int4* slow_list;
+    int heavy_t, med_t0;
+    VbResolveArgs rq;
+};
+typedef const VbJobParams __attribute__((address_space(4)))* VbJobParamsPtr;
+__device__ __forceinline__ VbJobParamsPtr vb_job_params() {
+    VbJobParamsPtr p = (VbJobParamsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));  // (what the optimiser cannot see through it cannot hoist to the kernel's entry)
+    return p;
+}
+template <class P>
+__device__ __forceinline__ VbResolveArgs vb_load_rq(P p) {
+    VbResolveArgs q;
+    q.posc = p->rq.posc; q.tri4 = p->rq.tri4; q.opp4 = p->rq.opp4; q.jn = p->rq.jn; q.jval = p->rq.jval;
+    q.jitems = p->rq.jitems; q.jspill = p->rq.jspill; q.spill = p->rq.spill; q.meta = p->rq.meta; q.V = p->rq.V;
+    q.T = p->rq.T; q.W = p->rq.W; q.H = p->rq.H; q.spill_cap = p->rq.spill_cap; q.want_grad = p->rq.want_grad;
+    q.dbg = p->rq.dbg;
+    return q;
+}
 // COVER (the scoring op): jcov = the (view, tile) coverage words [B][nt][4] the jobs OR their tile's interior into, jn = one
 // sticky flag raised by a job that met a triangle whose depth class does not let coverage decide; no slots, no lists.
 template <bool COVER>
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
-vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict__ lbox, int* __restrict__ jn,
-              unsigned* __restrict__ jid, int* __restrict__ jdesc, int* __restrict__ jbase, unsigned* __restrict__ jutile, int jcap,
-              int* __restrict__ meta, int dbg, VbHeavy hv, long long* __restrict__ timeline,
-              const float4* __restrict__ posc, int V, VbSlotIdx si, u64* __restrict__ jcov,
-              int4* __restrict__ slow_list, int heavy_t, int med_t0) {
+vb_job_kernel(VbJobParams prm_) {
     __shared__ VbWaveLds lds_all[4];
+    // PRM(field): a kernel parameter, read where it is used (see VbJobParams)
+#if VB_PARAM_BLOCK
+#define PRM(f) (vb_job_params()->f)
+#define VB_RQ() vb_load_rq(vb_job_params())
+#else
+#define PRM(f) (prm_.f)
+#define VB_RQ() vb_load_rq(&prm_)
+#endif
+    const int W = PRM(g.W), H = PRM(g.H), L = PRM(g.L), gnt = PRM(g.nt), gntx = PRM(g.ntx);
+    const int B = PRM(B), V = PRM(V), dbg = PRM(dbg);
+    int heavy_t = PRM(heavy_t);
+    const float4* const posc = PRM(posc);
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
 #endif
     // the scheduling hint of the previous step is requested before anything else (two dependent round trips that would
     // otherwise sit between the prologue and a heavy job)
-    const int gen = hv.gen[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
-    const int nheavy_prev = hv.gen[1 + hcur];
-    const int hid_first = hv.list[hcur * VB_HEAVY_CAP + min((int)blockIdx.x, VB_HEAVY_CAP - 1)];
+    const int gen = PRM(hv.gen)[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
+    const int nheavy_prev = PRM(hv.gen)[1 + hcur];
+    const int hid_first = PRM(hv.list)[hcur * VB_HEAVY_CAP + min((int)blockIdx.x, VB_HEAVY_CAP - 1)];
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
     __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
     __shared__ int lcoff[33];                 // first cluster of every link
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbWaveLds& S = lds_all[wave];
-    const int W = g.W, H = g.H, L = g.L, U = B * L;
+    const int U = B * L;
     // ---- prologue (every workgroup, redundantly): tile range and job count of every (view, link), prefix sum
-    if (tid <= L) lcoff[tid] = cl.coff[tid];
+    if (tid <= L) lcoff[tid] = PRM(cl.coff)[tid];
     for (int u = tid; u < U; u += 256) {
         int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
-        const bool ne = vb_unit_tiles(lbox + VB_LBOX_STRIDE * (size_t)u, W, H, tx0, ty0, nx, ny, COVER ? 0 : 1);
+        const bool ne = vb_unit_tiles(PRM(lbox) + VB_LBOX_STRIDE * (size_t)u, W, H, tx0, ty0, nx, ny, COVER ? 0 : 1);
         upre[u + 1] = ne ? nx * ny : 0;
         utile[u] = (unsigned)tx0 | ((unsigned)ty0 << 10) | ((unsigned)(ne ? nx : 1) << 22);
     }
@@ -1317,15 +1642,15 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     if (blockIdx.x == 0) {
         // job slots are numbered like the jobs: stage 3 finds a (view, link, tile) slot from the link's first job
         if (!COVER) {
-            for (int u = tid; u <= U; u += 256) jbase[u] = upre[u];
-            for (int u = tid; u < U; u += 256) jutile[u] = utile[u];
+            for (int u = tid; u <= U; u += 256) PRM(jbase)[u] = upre[u];
+            for (int u = tid; u < U; u += 256) PRM(jutile)[u] = utile[u];
         }
         if (tid == 0) {
-            meta[5] = total;  // number of jobs (the resolve kernel's loop bound)
-            if (!COVER && total > jcap) meta[EHR_META_OVERFLOW] = 1;  // cannot happen with one slot per (view, link, tile)
+            PRM(meta)[5] = total;  // number of jobs (the resolve kernel's loop bound)
+            if (!COVER && total > PRM(jcap)) PRM(meta)[EHR_META_OVERFLOW] = 1;  // cannot happen with one slot per (view, link, tile)
         }
     }
-    if (!COVER) total = min(total, jcap);
+    if (!COVER) total = min(total, PRM(jcap));
     // XCD-aware order: workgroup w runs on XCD w % 8 (observed, used for L2 locality only): every XCD takes a contiguous
     // eighth of the job list, so that a view's vertices, boxes and records stay in one L2.  Inside that eighth every wave
     // takes one job statically; the jobs beyond that are claimed (one returning atomic on the XCD's cursor) by whichever
@@ -1334,17 +1659,20 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     // same-address atomic) and the kernel is 20 % slower.
     const int per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
     const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
-    int* const cursor = vb_line(meta, xcd);
+    int* const cursor = vb_line(PRM(meta), xcd);
     VbJobArgs A;
-    A.rc = rc;
+    A.rc.tbox = PRM(rc.tbox);
+    A.rc.cbox = PRM(rc.cbox);
+    A.rc.trec = PRM(rc.trec);
+    A.rc.n = PRM(rc.n);
     A.posc = posc;
-    A.cvidx = si.cvidx;
+    A.cvidx = PRM(si.cvidx);
     A.lcoff = lcoff;
-    A.jid = jid;
-    A.jcov = jcov;
-    A.jdesc = jdesc;
-    A.jn = jn;
-    A.NC = cl.NC;
+    A.jid = PRM(jid);
+    A.jcov = PRM(jcov);
+    A.jdesc = PRM(jdesc);
+    A.jn = PRM(jn);
+    A.NC = PRM(cl.NC);
     A.V = V;
     A.W = W;
     A.H = H;
@@ -1360,7 +1688,7 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
     // meshes at 1080p have ~3000 of them in 8100 jobs and run 17 % slower with the heavy phase; the 8-view xArm7
     // workload has ~220 in 5000).
     const int hmax = (dbg >> 8) ? (dbg >> 8) : (int)gridDim.x / 2;  // (EHR_VB_DEBUG bits 8..: experiment with the limit)
-    const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > hmax) ? 0 : min(nheavy_prev, VB_HEAVY_CAP);
+    const int nheavy = ((dbg & 64) || total > 2 * 4 * (int)gridDim.x || nheavy_prev > hmax) ? 0 : min(nheavy_prev, min(VB_HEAVY_CAP, (int)gridDim.x));  // (<= one heavy job per workgroup)
     // ... and when there are fewer jobs than waves (one view, small images) most workgroups are idle anyway: jobs count as
     // heavy from a proportionally lower cost (down to an eighth: a few rounds), so that the longest ones are shared
     {
@@ -1368,28 +1696,29 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         heavy_t = (int)((float)heavy_t * f);
     }
     auto remember_heavy = [&](int id) {
-        const int at = atomicAdd(&hv.gen[1 + hnxt], 1);
-        if (at < VB_HEAVY_CAP) hv.list[hnxt * VB_HEAVY_CAP + at] = id;
+        const int at = atomicAdd(&PRM(hv.gen)[1 + hnxt], 1);
+        if (at < VB_HEAVY_CAP) PRM(hv.list)[hnxt * VB_HEAVY_CAP + at] = id;
     };
     // Long jobs below the heavy threshold: a wave that claims one late (after two or three others) is what the kernel
     // ends on -- 30 us on one wave whenever it starts -- so they are remembered as well and dealt out as static FIRST jobs,
     // one per wave, in the next step.  Only when the machine is short of jobs (at most 1.5 per wave): with more, claiming
     // balances the waves anyway and the jobs are better off in their own XCD's eighth of the list (L2).
-    const int med_t = max(med_t0, 1);
-    const int nmed = ((dbg & (64 | 128)) || total > 6 * (int)gridDim.x) ? 0 : min(hv.gen[4 + hcur], hv.mcap);
+    const int med_t = max(PRM(med_t0), 1);
+    const int nmed = ((dbg & (64 | 128)) || total > 6 * (int)gridDim.x) ? 0 : min(PRM(hv.gen)[4 + hcur], PRM(hv.mcap));
     auto remember_long = [&](int id) {
-        const int at = atomicAdd(&hv.gen[4 + hnxt], 1);
-        if (at < VB_MED_CAP) hv.mlist[hnxt * VB_MED_CAP + at] = id;
+        const int at = atomicAdd(&PRM(hv.gen)[4 + hnxt], 1);
+        if (at < VB_MED_CAP) PRM(hv.mlist)[hnxt * VB_MED_CAP + at] = id;
     };
     if (tid < 2) s_heavy[tid] = 0;
     __syncthreads();
 #if VB_PRIO_HEAVY
     if ((int)blockIdx.x < nheavy) __builtin_amdgcn_s_setprio(VB_PRIO_HEAVY);
 #endif
-    for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform
-        const int id = (hj == (int)blockIdx.x) ? hid_first : hv.list[hcur * VB_HEAVY_CAP + hj];
-        const int u = id / g.nt, tile = id - u * g.nt;
-        const int tx = tile % g.ntx, ty = tile / g.ntx;
+    int hres_job = -1, hres_b = 0, hres_rx0 = 0, hres_ry0 = 0;  // the heavy job wave 0 resolves once the workgroup has split up again
+    for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform (at most one turn: nheavy <= gridDim.x)
+        const int id = (hj == (int)blockIdx.x) ? hid_first : PRM(hv.list)[hcur * VB_HEAVY_CAP + hj];
+        const int u = id / gnt, tile = id - u * gnt;
+        const int tx = tile % gntx, ty = tile / gntx;
         const unsigned ut = utile[u];
         const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
         const int job = upre[u] + (ty - ty0) * nx + (tx - tx0);
@@ -1416,16 +1745,25 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         const int any_drawn = s_heavy[0];
         int tot_surv = s_heavy[1];
         if (!(any_drawn & 2) && dln > 0)
-            vb_flush(S, S0.key, S0.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+            vb_flush(S, S0.key, S0.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
         __syncthreads();
+#if VB_INLINE_RESOLVE
+        if (!COVER && any_drawn == 1) {
+            hres_job = job;
+            hres_b = b;
+            hres_rx0 = rx0;
+            hres_ry0 = ry0;
+        }
+#else
         if (any_drawn == 1) vb_publish(A, S0.key, S0.cov, job, u, tx, ty, wave, 4);  // every wave its share of the words
+#endif
         if (wave == 0) {
             if (any_drawn & 2) {  // put aside for vb_slow_kernel
-                if (lane == 0) vb_put_aside(slow_list, meta, jn, jdesc, job, u, tx, ty);
+                if (lane == 0) vb_put_aside(PRM(slow_list), PRM(meta), PRM(jn), PRM(jdesc), job, u, tx, ty);
             } else if (any_drawn) {
             } else if (lane == 0) {
-                jn[job] = -1;
-                jdesc[job] = -1;
+                PRM(jn)[job] = -1;
+                PRM(jdesc)[job] = -1;
             }
             if (lane == 0) {
                 s_heavy[0] = 0;
@@ -1442,6 +1780,10 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         __syncthreads();
     }
 
+#if VB_INLINE_RESOLVE
+    // (the loop's last barrier is behind us: waves 1-3 go on to their own jobs, nobody touches wave 0's LDS but wave 0)
+    if (!COVER && wave == 0 && hres_job >= 0) vb_resolve_from_lds(VB_RQ(), S, S.key, S.cov, (size_t)hres_job, hres_b, hres_rx0, hres_ry0);
+#endif
 #if VB_PRIO_HEAVY
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -1479,11 +1821,11 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(VB_PRIO_LONG);
 #endif
-            const int id = hv.mlist[hcur * VB_MED_CAP + 8 * rx + xcd];
-            u = id / g.nt;
-            const int tile = id - u * g.nt;
-            tx = tile % g.ntx;
-            ty = tile / g.ntx;
+            const int id = PRM(hv.mlist)[hcur * VB_MED_CAP + 8 * rx + xcd];
+            u = id / gnt;
+            const int tile = id - u * gnt;
+            tx = tile % gntx;
+            ty = tile / gntx;
             const unsigned ut = utile[u];
             const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
             job = upre[u] + (ty - ty0) * nx + (tx - tx0);
@@ -1519,13 +1861,13 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
                 ty = (int)((ut >> 10) & 4095u) + k / nx;
                 tx = (int)(ut & 1023u) + k - (k / nx) * nx;
             }
-            const int st = (nheavy > 0 || nmed > 0) ? hv.stamp[u * g.nt + ty * g.ntx + tx] : 0;
+            const int st = (nheavy > 0 || nmed > 0) ? PRM(hv.stamp)[u * gnt + ty * gntx + tx] : 0;
             // a workgroup took this one in the heavy phase / it is some wave's first job
             if ((nheavy > 0 && st == gen) || (nmed > 0 && st == -gen)) continue;
         }
         const int b = u / L, l = u - b * L;
         const size_t slot = (size_t)job;
-        const int dense_id = u * g.nt + ty * g.ntx + tx;
+        const int dense_id = u * gnt + ty * gntx + tx;
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
         VbRegion rg;  // tile + 1-pixel halo, inside the image (coverage-only form: the tile alone, same origin)
         rg.x0 = COVER ? rx0 + 1 : max(rx0, 0);
@@ -1551,10 +1893,10 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         if (COVER) {
             // flagged units (their depth range must be tested per pixel: edge-on slivers mostly) are the only deferred ones
             if (drawn >= 0 && dln > 0)
-                vb_flush<true>(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+                vb_flush<true>(S, S.key, S.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
             VB_WAVE_SYNC();
             if (drawn < 0 || S.bad) {  // a triangle for the general path, or a drawn pixel with a depth <= 0: coverage cannot
-                if (lane == 0) jn[0] = 1;  // decide here and the caller falls back for the whole call
+                if (lane == 0) PRM(jn)[0] = 1;  // decide here and the caller falls back for the whole call
                 continue;
             }
             if (drawn > 0) {
@@ -1563,17 +1905,17 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
                 if (lane < 4) {
                     const u64 w = ((S.cov[2 * lane + 1] >> 1) & 0xffffffffull) | (((S.cov[2 * lane + 2] >> 1) & 0xffffffffull) << 32);
                     // (layout [candidate][tile][pose][4]: the count kernel reads a candidate's words of a tile in one piece;
-                    //  jcap carries S, the poses per candidate, in this form)
-                    if (w) atomicOr((unsigned long long*)&jcov[((((size_t)(b / jcap) * g.nt + (size_t)ty * g.ntx + tx) * jcap + (b % jcap)) * 4 + lane)], w);
+                    //  PRM(jcap) carries S, the poses per candidate, in this form)
+                    if (w) atomicOr((unsigned long long*)&PRM(jcov)[((((size_t)(b / PRM(jcap)) * gnt + (size_t)ty * gntx + tx) * PRM(jcap) + (b % PRM(jcap))) * 4 + lane)], w);
                 }
             }
             continue;
         }
         if (drawn < 0) {  // a triangle for the general path (near-plane clipping, huge extent): put the job aside
-            if (lane == 0) vb_put_aside(slow_list, meta, jn, jdesc, job, u, tx, ty);
+            if (lane == 0) vb_put_aside(PRM(slow_list), PRM(meta), PRM(jn), PRM(jdesc), job, u, tx, ty);
             continue;
         }
-        if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, si.cvidx + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+        if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
 #ifdef VB_TIMELINE
         tl_jobs++;
         tl_maxsurv = max(tl_maxsurv, nsurv);
@@ -1587,15 +1929,19 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         }
         if (drawn == 0) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
-                jn[slot] = -1;
-                jdesc[slot] = -1;
+                PRM(jn)[slot] = -1;
+                PRM(jdesc)[slot] = -1;
             }
             continue;
         }
 #ifdef VB_TIMELINE
         const long long tl_j2 = __builtin_readcyclecounter();
 #endif
+#if VB_INLINE_RESOLVE
+        vb_resolve_from_lds(VB_RQ(), S, S.key, S.cov, slot, b, rx0, ry0);
+#else
         vb_publish(A, S.key, S.cov, job, u, tx, ty);
+#endif
 #ifdef VB_TIMELINE
         if (lane == 0) {
             const long long now = __builtin_readcyclecounter();
@@ -1606,16 +1952,16 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
 #endif
     }
 #ifdef VB_TIMELINE
-    if (lane == 0 && timeline) {
+    if (lane == 0 && PRM(timeline)) {
         const size_t gw = (size_t)blockIdx.x * 4 + wave;
         const unsigned hwid = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: wave slot, SIMD, CU, SH, SE
         const unsigned xccid = __builtin_amdgcn_s_getreg(20 | (31 << 11));  // XCC_ID
-        timeline[4 * gw] = tl_start;
-        timeline[4 * gw + 1] = wall_clock64();
-        timeline[4 * gw + 2] = tl_heavy;
-        timeline[4 * gw + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
+        PRM(timeline)[4 * gw] = tl_start;
+        PRM(timeline)[4 * gw + 1] = wall_clock64();
+        PRM(timeline)[4 * gw + 2] = tl_heavy;
+        PRM(timeline)[4 * gw + 3] = (long long)(tl_jobs & 0xff) | ((long long)(tl_maxsurv & 0xfff) << 8) | ((long long)(tl_sumsurv & 0xfff) << 20) |
                                ((long long)(hwid & 0xffff) << 32) | ((long long)(xccid & 0xf) << 48);
-        long long* const tx = timeline + 4 * (size_t)gridDim.x * 4 + 12 * gw;
+        long long* const tx = PRM(timeline) + 4 * (size_t)gridDim.x * 4 + 12 * gw;
         tx[0] = S.tl_units;
         tx[1] = S.tl_rounds;
         tx[2] = (long long)S.tl_flushes | ((long long)S.tl_tested << 16) | ((long long)S.tl_deferred << 40);
@@ -1624,9 +1970,11 @@ vb_job_kernel(BinGeom g, int B, VbClusters cl, VbRecs rc, const int* __restrict_
         for (int k = 0; k < 3; k++) tx[8 + k] = S.tl_c[4 + k];
     }
 #else
-    (void)timeline;
+    
 #endif
 }
+#undef PRM
+#undef VB_RQ
 
 // Stage 2a (normally empty): the jobs the lean code put aside, one wave each, with the general triangle path.
 __global__ void __launch_bounds__(256)
@@ -1658,33 +2006,35 @@ vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ p
     }
 }
 
-// Stage 2b: one WAVE per DRAWN job, persistent waves over the per-XCD lists the job kernel appended to.  From the
-// triangle ids of the job's region (tile + 1-pixel halo): covered/uncovered pixel pairs by wave-uniform bit arithmetic on
-// the coverage bitmap, silhouette analysis of the compacted hits (restates nvdiffrast's antialias mesh kernel), gather of
-// the link's antialiased value per pixel in the oracle's order.  Leaves in the job's slot the 256 values (jval), the
-// blended pairs the backward pass needs (jitems) and their number (jn; -1 = the link contributes nothing here).
-// A kernel of its own because its registers (36 wave-uniform 64-bit bitmaps, 24 floats of vertex positions per hit)
-// and the rasterizer's do not fit 128 VGPRs together: fused, the job kernel kept 350 bytes per lane in scratch and its
-// 4096 waves' 91 MB of scratch evicted each other from the 4 MB L2s.
+// Stage 2b, as a kernel of its own: one WAVE per drawn job whose coverage and triangle ids were PUBLISHED to its slot
+// (jid / jcov / jdesc) instead of being resolved by the wave that drew it.  Since round 5 the job kernel resolves its jobs
+// itself, straight from LDS (vb_resolve_job above); what is left for this kernel are the jobs vb_slow_kernel redrew with
+// the general triangle path (slow_list != NULL: exactly those), i.e. normally nothing -- the solver step only launches it
+// together with vb_slow_kernel.  slow_list == NULL: every job slot of the chunk (the round-4 form of the chain, kept as
+// the A/B reference: -DVB_INLINE_RESOLVE=0).
 __global__ void __launch_bounds__(256)
 vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, const int4* __restrict__ tri4,
                   const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const u64* __restrict__ jcov,
                   const int* __restrict__ jdesc,
                   int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems,
                   int* __restrict__ jspill, int jcap, int want_grad, VbItem* __restrict__ spill, int spill_cap,
-                  int* __restrict__ meta, int dbg) {
+                  int* __restrict__ meta, int dbg, const int4* __restrict__ slow_list) {
     __shared__ VbResolveLds lds_all[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbResolveLds& S = lds_all[wave];
-#define KT(i) (S.ids[i])
     const int W = g.W, H = g.H, L = g.L;
     (void)B;
     // XCD-aware like the job kernel (workgroup w runs on XCD w % 8; the slots of an eighth of the job list were written
     // through that XCD's L2), one job per wave and turn
+    const bool listed = slow_list != nullptr;
     const int total = min(meta[5], jcap), per_xcd = (total + 7) >> 3, xcd = blockIdx.x & 7;
     const int jbeg = xcd * per_xcd, jend = min(jbeg + per_xcd, total);
-    const int step = (int)(gridDim.x >> 3) * 4;
-    for (int job = jbeg + (int)(blockIdx.x >> 3) * 4 + wave; job < jend; job += step) {
+    const int it0 = listed ? (int)blockIdx.x * 4 + wave : jbeg + (int)(blockIdx.x >> 3) * 4 + wave;
+    const int it1 = listed ? *vb_line(meta, 17) : jend;
+    const int step = listed ? (int)gridDim.x * 4 : (int)(gridDim.x >> 3) * 4;
+    for (int it = it0; it < it1; it += step) {
+        const int job = listed ? slow_list[it].x : it;
+        if (job >= jcap) continue;
         const size_t slot = (size_t)job;
         // the ids are requested together with the descriptor (one round trip; an undrawn slot holds stale ids, unused)
         unsigned idw[VB_WORDS];
@@ -1717,177 +2067,12 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int 
             if (i < (unsigned)VB_RN)
                 S.ids[i] = (idw[k] != 0xffffffffu) ? idw[k] : (((C[k] >> lane) & 1ull) ? VB_ID_COVERED : 0xffffffffu);
         }
-        const int r = lane >> 3, c4 = (lane & 7) * 4;
-        const int myq = (r + 1) * VB_RW + (c4 + 1);
-        const float4* const pv = posc + (size_t)b * V;
-        int nitems = 0;       // wave-uniform
-        int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
-        VB_WAVE_SYNC();
-        for (int i = lane; i < 2 * VB_RN; i += 64) S.pairA[i] = 0.f;
-        // region pixels inside the image (wave-uniform bitmap) and the pair-validity bitmaps derived from it
-        u64 Iw[VB_WORDS];
-#pragma unroll
-        for (int k = 0; k < VB_WORDS; k++) {
-            const unsigned i = 64u * k + lane;
-            const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
-            const int x = rx0 + qx, y = ry0 + qy;
-            Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
-        }
-        u64 Vh[VB_WORDS], Vv[VB_WORDS];
-        {
-            // compile-time bitmaps (forced: a constexpr call with a loop index is otherwise evaluated at run time)
-            constexpr u64 KH[VB_WORDS] = {vb_word_h(0), vb_word_h(1), vb_word_h(2), vb_word_h(3), vb_word_h(4), vb_word_h(5)};
-            constexpr u64 KV[VB_WORDS] = {vb_word_v(0), vb_word_v(1), vb_word_v(2), vb_word_v(3), vb_word_v(4), vb_word_v(5)};
-            static_assert(VB_WORDS == 6, "tables above");
-            u64 s1[VB_WORDS], s34[VB_WORDS];
-            vb_shr<1>(Iw, s1);
-            vb_shr<VB_RW>(Iw, s34);
-#pragma unroll
-            for (int k = 0; k < VB_WORDS; k++) {
-                Vh[k] = Iw[k] & s1[k] & KH[k];
-                Vv[k] = Iw[k] & s34[k] & KV[k];
-            }
-        }
-        // ---- pairs with exactly one covered pixel.  Only those can change the result: with constant colour inside a
-        //      link a blend between two covered pixels is alpha * (1 - 1) = 0 in value and in gradient.
-        u64 Hw[2 * VB_WORDS];
-        int nh = 0;
-        {
-            u64 s1[VB_WORDS], s34[VB_WORDS];
-            vb_shr<1>(C, s1);
-            vb_shr<VB_RW>(C, s34);
-#pragma unroll
-            for (int k = 0; k < VB_WORDS; k++) {
-                Hw[k] = (C[k] ^ s1[k]) & Vh[k];
-                Hw[VB_WORDS + k] = (C[k] ^ s34[k]) & Vv[k];
-                nh += __popcll(Hw[k]) + __popcll(Hw[VB_WORDS + k]);
-            }
-        }
-        VB_WAVE_SYNC();
-        float val[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) val[j] = (KT(myq + j) != 0xffffffffu) ? 1.f : 0.f;
-        if (dbg & 2) nh = 0;
-        if (nh != 0) {
-            // ---- dense hit list, ordered by (direction, region index)
-            {
-                int base = 0;
-#pragma unroll
-                for (int s = 0; s < 2 * VB_WORDS; s++) {
-                    const u64 w = Hw[s];
-                    if (w) {
-                        if ((w >> lane) & 1)
-                            S.hits[base + vb_mbcnt(w)] = (unsigned short)(((s % VB_WORDS) * 64 + lane) | ((s / VB_WORDS) << 15));
-                        base += __popcll(w);
-                    }
-                }
-            }
-            VB_WAVE_SYNC();
-            // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
-            for (int hbase = 0; hbase < nh; hbase += 64) {
-                const int h = hbase + lane;
-                VbItem it;
-                it.packed = 0;
-                it.v1 = 0;
-                it.v2 = 0;
-                it.alpha = 0.f;
-                bool keep = false;
-                if (h < nh) {
-                    const int hq = S.hits[h];
-                    const int d = hq >> 15, q = hq & 0x7fff;
-                    const int qy = q / VB_RW, qx = q - qy * VB_RW;
-                    const int nq = q + (d ? VB_RW : 1);
-                    const unsigned k0 = KT(q), k1 = KT(nq);
-                    const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
-                    const int t = min((int)(chose0 ? k0 : k1) & 0x7fffffff, T - 1);  // (always a triangle id: the pixel has an uncovered neighbour)
-                    int px = rx0 + qx, py = ry0 + qy;
-                    if (!chose0) {
-                        px += 1 - d;
-                        py += d;
-                    }
-                    float4 p[3], o[3];
-                    const int4 ti = tri4[t], oi = opp4[t];  // one aligned 16-byte gather each
-                    const int vi[3] = {ti.x, ti.y, ti.z}, ov[3] = {oi.x, oi.y, oi.z};
-#pragma unroll
-                    for (int k = 0; k < 3; k++) p[k] = pv[vi[k]];
-#pragma unroll
-                    for (int k = 0; k < 3; k++) o[k] = ((unsigned)ov[k] < (unsigned)V) ? pv[ov[k]] : p[k];
-                    const AAPair a = aa_analyze(p, o, px, py, d, chose0, W, H);
-                    if (a.found) {
-                        S.pairA[d * VB_RN + q] = a.alpha;
-                        // keep for the backward pass if the destination pixel is interior to this tile
-                        const int oq = (a.alpha > 0.f) ? q : nq;
-                        const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
-                        const bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
-                        if (oi && a.alpha != 0.f) {
-                            it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
-                            it.v1 = (a.di == 0) ? vi[1] : (a.di == 1 ? vi[2] : vi[0]);  // edge di: v1-v2, v2-v0, v0-v1
-                            it.v2 = (a.di == 0) ? vi[2] : (a.di == 1 ? vi[0] : vi[1]);
-                            it.alpha = a.alpha;
-                            keep = want_grad != 0;
-                        }
-                    }
-                }
-                const u64 km = __ballot(keep);
-                if (km) {
-                    const int at = nitems + vb_mbcnt(km);
-                    const int nnew = nitems + __popcll(km);
-                    if (nnew > VB_JOB_ITEMS && spill_base < 0) {  // wave-uniform: first overflow of this job
-                        int base = 0;
-                        if (lane == 0) base = atomicAdd(&meta[EHR_META_SPILL], VB_SPILL_BLOCK);
-                        spill_base = __builtin_amdgcn_readfirstlane(base);
-                    }
-                    // items this job can keep: its slot, then its block of the spill pool as far as the pool reaches
-                    int room = VB_JOB_ITEMS;
-                    if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
-                    if (keep) {
-                        if (at < VB_JOB_ITEMS)
-                            jitems[slot * VB_JOB_ITEMS + at] = it;
-                        else if (at < room)
-                            spill[spill_base + (at - VB_JOB_ITEMS)] = it;
-                        else
-                            meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
-                    }
-                    nitems = min(nnew, room);  // never more than were stored: the composite kernel reads exactly these
-                }
-            }
-            VB_WAVE_SYNC();
-            // ---- gather the antialiased value of this link at my pixels (fixed order: down, left, right, up pair)
-            {
-                float cn[6], cd[4], cu[4];
-#pragma unroll
-                for (int j = 0; j < 6; j++) cn[j] = (KT(myq - 1 + j) != 0xffffffffu) ? 1.f : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    cd[j] = (KT(myq - VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
-                    cu[j] = (KT(myq + VB_RW + j) != 0xffffffffu) ? 1.f : 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float c = cn[j + 1];
-                    float v = c;
-                    float a;
-                    a = S.pairA[VB_RN + myq + j - VB_RW];
-                    if (a < 0.f) v += a * (c - cd[j]);
-                    a = S.pairA[myq + j - 1];
-                    if (a < 0.f) v += a * (c - cn[j]);
-                    a = S.pairA[myq + j];
-                    if (a > 0.f) v += a * (cn[j + 2] - c);
-                    a = S.pairA[VB_RN + myq + j];
-                    if (a > 0.f) v += a * (cu[j] - c);
-                    val[j] = v;
-                }
-            }
-        }
-        // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
-        const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
-        if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
-        if (lane == 0) {
-            jn[slot] = nz ? nitems : -1;
-            if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
-        }
+        VbResolveArgs Q;  // (wave-uniform; the compiler keeps what it needs in scalar registers)
+        Q.posc = posc; Q.tri4 = tri4; Q.opp4 = opp4; Q.jn = jn; Q.jval = jval; Q.jitems = jitems; Q.jspill = jspill;
+        Q.spill = spill; Q.meta = meta; Q.V = V; Q.T = T; Q.W = W; Q.H = H; Q.spill_cap = spill_cap; Q.want_grad = want_grad;
+        Q.dbg = dbg;
+        vb_resolve_job(Q, S.ids, S.pairA, S.hits, C, slot, b, rx0, ry0);
     }
-#undef KT
 }
 
 // Per (view, tile) of a BOUND reference mask: the fixed-point value the composite kernel would add to the view's frame
@@ -2560,10 +2745,10 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                 const long long x = tl[4 * i + 3];
                 const unsigned hw = (unsigned)(x >> 32) & 0xffff;
                 const long long* tx = &tl[4 * (size_t)nw + 12 * i];
-                fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; %lld units in %lld rounds ; %lld flushes: %lld of %lld units tested ; kcycles stage %.0f search %.0f walk %.0f flush %.0f ; xcc %lld cu %u simd %u\n", i, i / 4,
+                fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; %lld units in %lld rounds ; %lld flushes: %lld of %lld units tested ; kcycles stage %.0f search %.0f walk %.0f flush %.0f resolve %.0f ; xcc %lld cu %u simd %u\n", i, i / 4,
                         (tl[4 * i] - t0) * 0.01, (tl[4 * i + 2] - t0) * 0.01, (tl[4 * i + 1] - t0) * 0.01, x & 0xff, (x >> 8) & 0xfff,
                         (x >> 20) & 0xfff, tx[0], tx[1], tx[2] & 0xffff, (tx[2] >> 16) & 0xffffff, tx[2] >> 40, tx[3] * 1e-3, tx[4] * 1e-3, tx[5] * 1e-3,
-                        tx[6] * 1e-3, (x >> 48) & 0xf, (hw >> 8) & 15, (hw >> 4) & 3);
+                        tx[6] * 1e-3, tx[10] * 1e-3, (x >> 48) & 0xf, (hw >> 8) & 15, (hw >> 4) & 3);
             }
             long long mx = 0, sum = 0;
             int used = 0;
@@ -2601,7 +2786,7 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                     if (!hp.empty()) fprintf(stderr, " (%.1f, %lld)", hp.back().first * 0.01, hp.back().second);
                     fprintf(stderr, "\n");
                 }
-                fprintf(stderr, "[ehr timeline] single-wave jobs (drawn ones): %.1f wave-Mcycles in total, claim + set-up %.1f, publish %.1f\n", jc[0] * 1e-6, jc[1] * 1e-6, jc[2] * 1e-6);
+                fprintf(stderr, "[ehr timeline] single-wave jobs (drawn ones): %.1f wave-Mcycles in total, claim + set-up %.1f, publish / resolve %.1f\n", jc[0] * 1e-6, jc[1] * 1e-6, jc[2] * 1e-6);
                 fprintf(stderr, "[ehr timeline] flushes %lld, deferred units %lld, depth-tested units %lld; wave-Mcycles: staging %.1f, prefix+search %.1f, walk %.1f, flush %.1f (of %.1f in total)\n",
                         fl, de, te, cyc[0] * 1e-6, cyc[1] * 1e-6, cyc[2] * 1e-6, cyc[3] * 1e-6, busy * 0.01 * 2100.0 * 1e-6);
             }
@@ -2723,9 +2908,48 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         const int job_wgs = ((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7;
         // stage 1a (below) is launched by the stateless render call always, by the solver step only once a step needed it
         const bool with_slow = !tail || ctx->vb_slow_needed;
-        vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, jn, jid, jdesc, jbase, jutile, ctx->vb_jcap, meta, dbg,
-                                                    hv, (long long*)ctx->vb_spill.ptr, posc, V, si, jcov,
-                                                    with_slow ? slow_list : nullptr, heavy_t, med_t);
+        VbResolveArgs rq;  // the resolve stage runs inside the job kernel, on the wave that drew the job
+        rq.posc = posc;
+        rq.tri4 = (const int4*)ctx->vb_idx.ptr;
+        rq.opp4 = (const int4*)ctx->vb_idx.ptr + T;
+        rq.jn = jn;
+        rq.jval = jval;
+        rq.jitems = jitems;
+        rq.jspill = jspill;
+        rq.spill = spill;
+        rq.meta = meta;
+        rq.V = V;
+        rq.T = T;
+        rq.W = W;
+        rq.H = H;
+        rq.spill_cap = ctx->vb_spill_cap;
+        rq.want_grad = grad_mvp ? 1 : 0;
+        rq.dbg = dbg;
+        VbJobParams jp;
+        jp.g = g;
+        jp.B = Bk;
+        jp.cl = cl;
+        jp.rc = recs;
+        jp.lbox = lbox;
+        jp.jn = jn;
+        jp.jid = jid;
+        jp.jdesc = jdesc;
+        jp.jbase = jbase;
+        jp.jutile = jutile;
+        jp.jcap = ctx->vb_jcap;
+        jp.meta = meta;
+        jp.dbg = dbg;
+        jp.hv = hv;
+        jp.timeline = (long long*)ctx->vb_spill.ptr;
+        jp.posc = posc;
+        jp.V = V;
+        jp.si = si;
+        jp.jcov = jcov;
+        jp.slow_list = with_slow ? slow_list : nullptr;
+        jp.heavy_t = heavy_t;
+        jp.med_t0 = med_t;
+        jp.rq = rq;
+        vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(jp);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
         static const int slow_grid = getenv("EHR_VB_SLOW_GRID") ? atoi(getenv("EHR_VB_SLOW_GRID")) : 32;  // tuning knob
@@ -2734,12 +2958,23 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
             EHR_LAUNCH_CHECK();
         }
         if (time_it) EHR_HIP(hipEventRecord(ev[2], stream));
-        // stage 1b: drawn jobs -> per-link values and blended pairs
+        // stage 1b: drawn jobs -> per-link values and blended pairs.  The job kernel has done that for the jobs it drew itself;
+        // only the jobs vb_slow_kernel redrew are left (none, normally: a launch of 32 workgroups that read a counter)
+#if VB_INLINE_RESOLVE
+        if (with_slow) {
+            vb_resolve_kernel<<<std::max(8, slow_grid), 256, 0, stream>>>(g, Bk, posc, V, T, rq.tri4, rq.opp4, jid, jcov, jdesc, jn, jval,
+                                                                          jitems, jspill, ctx->vb_jcap, rq.want_grad, spill,
+                                                                          ctx->vb_spill_cap, meta, dbg, slow_list);
+            EHR_LAUNCH_CHECK();
+        }
+        (void)res_grid;
+#else
         const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
         vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, Bk, posc, V, T, (const int4*)ctx->vb_idx.ptr,
                                                        (const int4*)ctx->vb_idx.ptr + T, jid, jcov, jdesc, jn, jval, jitems, jspill,
-                                                       ctx->vb_jcap, grad_mvp ? 1 : 0, spill, ctx->vb_spill_cap, meta, dbg);
+                                                       ctx->vb_jcap, grad_mvp ? 1 : 0, spill, ctx->vb_spill_cap, meta, dbg, nullptr);
         EHR_LAUNCH_CHECK();
+#endif
         if (time_it) {
             for (int k = 3; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
         }
@@ -2891,8 +3126,24 @@ int ehr::vbuf_score(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                                                                 V, nvb, g, posc, recs, lbox, (int*)tcov, Bk * g.nt * 8, meta, Bk, gx,
                                                                 xcd_views, hv, 1 | 4);
         EHR_LAUNCH_CHECK();
-        vb_job_kernel<true><<<job_wgs, 256, 0, stream>>>(g, Bk, cl, recs, lbox, sticky, nullptr, nullptr, nullptr, nullptr, S, meta,
-                                                      64 | 128, hv, nullptr, posc, V, si, tcov, nullptr, 0x7fffffff, 0x7fffffff);
+        VbJobParams jp = {};
+        jp.g = g;
+        jp.B = Bk;
+        jp.cl = cl;
+        jp.rc = recs;
+        jp.lbox = lbox;
+        jp.jn = sticky;
+        jp.jcap = S;
+        jp.meta = meta;
+        jp.dbg = 64 | 128;
+        jp.hv = hv;
+        jp.posc = posc;
+        jp.V = V;
+        jp.si = si;
+        jp.jcov = tcov;
+        jp.heavy_t = 0x7fffffff;
+        jp.med_t0 = 0x7fffffff;
+        vb_job_kernel<true><<<job_wgs, 256, 0, stream>>>(jp);
         EHR_LAUNCH_CHECK();
         static const int count_grid = getenv("EHR_SCORE_COUNT_GRID") ? atoi(getenv("EHR_SCORE_COUNT_GRID")) : 4;  // tuning knob
         unsigned long long* const sacc = sacc0 + (size_t)flip * 16 * Qc;
