@@ -50,7 +50,7 @@ constexpr int VB_RH = EHR_TILE_H + 2;
 constexpr int VB_RN = VB_RW * VB_RH;   // 340
 constexpr int VB_WORDS = (VB_RN + 63) / 64;  // 6 coverage words
 constexpr int VB_LBOX_STRIDE = 16;     // ints per (view, link) box: min x, min y, max x, max y, padding to a 64-byte line
-#define VB_HEAVY_T_DEFAULT 2500        // cost (4-pixel units walked + 256 per rasterizer round) from which a job counts as
+#define VB_HEAVY_T_DEFAULT 3000        // cost (4-pixel units walked + 256 per rasterizer round) from which a job counts as
                                       // heavy: next step a whole workgroup takes it.  Units, not triangles: a tile of 130 long
                                       // thin triangles (7000 units) keeps a wave busy for 60 us, one of 380 small ones for 25
 constexpr int VB_HEAVY_CAP = 4096;    // heavy jobs remembered per step
@@ -142,6 +142,11 @@ struct VbHeavy {
                   // out as some wave's first job
     int mcap;     // long jobs consumed per step: min(VB_MED_CAP, 2 x workgroups of the job kernel) -- every one of them
                   // must find a wave with a static first job, and at least half the workgroups have those
+    int heavy_base;  // the cost from which a job counts as heavy (gen[6] holds the value in force, never below this one)
+    int heavy_max;   // heavy jobs a step can use (half the job kernel's workgroups): when a step records more, the value in
+                     // force rises by an eighth, so that the heaviest jobs keep their workgroups instead of the whole phase
+                     // being switched off (the Franka meshes at 1080p: 3000 jobs above 2500 in 8100; 112 instead of 124 us
+                     // with the ~500 heaviest shared); it sinks back when fewer than half as many are recorded
 };
 
 struct VbClusters {          // static acceleration index built by ehr_fused_plan (host): triangles grouped into
@@ -357,6 +362,15 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             hv.gen[0] = s_gen;
             hv.gen[1 + (s_gen & 1)] = 0;
             hv.gen[4 + (s_gen & 1)] = 0;
+            {   // the heavy threshold in force follows the number of heavy jobs the last step recorded
+                const int nprev = hv.gen[1 + ((s_gen - 1) & 1)];
+                int thr = max(hv.gen[6], hv.heavy_base);
+                if (nprev > hv.heavy_max)
+                    thr = min(thr + (thr >> 3), 1 << 24);
+                else if (2 * nprev < hv.heavy_max)
+                    thr = max(hv.heavy_base, thr - (thr >> 4));
+                hv.gen[6] = thr;
+            }
         }
         __syncthreads();
         {
@@ -1597,7 +1611,7 @@ vb_job_kernel(VbJobParams prm_) {
 #endif
     const int W = PRM(g.W), H = PRM(g.H), L = PRM(g.L), gnt = PRM(g.nt), gntx = PRM(g.ntx);
     const int B = PRM(B), V = PRM(V), dbg = PRM(dbg);
-    int heavy_t = PRM(heavy_t);
+    int heavy_t = max(PRM(heavy_t), PRM(hv.gen)[6]);  // (the value in force: the vertex kernel adapts it, see VbHeavy)
     const float4* const posc = PRM(posc);
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
@@ -2844,6 +2858,8 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     static const int heavy_t = getenv("EHR_VB_HEAVY_T") ? atoi(getenv("EHR_VB_HEAVY_T")) : VB_HEAVY_T_DEFAULT;  // tuning knob
     static const int med_t = getenv("EHR_VB_MED_T") ? atoi(getenv("EHR_VB_MED_T")) : VB_MED_T_DEFAULT;        // tuning knob
     hv.mcap = std::min(VB_MED_CAP, 2 * (((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7));
+    hv.heavy_base = heavy_t;
+    hv.heavy_max = ((((ctx->num_cus * std::max(1, job_grid)) + 7) & ~7)) / 2;
     static const int vertex_grid = getenv("EHR_VB_VERTEX_GRID") ? atoi(getenv("EHR_VB_VERTEX_GRID")) : 5;  // tuning knob
     static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
     static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
@@ -3095,6 +3111,8 @@ int ehr::vbuf_score(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     hv.mlist = hv.list + 2 * VB_HEAVY_CAP;
     hv.stamp = hv.gen;  // (never touched: the hint is off)
     hv.mcap = 0;
+    hv.heavy_base = 0;
+    hv.heavy_max = 0;
     EHR_HIP(hipMemsetAsync(hvp, 0, (n_hv + 16) * sizeof(int), stream));
     EHR_HIP(hipMemsetAsync(sacc0, 0, 2 * 16 * (size_t)Qc * sizeof(unsigned long long), stream));
     EHR_HIP(hipMemsetAsync(score, 0, (size_t)Q * sizeof(long long), stream));
