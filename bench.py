@@ -33,6 +33,20 @@ WORKLOAD = "xarm7_1280x720_8view"   # BASELINE configs[2]; --workload selects an
 VIEWS_PER_GPU = 8
 
 
+def csrc_sha16():
+    """First 16 hex digits of the SHA-256 over the kernel sources (easyhec_amd/csrc/*.hip, *.h, sorted by name): what the
+    committed counter files (profiles/counters.json, profiles/traffic.json) are keyed on, so that this script can say when
+    they describe other kernels than the ones it is timing (there is no .git on the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "easyhec_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes_per_frame(robot, H, W):
     """2*G + 16*P + 128*L  (geometry read fwd+bwd; per pixel: write mask, read ref, read both again)."""
     G = 12 * robot.num_verts + 12 * robot.num_tris
@@ -239,12 +253,10 @@ def drop_in_step(p, dev, steps=20):
         res[("fused_op_autograd" if fusedflag else "three_ops") + "_graph_ms_per_step"] = round(ms, 3)
         res[("fused_op_autograd" if fusedflag else "three_ops") + "_loss"] = round(float(tr.last_loss), 3)
         del tr, model
-    # SURVEY 8d's secondary byte count: the reference's traffic SHAPE through the three ops is 212-228 B per pixel of every
-    # (view, link) image (fwd + bwd); the rate below is that count over the measured step -- what the reference's own
-    # ops would have to sustain to match it, not bytes this library moves (it writes no rast_db, one colour channel, ...)
-    nbytes = 220.0 * p["n_views"] * len(p["robot"].meshes) * p["H"] * p["W"]
-    res["three_ops_reference_shape_bytes_per_step"] = int(nbytes)
-    res["three_ops_reference_shape_gbs"] = round(nbytes / (res["three_ops_graph_ms_per_step"] * 1e-3) / 1e9, 1)
+    # SURVEY 8d's secondary byte count: the REFERENCE's traffic shape through its three ops is 212-228 B per pixel of every
+    # (view, link) image (fwd + bwd).  A count for comparison only -- NOT bytes this library moves (its mirror writes no
+    # rast_db and one colour channel), so no rate is derived from it
+    res["reference_three_op_traffic_shape_bytes_per_step"] = int(220.0 * p["n_views"] * len(p["robot"].meshes) * p["H"] * p["W"])
     return res
 
 
@@ -273,21 +285,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    have_gpu = torch.cuda.is_available() and local_rank < torch.cuda.device_count()
-    dev = torch.device("cuda", local_rank) if have_gpu else None
+    # EHR_BENCH_DEVICE / EHR_BENCH_BACKEND: test-only (tests/test_gpu_launch.py runs this script with two ranks on ONE
+    # device over gloo, so that the N > 1 reporting code below has executed before the driver's multi-GPU run)
+    dev_index = int(os.environ.get("EHR_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("EHR_BENCH_BACKEND", "nccl")
+    have_gpu = torch.cuda.is_available() and dev_index < torch.cuda.device_count()
+    dev = torch.device("cuda", dev_index) if have_gpu else None
     if have_gpu:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev_index)
     if world > 1:
         # rendezvous first (127.0.0.1, env:// as the driver launches it): one process per GPU, RCCL ("nccl") over xGMI.
         # Without a device the group still forms (gloo) so that a mis-launch is reported by every rank, not as a hang.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if have_gpu:
+        if have_gpu and backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        elif have_gpu:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if not have_gpu:
         msg = (f"bench.py rank {rank}/{world}: no HIP device for LOCAL_RANK={local_rank} "
-               f"({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible) -- the process group formed, "
+               f"(device index {dev_index}, {torch.cuda.device_count() if torch.cuda.is_available() else 0} visible) -- the process group formed, "
                "but there is no CPU path to time (the render path is HIP only)")
         if world > 1:
             dist.barrier()
@@ -396,13 +414,16 @@ def main():
         # be read inside this run, so the figures come from profiles/traffic.json -- collected on the SAME launch form
         # this script times (ehr_solver_step, bound reference, no mask output; tools/gpu_traffic.sh) at the commit it names
         traffic, traffic_kernel, traffic_src = None, None, None
+        sha_now, stale = csrc_sha16(), False
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.workload == WORKLOAD:
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("hbm_bytes_whole_op")        # PMC-measured HBM bytes of ALL kernels of one step
                 traffic_kernel = tj.get("hbm_bytes_dominant_kernel")
-                traffic_src = {"file": "profiles/traffic.json", "commit": tj.get("commit"), "launch_form": tj.get("launch_form")}
+                traffic_src = {"file": "profiles/traffic.json", "commit": tj.get("commit"), "launch_form": tj.get("launch_form"),
+                               "csrc_sha16": tj.get("csrc_sha16")}
+                stale = stale or tj.get("csrc_sha16") != sha_now
             except Exception:
                 traffic = None
         # what binds the dominant kernel besides bandwidth (it is not HBM-bound at 8 views): VALU issue utilisation from the SQ
@@ -418,7 +439,9 @@ def main():
                             "spilled_vgprs": cj.get("resources", {}).get("spilled_vgprs"),
                             "vgprs": cj.get("resources", {}).get("vgprs"), "waves_per_simd": cj.get("resources", {}).get("waves_per_simd"),
                             "kernel_us_rocprof": cj.get("kernel_us_rocprof"),
-                            "counters_source": {"file": "profiles/counters.json", "commit": cj.get("commit")}}
+                            "counters_source": {"file": "profiles/counters.json", "commit": cj.get("commit"),
+                                                "csrc_sha16": cj.get("csrc_sha16")}}
+                stale = stale or cj.get("csrc_sha16") != sha_now
             except Exception:
                 counters = {}
         out = {
@@ -454,6 +477,14 @@ def main():
                          "traffic": traffic, "traffic_dominant_kernel": traffic_kernel, "traffic_source": traffic_src,
                          # real HBM rate of the whole step: counter bytes / driver-timed step (next to the algorithmic one)
                          "hbm_actual_step": round(traffic / (elapsed / args.steps) / 1e9, 2) if traffic else None,
+                         # ... and of the dominant kernel: counter bytes / its duration in THIS run / peak.  `frac` above is an
+                         # equivalent rate (algorithmic bytes the kernel does not move: no mask is written, the bound reference
+                         # is not re-read); this is the bandwidth the kernel really uses
+                         "frac_hbm_actual": round(traffic_kernel / (tile_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                         if traffic_kernel and tile_ms > 0 else None,
+                         # true when profiles/counters.json or traffic.json were collected on other kernel sources than the
+                         # ones in this tree (they name the SHA-256 of easyhec_amd/csrc they were collected on)
+                         "counters_stale": bool(stale), "csrc_sha16": sha_now,
                          "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": round(tile_ms, 5),
                          "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}},
         }

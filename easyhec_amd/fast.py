@@ -54,7 +54,11 @@ class FusedPoseStep:
         # the chain's stream between the solver step and Adam (default for the nccl backend, i.e. one process per GPU);
         # otherwise torch.distributed.all_reduce (gloo: the CPU tests, two ranks sharing one GPU).  rccl=True without a
         # process group makes a single-rank communicator (the same launch sequence on one GPU).
-        self.rccl = bool(rccl) if rccl is not None else (self.distributed and dist.get_backend(self.pg) == "nccl")
+        # (EHR_TRY_RCCL=1, test hook: attempt the library-owned exchange under any backend, so that the agreement / fall-back
+        #  branches below run where RCCL cannot come up -- two ranks on one device)
+        import os as _os
+        self.rccl = bool(rccl) if rccl is not None else (
+            self.distributed and (dist.get_backend(self.pg) == "nccl" or _os.environ.get("EHR_TRY_RCCL") == "1"))
         if self.rccl:
             ok, why = True, ""
             try:
@@ -111,6 +115,17 @@ class FusedPoseStep:
         # (ehr_fused_bind_ref; bit-identical results).  self.ref is this object's private copy, never written to.
         fused.bind_ref(self.glctx, self.scene, self.ref)
         self._graph = None
+        # A step the chain REPORTS (NaN loss: slot-limited plan overflowed / the view needs the general-triangle pass) leaves
+        # dof and Adam untouched, so nothing is lost but time -- unless nobody looks.  step() therefore looks itself, without
+        # ever waiting: every `check_every` steps the loss goes to pinned host memory behind an event, the copy that was
+        # started `check_every` steps earlier is inspected, and a NaN there triggers recover_from_overflow().  Callers that
+        # need an exact number of EFFECTIVE steps ask steps_done (Adam's own counter: it only advances on real steps).
+        self.check_every = 16
+        self._calls = 0
+        self._probe = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(1)
+        self._probe_ev = None
+        self.recoveries = []  # what recover_from_overflow() did, in order
+        self._calls0, self._steps0 = 0, 0  # step() calls / Adam steps at the last point both were known (mark_counts)
 
     def _init_comm(self):
         """ncclCommInitRank through the C ABI (``ehr_comm_*``): rank 0's ncclUniqueId travels over the process group that
@@ -185,7 +200,45 @@ class FusedPoseStep:
                 _lib.check(_lib.lib().ehr_graph_launch(self.glctx.handle, stream), "ehr_graph_launch")
             else:
                 self._enqueue(want_mask)
+            self._calls += 1
+            if self._calls % self.check_every == 0:
+                self._poll()
         return self.loss
+
+    def mark_counts(self):
+        """Remember how many step() calls and how many Adam steps there have been (synchronises): what recover_from_overflow
+        measures the reported -- i.e. not taken -- steps against.  Called wherever the Adam counter is set from outside."""
+        self._calls0, self._steps0 = self._calls, int(self.step_t.item())
+
+    def _rewind_history(self):
+        """The reported steps each wrote the (unchanged) pose to a new row of ``history_ops``: give those rows back, so that
+        the history holds one row per EFFECTIVE step (the space explorer samples camera poses from it)."""
+        lost = (self._calls - self._calls0) - (int(self.step_t.item()) - self._steps0)
+        if lost > 0:
+            hist = self.model.history_ops
+            row = int(self.hist_row.item())
+            lo = max(0, row - lost)
+            with torch.no_grad():
+                hist[lo:row].zero_()
+                self.hist_row.fill_(lo)
+            self.model._hist_n = None
+        self.mark_counts()
+        return max(lost, 0)
+
+    def _poll(self):
+        """Non-blocking look at the loss of the step taken `check_every` steps ago; starts the next look."""
+        if self._probe_ev is not None:
+            if not self._probe_ev.query():
+                return  # (still in flight: look again next time; never wait here)
+            self._probe_ev = None
+            v = float(self._probe[0])
+            if v != v:
+                what = self.recover_from_overflow()
+                if what:
+                    self.recoveries.append(what)
+        self._probe.copy_(self.loss, non_blocking=True)
+        self._probe_ev = torch.cuda.Event()
+        self._probe_ev.record()
 
     def capture(self):
         """Record the step's launch chain (5 kernels on one stream) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
@@ -221,6 +274,7 @@ class FusedPoseStep:
             rc = _lib.lib().ehr_fused_status(self.glctx.handle)
         if rc == 0:
             return False
+        self._rewind_history()
         had_graph = bool(self._graph)
         if rc == _lib.EHR_ERR_RETRY:
             # the step met triangles for the general-triangle pass, which the chain had not been launching: the context
@@ -266,3 +320,4 @@ class FusedPoseStep:
         self.exp_avg.copy_(torch.as_tensor(st["exp_avg"], dtype=torch.float32).reshape(6))
         self.exp_avg_sq.copy_(torch.as_tensor(st["exp_avg_sq"], dtype=torch.float32).reshape(6))
         self.step_t.fill_(int(round(float(torch.as_tensor(st["step"]).reshape(-1)[0]))))
+        self.mark_counts()

@@ -57,10 +57,13 @@ class OnlineCalibration:
             cfg.solver.max_lr = self.lr
             self.model = RBSolver(cfg, meshes=self.robot.meshes).to(self.device)
             trainer = RBSolverTrainer(cfg, self.model, self._batch(), fast=True)
-            loss = None
-            for _ in range(self.num_epochs):                              # do_fit (rbsolve_iter.py:139-155)
-                loss = trainer.step()[1]
+            # do_fit (rbsolve_iter.py:139-155): exactly num_epochs effective steps -- a step the chain reports instead of
+            # taking (a close-up view the slot-limited plan cannot hold) is recovered from and run again by fit()
+            trainer.fit(self.num_epochs)
+            loss = trainer.last_loss
             torch.cuda.synchronize(self.device)
+            if not np.isfinite(float(loss)):
+                raise RuntimeError(f"round {it}: the solve ended on a reported step (mask_loss NaN)")
             t1 = time.perf_counter()
             rec = {"round": it, "frames": len(self.qposes), "mask_loss": float(loss), "solve_s": t1 - t0}
             if it + 1 < self.explore_iters:                               # explore_next_state (rbsolve_iter.py:263-275)

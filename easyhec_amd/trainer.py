@@ -58,6 +58,7 @@ class RBSolverTrainer:
         self.pg = process_group
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.pg) > 1
         self.last_loss = None
+        self._reported = 0
         self.fast = None
         self._cuda_graph = None
         if graph and not fast:
@@ -84,6 +85,10 @@ class RBSolverTrainer:
         slower).  Single process only; the pose history cursor moves to the device (RBSolver._hist_dev)."""
         if self.distributed:
             raise RuntimeError("graph capture of the autograd step is single-process only")
+        if self.cfg.solver.do_grad_clip:
+            # (the eager step clips between backward() and step(); recording that needs the clip inside the capture, which
+            #  nobody has asked for: refuse rather than silently drop it -- the fast path refuses the same configuration)
+            raise ValueError("graph=True records the reference's default solver only (no gradient clipping)")
         m = self.model
         dev = m.dof.device
         if "gt_dof6" not in self.batch and "Tc_c2b" in self.batch:
@@ -132,8 +137,9 @@ class RBSolverTrainer:
             self._cuda_graph.replay()
             self.model._hist_n = None  # the device cursor moved; the host one is stale
             self.global_steps += 1
-            self.last_loss = self._static_loss
-            return {}, self._static_loss
+            # (a copy: the graph writes the same tensor again at the next replay, and callers collect losses lazily)
+            self.last_loss = self._static_loss.clone()
+            return {}, self.last_loss
         if self.fast is not None:
             # ONE optimiser state whatever is asked for: the launch chain also produces the rendered masks
             loss_value = self.fast.step(want_mask=with_outputs)[0]
@@ -188,30 +194,55 @@ class RBSolverTrainer:
         return out
 
     def fit(self, num_steps=None, log=None):
-        """Runs ``num_epochs`` steps (base.py:161 ``fit``); returns the list of logged (step, loss) pairs."""
+        """Runs ``num_epochs`` EFFECTIVE steps (base.py:161 ``fit``); returns the list of logged (step, loss) pairs.
+        A step the launch chain reports instead of taking (NaN loss; dof and Adam untouched: a slot-limited plan that
+        overflowed, a view that needs the general-triangle pass) does not count: the chain recovers by itself
+        (FusedPoseStep._poll, every few steps, or here at a logged step) and the lost iterations are run again, so the
+        solve takes exactly the steps it was asked for -- on every rank alike (Adam's step counter is replicated)."""
         n = self.cfg.solver.num_epochs if num_steps is None else num_steps
         history = []
         begin = time.time()
-        for it in range(n):
-            do_log = (it % self.cfg.solver.log_interval == 0) or it == n - 1
-            _, loss = self.step(with_outputs=False)
-            if do_log:
-                lv = float(loss)
-                if lv != lv and self.fast is not None:
-                    # the chain reports an internal overflow as NaN (and leaves dof / Adam state untouched): either the
-                    # slot-limited plan was too small -- planned again with every slot, the solve goes on -- or it says why
-                    what = self.fast.recover_from_overflow()
-                    if what:
-                        if log is not None:
-                            log(f"step {self.global_steps}: job slots overflowed; planned again with a slot per (view, link, tile)"
-                                if what == "job slots" else
-                                f"step {self.global_steps}: triangles at the near plane; the general-triangle pass joins the chain")
+        base_steps = self.global_steps
+        start = self.fast.steps_done if self.fast is not None else 0
+        remaining, rounds = n, 0
+        while remaining > 0:
+            for it in range(remaining):
+                last = it == remaining - 1
+                do_log = (self.global_steps % self.cfg.solver.log_interval == 0) or last
+                _, loss = self.step(with_outputs=False)
+                if do_log:
+                    lv = float(loss)
+                    if lv != lv and self.fast is not None:
+                        what = self.fast.recover_from_overflow()
+                        if what:
+                            self.fast.recoveries.append(what)
+                        else:
+                            from . import fused
+                            fused.check_status(self.fast.glctx)  # raises with the context's message
                         continue
+                    history.append((self.global_steps, lv))
+                    if log is not None:
+                        log(f"step {self.global_steps} mask_loss {lv:.4f} elapsed {time.time() - begin:.2f}s")
+            if self.fast is None:
+                break
+            done = self.fast.steps_done - start  # (synchronises: once per fit, twice if a step was reported)
+            if log is not None:
+                while self._reported < len(self.fast.recoveries):
+                    what = self.fast.recoveries[self._reported]
+                    self._reported += 1
+                    log("job slots overflowed; planned again with a slot per (view, link, tile)" if what == "job slots" else
+                        "triangles at the near plane; the general-triangle pass joins the chain")
+            self.global_steps = base_steps + done
+            remaining = n - done
+            if remaining > 0:
+                rounds += 1
+                if rounds > 4:
                     from . import fused
                     fused.check_status(self.fast.glctx)
-                history.append((self.global_steps, lv))
-                if log is not None:
-                    log(f"step {self.global_steps} mask_loss {lv:.4f} elapsed {time.time() - begin:.2f}s")
+                    raise RuntimeError(f"fit: {remaining} of {n} steps keep being reported as not taken (NaN loss)")
+                what = self.fast.recover_from_overflow()
+                if what:
+                    self.fast.recoveries.append(what)
         return history
 
     # checkpoint in the reference's layout: ckpt['model']['dof'] / ['history_ops'] (trainer/rbsolver.py:95-114)
@@ -239,6 +270,24 @@ class RBSolverTrainer:
             self.fast.exp_avg_sq.zero_()
             if "optimizer" in d:
                 self.fast.load_state_dict(d["optimizer"])
+            self.fast.mark_counts()
+        elif self._cuda_graph is not None:
+            # The captured graph updates the tensors it was recorded with: the restored state goes INTO them (a new state
+            # dict would leave the graph stepping the old moments, and save() writing tensors no replay touches), and the
+            # device-side history cursor moves to the restored history's first free row.
+            m = self.model
+            with torch.no_grad():
+                m._hist_dev.fill_(int(m.history_cursor()))
+                st = self.optimizer.state[m.dof]
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()  # no saved optimiser: a fresh Adam, like the reference's load_model path
+                saved = d.get("optimizer", {}).get("state", {})
+                if len(saved) > 0:
+                    first = saved[sorted(saved.keys())[0]]
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        st[k].copy_(torch.as_tensor(first[k], dtype=st[k].dtype).reshape(st[k].shape))
+                    st["step"].fill_(float(torch.as_tensor(first["step"]).reshape(-1)[0]))
         elif "optimizer" in d and len(d["optimizer"].get("state", {})) > 0:
             sd = d["optimizer"]
             first = sd["state"][sorted(sd["state"].keys())[0]]

@@ -527,14 +527,60 @@ def test_default_launch_chain_recovers_from_a_slot_overflow(env, xarm7, monkeypa
         else:
             assert tr.fast.slack == 1.0
         logs = []
-        hist = tr.fit(num_steps=6 if slack is None else 5, log=logs.append)
+        hist = tr.fit(num_steps=5, log=logs.append)   # five EFFECTIVE steps: the reported one is taken again
         if slack is None:
             assert any("job slots overflowed" in l for l in logs), logs  # the first step was the reported one
             assert tr.fast.slack == 0.0
         assert all(np.isfinite(l) for _, l in hist[-5:])
-        ends.append((model.dof.detach().clone(), tr.fast.step_t.clone()))
+        ends.append((model.dof.detach().clone(), tr.fast.step_t.clone(), model.history_ops[:8].clone(), tr.global_steps))
     assert int(ends[0][1]) == int(ends[1][1]) == 5            # five real Adam steps either way
+    assert ends[0][3] == ends[1][3] == 5
     assert torch.equal(ends[0][0], ends[1][0])                # ... to the same pose, bit for bit
+    assert torch.equal(ends[0][2], ends[1][2])                # ... through the same history: one row per effective step
+    assert float(ends[0][2][5:].abs().sum()) == 0.0
+
+
+def test_an_unattended_stepping_loop_recovers_by_itself(env, xarm7, monkeypatch):
+    """a caller that only ever calls trainer.step() -- never fit(), never looks at the loss --
+    must not be left on the initial pose by a reported step.  step() polls the loss every ``check_every`` steps without
+    waiting (pinned copy + event); a NaN there re-plans.  48 calls on the overflowing close-up: calls 1..32 are reported
+    (the poll at call 16 starts the look, the one at call 32 sees it), calls 33..48 are real steps -- and they equal the
+    first 16 steps of a solve that had every slot from the start, history rows included."""
+    fused, _, scene, dev = env
+    from easyhec_amd.config import Cfg
+    from easyhec_amd.rb_solver import RBSolver
+    from easyhec_amd.trainer import RBSolverTrainer
+    H, W, B = 64, 96, 2
+    K, lp, Tc, mvp = workload(xarm7, H, W, 0.075, B, seed=3)
+    K = np.array(K, dtype=np.float64)
+    K[:2, :2] *= 2.5
+    cfg = Cfg()
+    cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
+    cfg.model.rbsolver.init_Tc_c2b = np.asarray(Tc).tolist()
+    ref = torch.zeros((B, H, W), device=dev)
+    ref[:, 10:50, 20:70] = 1.0
+    batch = {"mask": ref, "link_poses": torch.tensor(lp, dtype=torch.float32, device=dev),
+             "K": torch.tensor(K, dtype=torch.float32, device=dev)[None].repeat(B, 1, 1)}
+    monkeypatch.setenv("EHR_VB_SLACK", "1.0")
+    model = RBSolver(cfg, meshes=xarm7.meshes).to(dev)
+    tr = RBSolverTrainer(cfg, model, batch, fast=True)
+    assert tr.fast.check_every == 16
+    for i in range(48):
+        tr.step()
+        if i in (15, 31):
+            torch.cuda.synchronize()   # (so that the look started at call 16 has certainly arrived by call 32)
+    torch.cuda.synchronize()
+    assert tr.fast.recoveries == ["job slots"] and tr.fast.slack == 0.0
+    assert tr.fast.steps_done == 16
+    monkeypatch.setenv("EHR_VB_SLACK", "0")
+    model2 = RBSolver(cfg, meshes=xarm7.meshes).to(dev)
+    tr2 = RBSolverTrainer(cfg, model2, batch, fast=True)
+    for _ in range(16):
+        tr2.step()
+    torch.cuda.synchronize()
+    assert torch.equal(model.dof.detach(), model2.dof.detach())
+    assert torch.equal(model.history_ops[:20], model2.history_ops[:20])
+    assert float(model.history_ops[16:20].abs().sum()) == 0.0
 
 
 def test_solver_step_switches_the_general_triangle_pass_on_when_a_step_needs_it(env, xarm7):

@@ -9,6 +9,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -45,3 +46,31 @@ def test_nccl_group_rccl_exchange_and_graph_at_world_size_one():
     assert r["bit_equal_to_plain_step"], r
     # the data-parallel form adds one 8-float all-reduce and one 6-thread Adam launch to the chain
     assert r["dp_ms_per_step"] <= 1.5 * r["plain_ms_per_step"], r
+
+
+@pytest.mark.parametrize("try_rccl", [False, True])
+def test_bench_with_two_ranks_on_one_device_over_gloo(try_rccl):
+    """bench.py's N > 1 code -- the rendezvous, the collective warm-up decision, the broadcast in
+    timed_blocks, per_rank_ms_per_step, allreduce_8float_us -- has to have run before the driver's multi-GPU bench does.
+    No second GPU here: two ranks share cuda:0 and exchange over gloo (EHR_BENCH_BACKEND / EHR_BENCH_DEVICE, test-only).
+    try_rccl: the library-owned RCCL exchange is ATTEMPTED (EHR_TRY_RCCL=1); two ranks on one device are refused by RCCL, so
+    this walks FusedPoseStep's agreement + fall-back branches (fast.py): both ranks must end up on torch.distributed."""
+    port = 31700 + (os.getpid() % 1000) + (50 if try_rccl else 0)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EHR_BENCH_BACKEND="gloo", EHR_BENCH_DEVICE="0")
+    if try_rccl:
+        env["EHR_TRY_RCCL"] = "1"
+    args = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "10", "--no-cpu-baseline"]
+    out = subprocess.run(args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]            # exactly one JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_views"] == 16 and r["config"]["views_per_gpu"] == 8
+    assert len(r["per_rank_ms_per_step"]) == 2 and all(0.0 < t < 50.0 for t in r["per_rank_ms_per_step"])
+    assert 0.0 < r["allreduce_8float_us"] < 1.0e5
+    assert r["value"] > 0 and r["scaling"] == "weak" and "torch.distributed" in r["config"]["parallelism"]
+    assert r["ms_per_step"] >= max(r["per_rank_ms_per_step"]) - 1e-6     # the job is as slow as its slowest rank
+    assert np.isfinite(r["config"]["final_mask_loss"])
+    if try_rccl:
+        assert "library-owned RCCL exchange unavailable" in out.stderr

@@ -49,3 +49,47 @@ def test_resume_in_a_new_process_continues_bit_for_bit(tmp_path, fast):
         assert np.abs(a["dof"] - b["dof"]).max() <= 1e-5
         assert np.abs(a["history"][:60] - b["history"][:60]).max() <= 1e-5
     assert (np.abs(b["history"][:60]).sum(axis=1) > 0).all() and (b["history"][60:] == 0).all()  # appended, not overwritten
+
+
+def test_resume_into_a_graph_captured_autograd_step(tmp_path):
+    """RBSolverTrainer(graph=True) without ``fast`` replays a torch.cuda.CUDAGraph that updates the Adam
+    tensors it was recorded with.  resume() must put the restored moments / step INTO those tensors and move the device-side
+    history cursor: 8 steps, save, (fresh trainer, graph=True) resume, 8 steps == 16 uninterrupted graph-replayed steps."""
+    import resume_worker as w
+    from easyhec_amd.robot import load_robot
+    from easyhec_amd.trainer import RBSolverTrainer
+    from test_gpu_fast import problem
+
+    def build():
+        cfg, make, batch = problem(load_robot("xarm7"), 2, 120, 160, 0.125)
+        cfg.model.rbsolver.use_fused = True   # (the fused op under autograd: few nodes, the same optimiser plumbing)
+        model = make()
+        return model, RBSolverTrainer(cfg, model, batch, graph=True)
+
+    model, tr = build()
+    for _ in range(16):
+        tr.step()
+    torch.cuda.synchronize()
+    full_dof, full_hist = model.dof.detach().cpu().clone(), model.history_ops[:20].cpu().clone()
+    model2, tr2 = build()
+    for _ in range(8):
+        tr2.step()
+    ckpt = str(tmp_path / "graph.pth")
+    tr2.save(ckpt)
+    model3, tr3 = build()
+    tr3.resume(ckpt)
+    st = tr3.optimizer.state[model3.dof]
+    assert float(st["step"]) == 8 and st["step"].is_cuda        # restored in place, still the capturable device tensor
+    for _ in range(8):
+        tr3.step()
+    torch.cuda.synchronize()
+    assert float(tr3.optimizer.state[model3.dof]["step"]) == 16
+    assert (model3.dof.detach().cpu() - full_dof).abs().max() <= 1e-6
+    hist = model3.history_ops[:20].cpu()
+    assert (hist[:16].abs().sum(dim=1) > 0).all() and (hist[16:] == 0).all()   # appended after the restored rows
+    assert (hist[:16] - full_hist[:16]).abs().max() <= 1e-6
+    # save() after a resume writes the tensors the graph steps
+    ckpt2 = str(tmp_path / "graph2.pth")
+    tr3.save(ckpt2)
+    d = torch.load(ckpt2, map_location="cpu", weights_only=False)
+    assert float(torch.as_tensor(d["optimizer"]["state"][0]["step"]).reshape(-1)[0]) == 16

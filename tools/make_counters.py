@@ -8,8 +8,11 @@ valu_util = SQ_INSTS_VALU x 4 cycles / (SIMDs x kernel cycles): a wave64 VALU in
 four cycles, the chip has 256 CUs x 4 SIMDs, kernel cycles = rocprofv3's mean duration x the 2.4 GHz engine clock."""
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KERNEL = "vb_job_kernel<false>"
 SIMDS, CLOCK_GHZ = 1024, 2.4
@@ -36,7 +39,8 @@ def main():
                                "scratch_bytes_per_lane": int(m.group(6)), "lds_bytes": int(m.group(7)), "waves_per_simd": int(m.group(8))}
     job = next((v for k, v in res.items() if k.startswith("vb_job_kernelILb0E")), {})
     cycles = dur * 1e-6 * CLOCK_GHZ * 1e9
-    out = {"commit": commit, "kernel": "vb_job_kernel<false>", "workload": "xarm7_1280x720_8view",
+    from bench import csrc_sha16
+    out = {"commit": commit, "csrc_sha16": csrc_sha16(), "kernel": "vb_job_kernel<false>", "workload": "xarm7_1280x720_8view",
            "kernel_us_rocprof": dur, "chain_kernels_us": chain, "chain_total_us": round(sum(chain.values()), 2),
            "SQ_INSTS_VALU": cnt.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": cnt.get("SQ_INSTS_SALU"), "SQ_INSTS_LDS": cnt.get("SQ_INSTS_LDS"),
            "SQ_ACTIVE_INST_ANY": cnt.get("SQ_ACTIVE_INST_ANY"), "SQ_WAVE_CYCLES": cnt.get("SQ_WAVE_CYCLES"), "SQ_WAVES": cnt.get("SQ_WAVES"),

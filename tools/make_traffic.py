@@ -42,12 +42,12 @@ def main():
     hbm = {k: int(round((2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024)) for k, v in kern.items()}
     B, H, W = 8, 720, 1280
     sys.path.insert(0, ROOT)
-    from bench import algorithmic_bytes_per_frame
+    from bench import algorithmic_bytes_per_frame, csrc_sha16
     from easyhec_amd.robot import load_robot
     rb = load_robot("xarm7")
     alg = algorithmic_bytes_per_frame(rb, H, W) * B
     G = 12 * rb.num_verts + 12 * rb.num_tris
-    out = {"round": 4, "commit": commit,
+    out = {"round": 5, "commit": commit, "csrc_sha16": csrc_sha16(),
            "launch_form": "ehr_solver_step, reference masks bound (ehr_fused_bind_ref), mask = NULL: what bench.py times",
            "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/step_bench.py ; the same with --pmc WRITE_SIZE "
                       "(separate passes, 8 views 1280x720 xArm7, mean of the last 100 launches of every kernel)",
