@@ -234,25 +234,32 @@ def drop_in_step(p, dev, steps=20):
     from easyhec_amd.trainer import RBSolverTrainer
     tr0 = p["trainer"]
     res = {}
-    for fusedflag in (False, True):
-        cfg = Cfg()
-        cfg.model.rbsolver.H, cfg.model.rbsolver.W = p["H"], p["W"]
-        cfg.model.rbsolver.init_Tc_c2b = p["Tc_init"].tolist()
-        cfg.model.rbsolver.use_fused = fusedflag
-        model = RBSolver(cfg, meshes=p["robot"].meshes).to(dev)
-        batch = {k: tr0.batch[k] for k in ("mask", "link_poses", "K")}
-        tr = RBSolverTrainer(cfg, model, batch, graph=True)
-        for _ in range(3):
-            tr.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        res[("fused_op_autograd" if fusedflag else "three_ops") + "_graph_ms_per_step"] = round(ms, 3)
-        res[("fused_op_autograd" if fusedflag else "three_ops") + "_loss"] = round(float(tr.last_loss), 3)
-        del tr, model
+    # three_ops: this repo's optimised mirror of the reference's schedule (renderer.NVDiffrastRenderer); import_swap_only: the
+    # reference's OWN renderer / solver statements with only the import swapped (renderer.ReferenceScheduleRenderer: three
+    # colour channels, rast_db written, nothing cached or batched) -- the number INTEGRATION.md section 2 promises
+    for name, fusedflag, refsched, graphs in (("three_ops", False, False, (True,)), ("fused_op_autograd", True, False, (True,)),
+                                              ("import_swap_only", False, True, (True, False))):
+        for graph in graphs:
+            cfg = Cfg()
+            cfg.model.rbsolver.H, cfg.model.rbsolver.W = p["H"], p["W"]
+            cfg.model.rbsolver.init_Tc_c2b = p["Tc_init"].tolist()
+            cfg.model.rbsolver.use_fused = fusedflag
+            cfg.model.rbsolver.reference_schedule = refsched
+            model = RBSolver(cfg, meshes=p["robot"].meshes).to(dev)
+            batch = {k: tr0.batch[k] for k in ("mask", "link_poses", "K")}
+            tr = RBSolverTrainer(cfg, model, batch, graph=graph)
+            n = steps if graph else max(3, steps // 4)
+            for _ in range(3):
+                tr.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                tr.step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / n * 1e3
+            res[f"{name}_{'graph' if graph else 'eager'}_ms_per_step"] = round(ms, 3)
+            res[f"{name}_loss"] = round(float(tr.last_loss), 3)
+            del tr, model
     # SURVEY 8d's secondary byte count: the REFERENCE's traffic shape through its three ops is 212-228 B per pixel of every
     # (view, link) image (fwd + bwd).  A count for comparison only -- NOT bytes this library moves (its mirror writes no
     # rast_db and one colour channel), so no rate is derived from it

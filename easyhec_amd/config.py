@@ -21,6 +21,12 @@ class RBSolverCfg:
     H: int = 720
     W: int = 1280
     use_fused: bool = True     # fused mask-loss kernel (default) or the three drop-in ops exactly as the reference
+    # use_fused=False only: issue EXACTLY the calls of the reference's own files (nvdiffrast_renderer.py:33-47 inside the loop
+    # of rb_solver.py:58-71) -- what a maintainer gets who swaps `import nvdiffrast.torch as dr` and changes nothing else:
+    # K_to_projection, ones(verts.shape) and transform_pos per call, three colour channels, rast_db written (grad_db default),
+    # rast not detached, no topology argument, one flip / stack / clamp per frame as written.  False = this repo's
+    # optimised mirror of the same schedule (renderer.NVDiffrastRenderer: cached constants, one channel, batched glue)
+    reference_schedule: bool = False
 
 
 @dataclass

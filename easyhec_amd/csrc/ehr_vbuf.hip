@@ -1844,6 +1844,9 @@ vb_job_kernel(VbJobParams prm_) {
             const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
             job = upre[u] + (ty - ty0) * nx + (tx - tx0);
             if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
+#ifdef VB_EXPERIMENT_SKIP_LONG
+            continue;  // timing experiment only (results wrong): what the kernel costs without its long single-wave jobs
+#endif
         } else {
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(0);

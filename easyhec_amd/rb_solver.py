@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import fused
 from .mesh_io import load_mesh
-from .renderer import NVDiffrastRenderer
+from .renderer import NVDiffrastRenderer, ReferenceScheduleRenderer
 from .se3 import se3_exp_map, se3_log_map
 
 __all__ = ["RBSolver"]
@@ -84,7 +84,8 @@ class RBSolver(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("RBSolver renders on a HIP device only: move the module with .cuda() first "
                                    "(there is no CPU render path)")
-            self.renderer = NVDiffrastRenderer([self.H, self.W], device=dev)
+            ref_sched = bool(getattr(self.cfg, "reference_schedule", False)) and not self.cfg.use_fused
+            self.renderer = (ReferenceScheduleRenderer if ref_sched else NVDiffrastRenderer)([self.H, self.W], device=dev)
             self._scene = None
         return self.renderer
 
@@ -124,6 +125,26 @@ class RBSolver(nn.Module):
             per_frame_loss.append(((composite - masks_ref[frame].float()) ** 2).sum())
         return torch.stack(per_frame_mask), torch.stack(per_frame_loss).mean()
 
+    def _forward_reference_schedule(self, renderer, Tc_c2b, link_poses, K, masks_ref):
+        """rb_solver.py:58-71 statement by statement (``cfg.model.rbsolver.reference_schedule``): per frame, per link
+        ``Tc_c2b @ link_poses[bid, link]`` and one ``render_mask`` call; stack / sum / clamp; SSE; mean over frames."""
+        losses = []
+        all_frame_all_link_si = []
+        batch_size = masks_ref.shape[0]
+        for bid in range(batch_size):
+            all_link_si = []
+            for link_idx in range(self.nlinks):
+                Tc_c2l = Tc_c2b @ link_poses[bid, link_idx]
+                verts, faces = getattr(self, f"vertices_{link_idx}"), getattr(self, f"faces_{link_idx}")
+                si = renderer.render_mask(verts, faces, K=K, object_pose=Tc_c2l)
+                all_link_si.append(si)
+            all_link_si = torch.stack(all_link_si).sum(0).clamp(max=1)
+            all_frame_all_link_si.append(all_link_si)
+            loss = torch.sum((all_link_si - masks_ref[bid].float()) ** 2)
+            losses.append(loss)
+        loss = torch.stack(losses).mean()
+        return torch.stack(all_frame_all_link_si), loss
+
     # -- forward -------------------------------------------------------------------------------------------------
     def forward(self, dps, with_outputs=True):
         assert dps.get("global_step", 0) == 0
@@ -151,6 +172,9 @@ class RBSolver(nn.Module):
                                                       want_mask=with_outputs)
             loss = losses.mean()
             all_frame_all_link_si = rendered if with_outputs else None
+        elif isinstance(renderer, ReferenceScheduleRenderer):
+            rendered, loss = self._forward_reference_schedule(renderer, Tc_c2b, link_poses, K, masks_ref)
+            all_frame_all_link_si = rendered
         else:
             rendered, loss = self._forward_three_ops(renderer, Tc_c2b, link_poses, K, masks_ref)
             all_frame_all_link_si = rendered

@@ -264,3 +264,39 @@ def test_graph_replay_of_the_three_op_step_equals_eager(xarm7):
     assert (ma.dof.detach() - mb.dof.detach()).abs().max() <= 1e-5
     assert mb.history_cursor() == 8 and ma.history_cursor() == 8
     assert (ma.history_ops[:8] - mb.history_ops[:8]).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_import_swap_only_schedule_equals_the_optimised_mirror(xarm7, graph):
+    """``reference_schedule=True`` issues the reference's own statements (nvdiffrast_renderer.py:33-47
+    inside rb_solver.py:58-71: K projection, ones[V,3] and transform_pos per call, rast_db written, rast undetached, no
+    topology argument, flip / stack / clamp per frame).  It must give what this repo's optimised mirror of the same schedule
+    gives -- same masks, same loss curve, same pose trajectory to float-reassociation noise (the gradient through the
+    barycentrics of an all-ones colour is exactly zero; the three channels are equal) -- eager and replayed from a graph."""
+    from easyhec_amd.renderer import NVDiffrastRenderer, ReferenceScheduleRenderer
+    from easyhec_amd.trainer import RBSolverTrainer
+    from test_gpu_fast import problem
+    cfg_a, make_a, batch = problem(xarm7, 2, 120, 160, 0.125)
+    cfg_a.model.rbsolver.use_fused = False
+    cfg_b, make_b, _ = problem(xarm7, 2, 120, 160, 0.125)
+    cfg_b.model.rbsolver.use_fused = False
+    cfg_b.model.rbsolver.reference_schedule = True
+    ma, mb = make_a(), make_b()
+    assert type(ma._ensure_renderer()) is NVDiffrastRenderer and type(mb._ensure_renderer()) is ReferenceScheduleRenderer
+    with torch.no_grad():
+        ra = ma(dict(batch, global_step=0))[0]["rendered_masks"]
+        rb = mb(dict(batch, global_step=0))[0]["rendered_masks"]
+    assert (ra - rb).abs().max() <= 1e-6 and float(ra.sum()) > 100.0
+    for m in (ma, mb):   # (the probing forwards recorded a pose each)
+        m.history_ops.zero_()
+        m._hist_n = None
+    ta = RBSolverTrainer(cfg_a, ma, batch)
+    tb = RBSolverTrainer(cfg_b, mb, batch, graph=graph)
+    la, lb = [], []
+    for _ in range(6):
+        la.append(float(ta.step()[1]))
+        lb.append(float(tb.step()[1]))
+    torch.cuda.synchronize()
+    assert np.allclose(la, lb, rtol=1e-4), (la, lb)
+    assert la[-1] < la[0]
+    assert (ma.dof.detach() - mb.dof.detach()).abs().max() <= 1e-5
