@@ -18,16 +18,17 @@ SIGNATURES = {
     "ehr_ctx_create": (c_int, [c_int, ctypes.POINTER(c_void_p)]),
     "ehr_ctx_destroy": (c_int, [c_void_p]),
     "ehr_ctx_scratch_bytes": (c_size_t, [c_void_p]),
+    "ehr_tile_flags_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ehr_rasterize_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                  c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p]),
     "ehr_rasterize_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                   c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_void_p]),
     "ehr_rasterize_grad_db": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                    c_void_p, c_void_p]),
     "ehr_interpolate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                    c_void_p, c_void_p]),
+                                    c_void_p, c_void_p, c_void_p]),
     "ehr_interpolate_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                     c_int, c_void_p, c_void_p, c_void_p]),
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ehr_interpolate_da_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p, c_void_p]),
     "ehr_interpolate_da_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 8 +
                                 [c_void_p, c_void_p, c_void_p]),
@@ -35,7 +36,7 @@ SIGNATURES = {
     "ehr_antialias_topology": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ehr_antialias_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ehr_antialias_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                  c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ehr_antialias_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ehr_fused_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,

@@ -331,6 +331,20 @@ __device__ __forceinline__ void aa_pos_grad(float4 p1, float4 p2, int px, int py
     g2[0] = gp2x; g2[1] = gp2y; g2[2] = gp2w;
 }
 
+// ---- tile flags of the drop-in ops ---------------------------------------------------------------------------------
+// dr.rasterize can hand its consumers one byte per (image, 32 x 8 pixel tile): non-zero iff some pixel of the tile holds a
+// triangle.  A robot link covers a few per cent of a 1280 x 720 frame, and dr.interpolate / dr.antialias / the backward
+// passes are full-image kernels per (view, link): with the flags they touch `rast` only where something was drawn and
+// write zeros (or copy the colour) elsewhere.  NULL = no flags: every tile counts as occupied.
+constexpr int EHR_FLAG_TW = 32, EHR_FLAG_TH = 8;
+__host__ __device__ __forceinline__ int flag_ntx(int W) { return (W + EHR_FLAG_TW - 1) / EHR_FLAG_TW; }
+__host__ __device__ __forceinline__ int flag_nty(int H) { return (H + EHR_FLAG_TH - 1) / EHR_FLAG_TH; }
+__device__ __forceinline__ bool tile_occupied(const unsigned char* __restrict__ flags, int b, int ix, int iy, int W, int H) {
+    if (!flags) return true;
+    const int ntx = flag_ntx(W), nty = flag_nty(H);
+    return flags[((size_t)b * nty + (iy / EHR_FLAG_TH)) * ntx + (ix / EHR_FLAG_TW)] != 0;
+}
+
 // ---- wave helpers ------------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ int lane_id() { return __lane_id(); }

@@ -19,13 +19,21 @@ namespace ehr {
 
 __global__ void __launch_bounds__(256) interp_fwd_kernel(const float* __restrict__ attr, const float4* __restrict__ rast,
                                                          const int32_t* __restrict__ tri, int B, int Ba, int V, int T,
-                                                         int A, size_t P, float* __restrict__ out) {
+                                                         int A, size_t P, float* __restrict__ out, int H, int W,
+                                                         const unsigned char* __restrict__ flags) {
     size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= P * B) return;
     int b = (int)(pix / P);
+    float* o = out + pix * A;
+    if (flags) {  // a tile nothing was drawn into: zeros, and `rast` is not read
+        const int rem = (int)(pix - (size_t)b * P), iy = rem / W, ix = rem - iy * W;
+        if (!tile_occupied(flags, b, ix, iy, W, H)) {
+            for (int k = 0; k < A; k++) o[k] = 0.f;
+            return;
+        }
+    }
     float4 r = rast[pix];
     int t = float_to_tri(r.w) - 1;
-    float* o = out + pix * A;
     bool ok = t >= 0 && t < T;
     int v0 = 0, v1 = 0, v2 = 0;
     if (ok) {
@@ -48,10 +56,18 @@ __global__ void __launch_bounds__(256) interp_fwd_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) interp_grad_kernel(const float* __restrict__ attr, const float4* __restrict__ rast,
                                                           const int32_t* __restrict__ tri, const float* __restrict__ dy,
                                                           int B, int Ba, int V, int T, int A, size_t P,
-                                                          float* __restrict__ grad_attr, float4* __restrict__ grad_rast) {
+                                                          float* __restrict__ grad_attr, float4* __restrict__ grad_rast, int H,
+                                                          int W, const unsigned char* __restrict__ flags) {
     size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= P * B) return;
     int b = (int)(pix / P);
+    if (flags) {  // a tile nothing was drawn into: no gradient, neither `rast` nor dy is read
+        const int rem = (int)(pix - (size_t)b * P), iy = rem / W, ix = rem - iy * W;
+        if (!tile_occupied(flags, b, ix, iy, W, H)) {
+            grad_rast[pix] = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+    }
     float4 r = rast[pix];
     int t = float_to_tri(r.w) - 1;
     float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -318,13 +334,14 @@ __device__ __forceinline__ AAHit aa_pair(const float4* __restrict__ rast, const 
 // Pairs across a tile border are analysed by both tiles.  Round 3 had three launches here (zero the list's counter,
 // discover the pairs + copy the colour, analyse and scatter with float atomics).
 constexpr int AA_TW = 32, AA_TH = 8;
+static_assert(AA_TW == EHR_FLAG_TW && AA_TH == EHR_FLAG_TH, "the tile flags of dr.rasterize are per antialias tile");
 constexpr int AA_MAXP = 2 * AA_TW * AA_TH + AA_TW + AA_TH;  // own pairs + the halo pairs of the first column and row
 
 __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
                                                      const float4* __restrict__ pos, const int32_t* __restrict__ tri,
                                                      const int32_t* __restrict__ opp, int range_mode, int B, int V, int T,
                                                      int H, int W, int C, int ntx, int nty, float* __restrict__ out,
-                                                     int4* __restrict__ work) {
+                                                     int4* __restrict__ work, const unsigned char* __restrict__ flags) {
     __shared__ int s_npair, s_count;
     __shared__ unsigned s_pair[AA_MAXP];   // px - tx0 + 1 (6 bits) | (py - ty0 + 1) << 6 (4 bits) | d << 10
     __shared__ float s_alpha[AA_MAXP];     // 0 = nothing lands anywhere
@@ -337,6 +354,21 @@ __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ c
     const size_t P = (size_t)H * W;
     const bool in = px < W && py < H;
     const size_t idx = (size_t)b * P + (size_t)py * W + px;
+    if (flags) {
+        // Pairs need two different triangle ids: a tile that holds no triangle, and none of whose four neighbours does,
+        // has no pair and is part of none (its first column / row looks at the left / lower tile, its last at the right /
+        // upper one).  Its pixels keep their colour; `rast` is not read.  (workgroup-uniform: five bytes)
+        const int ttx = tile % ntx, tty = tile / ntx;
+        const unsigned char* const f = flags + (size_t)b * ntx * nty;
+        const bool any = f[tile] | (ttx > 0 ? f[tile - 1] : 0) | (ttx + 1 < ntx ? f[tile + 1] : 0) |
+                         (tty > 0 ? f[tile - ntx] : 0) | (tty + 1 < nty ? f[tile + ntx] : 0);
+        if (!any) {
+            if (in)
+                for (int k = 0; k < C; k++) out[idx * C + k] = color[idx * C + k];
+            if (tid == 0) work[(size_t)blockIdx.x * AA_SEG] = make_int4(0, 0, 0, 0);
+            return;
+        }
+    }
     if (tid == 0) {
         s_npair = 0;
         s_count = 0;
@@ -475,26 +507,27 @@ using namespace ehr;
 extern "C" {
 
 int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int B, int Ba, int V, int T, int A,
-                        int H, int W, float* out, void* stream_) {
+                        int H, int W, float* out, const unsigned char* tile_flags, void* stream_) {
     if (!attr || !rast || !tri || !out) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: NULL tensor");
     if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: attr batch %d must be 1 or %d", Ba, B);
     size_t P = (size_t)H * W, n = P * B;
     if (n == 0) return EHR_OK;
     interp_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(attr, (const float4*)rast, tri, B, Ba,
-                                                                                  V, T, A, P, out);
+                                                                                  V, T, A, P, out, H, W, tile_flags);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }
 
 int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba, int V,
-                         int T, int A, int H, int W, float* grad_attr, float* grad_rast, void* stream_) {
+                         int T, int A, int H, int W, float* grad_attr, float* grad_rast, const unsigned char* tile_flags,
+                         void* stream_) {
     if (!attr || !rast || !tri || !dy || !grad_rast)
         return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: NULL tensor");
     if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: attr batch %d must be 1 or %d", Ba, B);
     size_t P = (size_t)H * W, n = P * B;
     if (n == 0) return EHR_OK;
     interp_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(
-        attr, (const float4*)rast, tri, dy, B, Ba, V, T, A, P, grad_attr, (float4*)grad_rast);
+        attr, (const float4*)rast, tri, dy, B, Ba, V, T, A, P, grad_attr, (float4*)grad_rast, H, W, tile_flags);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }
@@ -555,7 +588,8 @@ static size_t aa_segments(int B, int H, int W) {  // one per (image, 32 x 8 tile
 size_t ehr_antialias_work_bytes(int B, int H, int W) { return std::max<size_t>(aa_segments(B, H, W), 1) * AA_SEG * sizeof(int4); }
 
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
-                      int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work, void* stream_) {
+                      int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work,
+                      const unsigned char* tile_flags, void* stream_) {
     if (!color || !rast || !pos || !tri || !opp || !out || !work)
         return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: NULL tensor");
     if (out == color) return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: out must not alias color (every pixel reads its neighbours' colours)");
@@ -565,7 +599,7 @@ int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, c
     if (n == 0) return EHR_OK;
     aa_fwd_kernel<<<(unsigned)aa_segments(B, H, W), 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp,
                                                                       range_mode, B, V, T, H, W, C, (W + AA_TW - 1) / AA_TW,
-                                                                      (H + AA_TH - 1) / AA_TH, out, (int4*)work);
+                                                                      (H + AA_TH - 1) / AA_TH, out, (int4*)work, tile_flags);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

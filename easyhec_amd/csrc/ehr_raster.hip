@@ -323,17 +323,28 @@ __global__ void __launch_bounds__(256) raster_direct_kernel(ClipSource src, int 
     }
 }
 
+// One workgroup per (image, 32 x 8 tile) -- a row of the tile is 512 contiguous bytes of `rast` --, so that the tile's
+// flag (does any pixel hold a triangle?) is one __syncthreads_or and one byte store: nothing to initialise, no atomics.
 template <bool WITH_DB>
 __global__ void __launch_bounds__(256) raster_shade_kernel(ClipSource src, int B, int W, int H, u64* __restrict__ key,
-                                                           float4* __restrict__ rast, float4* __restrict__ rast_db) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, P = (size_t)W * H;
-    if (idx >= P * B) return;
-    const int b = (int)(idx / P);
-    const int rem = (int)(idx - (size_t)b * P);
-    const int iy = rem / W, ix = rem - iy * W;
-    const u64 k = key[idx];
-    if (k != ~0ull) key[idx] = ~0ull;  // re-armed for the next call: the key image is all ones between calls
-    shade_pixel<WITH_DB>(src, b, k, ix, iy, W, H, rast, rast_db);
+                                                           float4* __restrict__ rast, float4* __restrict__ rast_db,
+                                                           unsigned char* __restrict__ flags) {
+    const int ntx = flag_ntx(W), nty = flag_nty(H);
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const int ix = (tile % ntx) * EHR_FLAG_TW + (int)(threadIdx.x % EHR_FLAG_TW);
+    const int iy = (tile / ntx) * EHR_FLAG_TH + (int)(threadIdx.x / EHR_FLAG_TW);
+    bool drawn = false;
+    if (ix < W && iy < H) {
+        const size_t idx = ((size_t)b * H + iy) * W + ix;
+        const u64 k = key[idx];
+        drawn = k != ~0ull;
+        if (drawn) key[idx] = ~0ull;  // re-armed for the next call: the key image is all ones between calls
+        shade_pixel<WITH_DB>(src, b, k, ix, iy, W, H, rast, rast_db);
+    }
+    if (flags) {  // (kernel-uniform)
+        const int any = __syncthreads_or(drawn ? 1 : 0);
+        if (threadIdx.x == 0) flags[((size_t)b * nty) * ntx + tile] = any ? 1 : 0;
+    }
 }
 
 // ---- rasterize backward ------------------------------------------------------------------------------------------
@@ -341,13 +352,15 @@ __global__ void __launch_bounds__(256) raster_shade_kernel(ClipSource src, int B
 __global__ void __launch_bounds__(256) raster_grad_kernel(const float4* __restrict__ pos, const int32_t* __restrict__ tri,
                                                           const float4* __restrict__ rast,
                                                           const float4* __restrict__ dy, int range_mode, int B, int V,
-                                                          int T, int H, int W, float* __restrict__ grad_pos) {
+                                                          int T, int H, int W, float* __restrict__ grad_pos,
+                                                          const unsigned char* __restrict__ flags) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t P = (size_t)H * W;
     if (idx >= P * B) return;
     int b = (int)(idx / P);
     int rem = (int)(idx - (size_t)b * P);
     int iy = rem / W, ix = rem - iy * W;
+    if (!tile_occupied(flags, b, ix, iy, W, H)) return;  // nothing drawn in this tile: neither rast nor dy is read
     float4 r = rast[idx];
     int t = float_to_tri(r.w) - 1;
     if (t < 0 || t >= T) return;
@@ -470,7 +483,7 @@ using namespace ehr;
 
 extern "C" {
 
-int ehr_version(void) { return 5; }
+int ehr_version(void) { return 6; }
 
 const char* ehr_last_error(void) { return g_last_error.c_str(); }
 
@@ -559,8 +572,12 @@ size_t ehr_ctx_scratch_bytes(ehr_ctx* c) {
     return n;
 }
 
+size_t ehr_tile_flags_bytes(int B, int H, int W) {
+    return (((size_t)std::max(B, 0) * flag_ntx(std::max(W, 1)) * flag_nty(std::max(H, 1))) + 3) & ~(size_t)3;
+}
+
 int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
-                      int T, int H, int W, float* rast, float* rast_db, void* stream_) {
+                      int T, int H, int W, float* rast, float* rast_db, unsigned char* tile_flags, void* stream_) {
     if (!ctx) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: ctx is NULL");
     if (!pos || (!tri && T > 0) || !rast) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: NULL tensor");
     if (B <= 0 || V < 0 || T < 0 || H <= 0 || W <= 0) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: bad sizes");
@@ -632,16 +649,18 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
                 raster_direct_kernel<<<dim3(nbx, Z, B), 256, 0, stream>>>(src, W, H, band_rows, key);
                 EHR_LAUNCH_CHECK();
             }
-            const unsigned sgrid = (unsigned)((npix + 255) / 256);
+            const dim3 sgrid((unsigned)(flag_ntx(W) * flag_nty(H)), (unsigned)B);
             if (rast_db)
-                raster_shade_kernel<true><<<sgrid, 256, 0, stream>>>(src, B, W, H, key, (float4*)rast, (float4*)rast_db);
+                raster_shade_kernel<true><<<sgrid, 256, 0, stream>>>(src, B, W, H, key, (float4*)rast, (float4*)rast_db, tile_flags);
             else
-                raster_shade_kernel<false><<<sgrid, 256, 0, stream>>>(src, B, W, H, key, (float4*)rast, nullptr);
+                raster_shade_kernel<false><<<sgrid, 256, 0, stream>>>(src, B, W, H, key, (float4*)rast, nullptr, tile_flags);
             EHR_LAUNCH_CHECK();
             ctx->rkeys_clean = ctx->rkeys.moves;
             return EHR_OK;
         }
     }
+    // (the queued form does not work out which tiles it drew into: every tile counts as occupied)
+    if (tile_flags && (rc = fill_words(tile_flags, ehr_tile_flags_bytes(B, H, W) / sizeof(unsigned), 0x01010101u, stream))) return rc;
     // counts | cursors | meta are all zero between calls (raster_tile_kernel, the last kernel below, zeroes what a call
     // dirtied); only a fresh or moved buffer, or one a failed call left behind, is cleared here.
     if (ctx->counts_clean != ctx->counts.moves) {
@@ -714,14 +733,14 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
 }
 
 int ehr_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, const float* dy, int range_mode, int B,
-                       int V, int T, int H, int W, float* grad_pos, void* stream_) {
+                       int V, int T, int H, int W, float* grad_pos, const unsigned char* tile_flags, void* stream_) {
     if (!pos || !tri || !rast || !dy || !grad_pos) return fail(EHR_ERR_INVALID, "ehr_rasterize_grad: NULL tensor");
     hipStream_t stream = (hipStream_t)stream_;
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
     raster_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>((const float4*)pos, tri, (const float4*)rast,
                                                                         (const float4*)dy, range_mode, B, V, T, H, W,
-                                                                        grad_pos);
+                                                                        grad_pos, tile_flags);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

@@ -19,7 +19,7 @@ import torch
 from . import _lib
 
 __all__ = ["RasterizeCudaContext", "RasterizeGLContext", "rasterize", "interpolate", "antialias",
-           "antialias_construct_topology_hash", "TopologyHash"]
+           "antialias_construct_topology_hash", "TopologyHash", "carry_tile_flags"]
 
 
 def _stream():
@@ -29,6 +29,32 @@ def _stream():
 def _require(cond, msg):
     if not cond:
         raise RuntimeError(msg)
+
+
+# Tile flags (ABI 6): dr.rasterize leaves one byte per (image, 32 x 8 tile) -- "a triangle was drawn here" -- in a small
+# tensor that rides on the `rast` tensor object it returns (a Python attribute: it follows the object through
+# .contiguous() of a contiguous tensor, not through views or detach()).  dr.interpolate / dr.antialias and the backward
+# passes look for it on the `rast` they are handed and skip the empty nine tenths of a link's image; without it (a `rast`
+# that came from somewhere else) they process every pixel, as before.  The results are identical either way.
+_FLAGS_ATTR = "_ehr_tile_flags"
+
+
+def _flags_of(rast):
+    f = getattr(rast, _FLAGS_ATTR, None)
+    if f is None:
+        return None
+    B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
+    ok = f.is_cuda and f.device == rast.device and f.numel() == _lib.lib().ehr_tile_flags_bytes(B, H, W)
+    return f if ok else None
+
+
+def carry_tile_flags(src, dst):
+    """Hand ``src``'s tile flags (if any) on to ``dst`` -- a detached or otherwise re-wrapped tensor over the SAME rasterizer
+    output -- and return ``dst``."""
+    f = getattr(src, _FLAGS_ATTR, None)
+    if f is not None and dst.shape[:3] == src.shape[:3]:
+        setattr(dst, _FLAGS_ATTR, f)
+    return dst
 
 
 def _check_dev(name, t, dtype):
@@ -78,7 +104,7 @@ RasterizeGLContext = RasterizeCudaContext
 
 class _RasterizeFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, glctx, pos, tri, resolution, ranges, grad_db):
+    def forward(ctx, glctx, pos, tri, resolution, ranges, grad_db, flags):
         H, W = int(resolution[0]), int(resolution[1])
         if ranges is None:
             B, V = pos.shape[0], pos.shape[1]
@@ -92,10 +118,11 @@ class _RasterizeFunc(torch.autograd.Function):
         db = torch.empty((B, H, W, 4), dtype=torch.float32, device=pos.device) if grad_db else None
         with torch.cuda.device(pos.device):
             _lib.check(_lib.lib().ehr_rasterize_fwd(glctx.handle, _lib.ptr(pos), _lib.ptr(tri), rptr, B, V, T, H, W,
-                                                    _lib.ptr(rast), _lib.ptr(db), _stream()), "rasterize")
+                                                    _lib.ptr(rast), _lib.ptr(db), _lib.ptr(flags), _stream()), "rasterize")
         if db is None:
             db = torch.empty((B, H, W, 0), dtype=torch.float32, device=pos.device)
         ctx.save_for_backward(pos, tri, rast)
+        ctx.flags = flags
         ctx.range_mode = ranges is not None
         if not grad_db:
             ctx.mark_non_differentiable(db)
@@ -107,7 +134,7 @@ class _RasterizeFunc(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, ddb):
         if dy is None and ddb is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         pos, tri, rast = ctx.saved_tensors
         B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
         V, T = pos.shape[-2], tri.shape[0]
@@ -116,14 +143,14 @@ class _RasterizeFunc(torch.autograd.Function):
             if dy is not None:   # through (u, v)
                 dy = dy.contiguous()
                 _lib.check(_lib.lib().ehr_rasterize_grad(_lib.ptr(pos), _lib.ptr(tri), _lib.ptr(rast), _lib.ptr(dy),
-                                                         int(ctx.range_mode), B, V, T, H, W, _lib.ptr(g), _stream()),
-                           "rasterize backward")
+                                                         int(ctx.range_mode), B, V, T, H, W, _lib.ptr(g),
+                                                         _lib.ptr(ctx.flags), _stream()), "rasterize backward")
             if ddb is not None:  # through the pixel differentials of (u, v) (nobody on EasyHeC's path asks for this)
                 ddb = ddb.contiguous()
                 _lib.check(_lib.lib().ehr_rasterize_grad_db(_lib.ptr(pos), _lib.ptr(tri), _lib.ptr(rast), _lib.ptr(ddb),
                                                             int(ctx.range_mode), B, V, T, H, W, _lib.ptr(g), _stream()),
                            "rasterize backward (rast_db)")
-        return None, g, None, None, None, None
+        return None, g, None, None, None, None, None
 
 
 def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
@@ -147,19 +174,26 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
         _require(isinstance(ranges, torch.Tensor) and not ranges.is_cuda and ranges.dtype == torch.int32 and
                  ranges.dim() == 2 and ranges.shape[1] == 2,
                  "range mode - ranges must be a CPU int32 tensor with shape [>0, 2]")
-    return _RasterizeFunc.apply(glctx, pos.contiguous(), tri.contiguous(), resolution, ranges, bool(grad_db))
+    B = pos.shape[0] if ranges is None else ranges.shape[0]
+    flags = torch.empty((_lib.lib().ehr_tile_flags_bytes(B, int(resolution[0]), int(resolution[1])),), dtype=torch.uint8,
+                        device=pos.device)
+    rast, db = _RasterizeFunc.apply(glctx, pos.contiguous(), tri.contiguous(), resolution, ranges, bool(grad_db), flags)
+    setattr(rast, _FLAGS_ATTR, flags)
+    return rast, db
 
 
 class _InterpolateFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, attr, rast, tri):
+    def forward(ctx, attr, rast, tri, flags):
         B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
         Ba, V, A = attr.shape
         out = torch.empty((B, H, W, A), dtype=torch.float32, device=rast.device)
         with torch.cuda.device(rast.device):
             _lib.check(_lib.lib().ehr_interpolate_fwd(_lib.ptr(attr), _lib.ptr(rast), _lib.ptr(tri), B, Ba, V,
-                                                      tri.shape[0], A, H, W, _lib.ptr(out), _stream()), "interpolate")
+                                                      tri.shape[0], A, H, W, _lib.ptr(out), _lib.ptr(flags), _stream()),
+                       "interpolate")
         ctx.save_for_backward(attr, rast, tri)
+        ctx.flags = flags
         return out
 
     @staticmethod
@@ -175,8 +209,8 @@ class _InterpolateFunc(torch.autograd.Function):
         with torch.cuda.device(rast.device):
             _lib.check(_lib.lib().ehr_interpolate_grad(_lib.ptr(attr), _lib.ptr(rast), _lib.ptr(tri), _lib.ptr(dy), B,
                                                        Ba, V, tri.shape[0], A, H, W, _lib.ptr(g_attr),
-                                                       _lib.ptr(g_rast), _stream()), "interpolate backward")
-        return g_attr, g_rast, None
+                                                       _lib.ptr(g_rast), _lib.ptr(ctx.flags), _stream()), "interpolate backward")
+        return g_attr, g_rast, None, None
 
 
 class _InterpolateDaFunc(torch.autograd.Function):
@@ -227,8 +261,9 @@ def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
         attr = attr[None]
     _require(attr.dim() == 3, "attr must have shape [>0, >0, >0] or [>0, >0]")
     _require(attr.shape[0] in (1, rast.shape[0]), "attr batch must be 1 or match rast")
+    flags = _flags_of(rast)
     attr, rast, tri = attr.contiguous(), rast.contiguous(), tri.contiguous()
-    out = _InterpolateFunc.apply(attr, rast, tri)
+    out = _InterpolateFunc.apply(attr, rast, tri, flags)
     if diff_attrs is None:
         return out, torch.empty((out.shape[0], out.shape[1], out.shape[2], 0), dtype=torch.float32, device=out.device)
     _require(rast_db is not None, "interpolate: diff_attrs needs rast_db (the second output of rasterize)")
@@ -275,7 +310,7 @@ def antialias_construct_topology_hash(tri):
 
 class _AntialiasFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color, rast, pos, tri, opp, boost):
+    def forward(ctx, color, rast, pos, tri, opp, boost, flags):
         B, H, W, C = color.shape
         V, T = pos.shape[-2], tri.shape[0]
         range_mode = int(pos.dim() == 2)
@@ -285,7 +320,7 @@ class _AntialiasFunc(torch.autograd.Function):
         with torch.cuda.device(color.device):
             _lib.check(lib.ehr_antialias_fwd(_lib.ptr(color), _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri),
                                              _lib.ptr(opp), range_mode, B, V, T, H, W, C, _lib.ptr(out),
-                                             _lib.ptr(work), _stream()), "antialias")
+                                             _lib.ptr(work), _lib.ptr(flags), _stream()), "antialias")
         ctx.save_for_backward(color, rast, pos, tri, work)
         ctx.boost = float(boost)
         return out
@@ -308,7 +343,7 @@ class _AntialiasFunc(torch.autograd.Function):
                        "antialias backward")
         if ctx.boost != 1.0:
             g_pos = g_pos * ctx.boost
-        return g_color, None, g_pos, None, None, None
+        return g_color, None, g_pos, None, None, None, None
 
 
 def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
@@ -340,4 +375,4 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
     _require(isinstance(topology_hash, TopologyHash) and topology_hash.num_triangles == tri.shape[0],
              "topology_hash does not belong to tri")
     return _AntialiasFunc.apply(color.contiguous(), rast.contiguous(), pos.contiguous(), tri, topology_hash.opp,
-                                pos_gradient_boost)
+                                pos_gradient_boost, _flags_of(rast))

@@ -105,7 +105,7 @@ class NVDiffrastRenderer:
             # (the colour is the same at every vertex, so it does not depend on the barycentrics: the gradient that would
             #  flow back through rast_out into pos_clip is exactly zero -- every term is dy * (1 - 1) -- and detaching saves
             #  two full-image backward kernels per (frame, link); the silhouette gradient comes from dr.antialias)
-            color, _ = dr.interpolate(vtx_color, rast_out.detach(), faces)
+            color, _ = dr.interpolate(vtx_color, dr.carry_tile_flags(rast_out, rast_out.detach()), faces)
             color = dr.antialias(color, rast_out, pos_clip, faces, topology_hash=self._topology(faces))
             mask = color.view(color.shape[1], color.shape[2])  # [1, H, W, 1]: a view both ways (indexing = fill + copy in backward)
         else:

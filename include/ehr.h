@@ -37,7 +37,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 5 (2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*, ehr_rasterize_grad_db) */
+int ehr_version(void);                 /* ABI version, currently 6 (6: tile flags -- ehr_tile_flags_bytes, a tile_flags argument on ehr_rasterize_fwd / _grad, ehr_interpolate_fwd / _grad, ehr_antialias_fwd; 2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*, ehr_rasterize_grad_db) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
@@ -59,13 +59,18 @@ size_t ehr_ctx_scratch_bytes(ehr_ctx* ctx);
  * asynchronously and is looked at by the next call, and a frame that outgrows the storage is still rendered exactly (the
  * tiles whose queues did not fit find their triangles themselves; slower, never incomplete) before the storage grows.
  * Neither form enqueues a fill: the context's counters / key image are left clean by the call's last kernel. */
+/* tile_flags (optional, NULL = not wanted): ehr_tile_flags_bytes(B, H, W) bytes, one per (image, 32 x 8 pixel tile, row-major,
+ * ceil(W / 32) per row), set to non-zero iff some pixel of the tile holds a triangle (the queued form sets them all).  The
+ * ops below that take `tile_flags` leave `rast` unread where the flag is zero: a robot link covers a few per cent of a
+ * frame, and the reference's schedule is five full-image passes per (view, link).  Passing NULL there is always valid. */
+size_t ehr_tile_flags_bytes(int B, int H, int W);
 int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const int32_t* ranges_host, int B, int V,
-                      int T, int H, int W, float* rast, float* rast_db, void* stream);
+                      int T, int H, int W, float* rast, float* rast_db, unsigned char* tile_flags, void* stream);
 
 /* backward of dr.rasterize w.r.t. pos through (u,v); dy = grad of rast [B,H,W,4] (z/w and id carry no gradient).
  * grad_pos (pos's shape) is ACCUMULATED into: the caller zero-fills it. */
 int ehr_rasterize_grad(const float* pos, const int32_t* tri, const float* rast, const float* dy, int range_mode, int B,
-                       int V, int T, int H, int W, float* grad_pos, void* stream);
+                       int V, int T, int H, int W, float* grad_pos, const unsigned char* tile_flags, void* stream);
 /* ... and w.r.t. pos through rast_db: ddb = grad of rast_db [B,H,W,4]; grad_pos is ACCUMULATED into.  (EasyHeC discards
  * rast_db, nvdiffrast_renderer.py:39; this completes the op.) */
 int ehr_rasterize_grad_db(const float* pos, const int32_t* tri, const float* rast, const float* ddb, int range_mode, int B,
@@ -73,11 +78,12 @@ int ehr_rasterize_grad_db(const float* pos, const int32_t* tri, const float* ras
 
 /* replaces dr.interpolate -- nvdiffrast_renderer.py:42.  attr [Ba,V,A] with Ba == B or 1; out [B,H,W,A]. */
 int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri, int B, int Ba, int V, int T, int A,
-                        int H, int W, float* out, void* stream);
+                        int H, int W, float* out, const unsigned char* tile_flags, void* stream);
 /* grad_attr [Ba,V,A] is ACCUMULATED into (caller zero-fills) and may be NULL when the attributes need no gradient
  * (EasyHeC interpolates constant colours); grad_rast [B,H,W,4] is overwritten. */
 int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tri, const float* dy, int B, int Ba, int V,
-                         int T, int A, int H, int W, float* grad_attr, float* grad_rast, void* stream);
+                         int T, int A, int H, int W, float* grad_attr, float* grad_rast, const unsigned char* tile_flags,
+                         void* stream);
 
 /* dr.interpolate's second output, the attribute pixel differentials (interpolate(attr, rast, tri, rast_db, diff_attrs);
  * EasyHeC does not ask for them -- nvdiffrast_renderer.py:42 passes neither -- they complete the op's signature).
@@ -104,7 +110,8 @@ int ehr_antialias_topology(const int32_t* tri, int T, int32_t* opp, void* scratc
  * deterministic: every pixel adds the blends that land on it in the order of a serial sweep over pixel pairs. */
 size_t ehr_antialias_work_bytes(int B, int H, int W);
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
-                      int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work, void* stream);
+                      int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work,
+                      const unsigned char* tile_flags, void* stream);
 /* grad_color [B,H,W,C] is overwritten (may be NULL: not wanted); grad_pos (pos's shape) is ACCUMULATED into (caller zero-fills). */
 int ehr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
                        const void* work, int range_mode, int B, int V, int T, int H, int W, int C, float* grad_color,

@@ -45,7 +45,7 @@ def main():
             db = torch.empty((1, H, W, 4), dtype=torch.float32, device=dev)
             fn, st = _lib.lib().ehr_rasterize_fwd, torch.cuda.current_stream().cuda_stream
             args = (ctx.handle, _lib.ptr(pos), _lib.ptr(faces), None, 1, int(verts.shape[0]), int(faces.shape[0]), H, W,
-                    _lib.ptr(out), _lib.ptr(db) if a.db else None, ctypes.c_void_p(st))
+                    _lib.ptr(out), _lib.ptr(db) if a.db else None, None, ctypes.c_void_p(st))
             for _ in range(10):
                 _lib.check(fn(*args), "rasterize")
             torch.cuda.synchronize()

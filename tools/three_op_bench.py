@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--graph", action="store_true", help="record the autograd step in a torch.cuda.CUDAGraph and replay it "
                     "(RBSolverTrainer(graph=True)): the ~1 500 launches of the three-op step at GPU speed")
+    ap.add_argument("--only", default="", help="one of three_ops / import_swap_only / fused_autograd (profiling runs)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     wl = WORKLOADS["xarm7_1280x720_8view"]
@@ -34,6 +35,9 @@ def main():
     Tc = camera_Tc_c2b(radius=wl["radius"], lift=wl["lift"])
     out = {}
     for fusedflag, refsched in ((False, False), (False, True), (True, False)):
+        name = "fused_autograd" if fusedflag else ("import_swap_only" if refsched else "three_ops")
+        if a.only and a.only != name:
+            continue
         cfg = Cfg()
         cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
         cfg.model.rbsolver.init_Tc_c2b = perturb_pose(Tc).tolist()
