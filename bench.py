@@ -258,7 +258,8 @@ def drop_in_step(p, dev, steps=20):
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / n * 1e3
             res[f"{name}_{'graph' if graph else 'eager'}_ms_per_step"] = round(ms, 3)
-            res[f"{name}_loss"] = round(float(tr.last_loss), 3)
+            if graph:  # (3 + `steps` iterations from the same start for every variant: the losses are comparable)
+                res[f"{name}_loss"] = round(float(tr.last_loss), 3)
             del tr, model
     # SURVEY 8d's secondary byte count: the REFERENCE's traffic shape through its three ops is 212-228 B per pixel of every
     # (view, link) image (fwd + bwd).  A count for comparison only -- NOT bytes this library moves (its mirror writes no
