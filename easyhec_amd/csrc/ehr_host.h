@@ -37,6 +37,10 @@ struct Scratch {
     int reserve(size_t bytes);  // may hipFree + hipMalloc (synchronises); never called on the fused hot path
     void release();
     unsigned long long moves = 0;  // bumped whenever this buffer moves: captured graphs hold raw pointers
+    // set once a call that used this buffer was recorded into somebody else's stream capture (torch.cuda.graphs): the graph
+    // holds the raw pointer, so the buffer must never move again -- a reserve() that would have to grow it fails loudly
+    // instead of leaving the graph's replays writing into freed memory
+    bool pinned = false;
 };
 
 // Device fills / copies of the drop-in ops as plain kernels (ehr_raster.hip): a hipMemsetAsync / hipMemcpyAsync recorded

@@ -25,6 +25,10 @@ int fail(int code, const char* fmt, ...) {
 
 int Scratch::reserve(size_t bytes) {
     if (bytes <= cap) return EHR_OK;
+    if (pinned && ptr)
+        return fail(EHR_ERR_INVALID, "this context's rasterizer scratch (%zu bytes) is referenced by a captured graph and cannot grow "
+                    "to %zu bytes: render other shapes through a RasterizeCudaContext of their own (or capture again on a fresh one)",
+                    cap, bytes);
     moves++;
     if (ptr) {
         EHR_HIP(hipDeviceSynchronize());
@@ -583,6 +587,12 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     if (B <= 0 || V < 0 || T < 0 || H <= 0 || W <= 0) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: bad sizes");
     if (H > 32768 || W > 32768) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: resolution above 32768 is unsupported");
     hipStream_t stream = (hipStream_t)stream_;
+    {   // a call recorded into a stream capture bakes the scratch pointers into the graph: from then on they stay where they are
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cs);
+        if (cs != hipStreamCaptureStatusNone)
+            for (Scratch* sc : {&ctx->counts, &ctx->offsets, &ctx->entries, &ctx->rkeys, &ctx->ranges}) sc->pinned = true;
+    }
     BinGeom g;
     g.W = W;
     g.H = H;

@@ -342,3 +342,78 @@ def test_renderer_wrapper_matches_reference_semantics(env, oracle, xarm7):
     assert np.abs(m.cpu().numpy() - exp).max() <= 5e-7
     hard = ren.render_mask(tv, tf, torch.tensor(K, dtype=torch.float32, device=dev), pose, anti_aliasing=False)
     assert hard.dtype == torch.bool and (hard.cpu().numpy() == (rast[0, ::-1, :, 2] > 0)).all()
+
+
+def test_tile_flags_follow_the_rasterizer_and_change_no_result(env, oracle):
+    """ABI 6: dr.rasterize attaches one byte per (image, 32 x 8 tile) to the `rast` it returns -- non-zero iff a pixel of the tile
+    holds a triangle (direct form; the queued form sets them all) -- and dr.interpolate / dr.antialias / the backward passes skip
+    `rast` where it is zero.  The results with the flags equal the results without them (a `rast` whose attribute was removed), bit
+    for bit where the kernels gather, within the atomics' tolerance for the position gradient."""
+    dr, _, dev = env
+    ctx = dr.RasterizeCudaContext()
+    H, W = 200, 360
+    rng = np.random.default_rng(77)
+    pos, tri = helpers.random_mesh(rng, 300, shared=True, size=0.12)   # a small object: most tiles stay empty
+    pos[:, 0] = pos[:, 0] * 0.35 + 0.4 * pos[:, 3]
+    pos[:, 1] = pos[:, 1] * 0.35 - 0.3 * pos[:, 3]
+    tt = t(tri, dev)
+    attr = t(rng.uniform(0, 1, size=(1, pos.shape[0], 3)).astype(np.float32), dev)
+    outs = []
+    for with_flags in (True, False):
+        tp = t(pos[None], dev, True)
+        r, _ = dr.rasterize(ctx, tp, tt, [H, W])
+        flags = getattr(r, "_ehr_tile_flags", None)
+        assert flags is not None and flags.dtype == torch.uint8
+        if with_flags:
+            ntx, nty = (W + 31) // 32, (H + 7) // 8
+            f = flags[: ntx * nty].cpu().numpy().reshape(nty, ntx) != 0
+            ids = r.detach().cpu().numpy()[0, :, :, 3]
+            want = np.zeros((nty, ntx), dtype=bool)
+            for ty in range(nty):
+                for tx in range(ntx):
+                    want[ty, tx] = (ids[ty * 8:(ty + 1) * 8, tx * 32:(tx + 1) * 32] != 0).any()
+            assert (f == want).all() and 0 < want.sum() < want.size // 2
+            rr = r
+        else:
+            assert getattr(r.detach(), "_ehr_tile_flags", None) is None   # (a re-wrapped tensor carries none ...)
+            delattr(r, "_ehr_tile_flags")                                  # ... and this one shall not either
+            rr = r
+        c, _ = dr.interpolate(attr, rr, tt)
+        a = dr.antialias(c, rr, tp, tt)
+        (a * a).sum().backward()
+        outs.append((c.detach().clone(), a.detach().clone(), tp.grad.detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    g0, g1 = outs[0][2], outs[1][2]
+    assert float((g0 - g1).abs().max()) <= 1e-5 * max(1.0, float(g1.abs().max())) and float(g1.abs().max()) > 0
+    c_ref = oracle.interpolate(attr.cpu().numpy(), oracle.rasterize(pos[None], tri, [H, W])[0], tri)
+    assert (outs[0][0].cpu().numpy() == c_ref).all()
+
+
+def test_a_context_whose_calls_were_captured_refuses_to_move_its_scratch():
+    """a torch.cuda.CUDAGraph that recorded dr.rasterize holds the context's scratch pointers.  A later call
+    that would have to GROW that scratch must fail loudly instead of freeing what the graph's replays write into."""
+    from easyhec_amd import dr
+    dev = torch.device("cuda:0")
+    ctx = dr.RasterizeCudaContext()
+    rng = np.random.default_rng(5)
+    pos, tri = helpers.random_mesh(rng, 200, shared=True, size=0.3)
+    tp, tt = t(pos[None], dev), t(tri, dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            dr.rasterize(ctx, tp, tt, [64, 96], grad_db=False)   # warm-up: sizes the scratch
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        r, _ = dr.rasterize(ctx, tp, tt, [64, 96], grad_db=False)
+    g.replay()
+    torch.cuda.synchronize()
+    first = r.clone()
+    dr.rasterize(ctx, tp, tt, [64, 96], grad_db=False)            # same shape, eager: fine
+    with pytest.raises(RuntimeError, match="captured graph"):
+        dr.rasterize(ctx, tp, tt, [512, 768], grad_db=False)      # would move the key image
+    g.replay()                                                    # ... and the graph still replays into live memory
+    torch.cuda.synchronize()
+    assert torch.equal(r, first)
