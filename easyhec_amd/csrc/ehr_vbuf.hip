@@ -1616,11 +1616,19 @@ vb_job_kernel(VbJobParams prm_) {
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
 #endif
-    // the scheduling hint of the previous step is requested before anything else (two dependent round trips that would
-    // otherwise sit between the prologue and a heavy job)
-    const int gen = PRM(hv.gen)[0], hcur = (gen - 1) & 1, hnxt = gen & 1;
-    const int nheavy_prev = PRM(hv.gen)[1 + hcur];
-    const int hid_first = PRM(hv.list)[hcur * VB_HEAVY_CAP + min((int)blockIdx.x, VB_HEAVY_CAP - 1)];
+    // the scheduling hint of the previous step is requested before anything else, in ONE round trip: which of the two
+    // lists is the one to consume follows from the generation, so both lists' counts and this workgroup's entry of either are
+    // requested together with it (they were a second, dependent round trip on every wave's way to its first job)
+    const int* const hgen = PRM(hv.gen);
+    const int gen = hgen[0], hc1 = hgen[1], hc2 = hgen[2], hm4 = hgen[4], hm5 = hgen[5];
+    const int hida = PRM(hv.list)[min((int)blockIdx.x, VB_HEAVY_CAP - 1)];
+    const int hidb = PRM(hv.list)[VB_HEAVY_CAP + min((int)blockIdx.x, VB_HEAVY_CAP - 1)];
+    // (Not the long job a wave starts with: its index depends on the number of heavy workgroups.  Dealing the long jobs to
+    //  the XCD's LAST workgroups instead, counted from the end, makes the index known here -- measured: 84.7 vs 83.1 us, the
+    //  last workgroups of a 1024-workgroup grid start last.)
+    const int hcur = (gen - 1) & 1, hnxt = gen & 1;
+    const int nheavy_prev = hcur ? hc2 : hc1;
+    const int hid_first = hcur ? hidb : hida;
     __shared__ int upre[VB_MAX_UNITS + 1];   // first job of every (view, link)
     __shared__ unsigned utile[VB_MAX_UNITS];  // its tile range: tx0 | ty0 << 10 | nx << 22
     __shared__ int lcoff[33];                 // first cluster of every link
@@ -1628,6 +1636,31 @@ vb_job_kernel(VbJobParams prm_) {
     VbWaveLds& S = lds_all[wave];
     const int U = B * L;
     // ---- prologue (every workgroup, redundantly): tile range and job count of every (view, link), prefix sum
+    int total;
+    if (U <= 64) {
+        // At most one (view, link) per lane: EVERY WAVE builds the tables by itself -- its own read of the link boxes, a wave
+        // scan, the same values to the same LDS words as its three siblings -- and goes on without a barrier: the two
+        // workgroup barriers and the LDS hand-over of the cooperative form below stood between every wave and its first job
+        // (3.0-3.4 us into the kernel; the long jobs the kernel ends on are first jobs).
+        if (lane <= L) lcoff[lane] = PRM(cl.coff)[lane];
+        int cnt = 0;
+        if (lane < U) {
+            int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
+            const bool ne = vb_unit_tiles(PRM(lbox) + VB_LBOX_STRIDE * (size_t)lane, W, H, tx0, ty0, nx, ny, COVER ? 0 : 1);
+            cnt = ne ? nx * ny : 0;
+            utile[lane] = (unsigned)tx0 | ((unsigned)ty0 << 10) | ((unsigned)(ne ? nx : 1) << 22);
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane < U) upre[lane + 1] = incl;
+        if (lane == 0) upre[0] = 0;
+        total = vb_readlane(incl, 63);
+        VB_WAVE_SYNC();
+    } else {
     if (tid <= L) lcoff[tid] = PRM(cl.coff)[tid];
     for (int u = tid; u < U; u += 256) {
         int tx0 = 0, ty0 = 0, nx = 0, ny = 0;
@@ -1652,9 +1685,11 @@ vb_job_kernel(VbJobParams prm_) {
         }
     }
     __syncthreads();
-    int total = upre[U];
+    total = upre[U];
+    }
     if (blockIdx.x == 0) {
         // job slots are numbered like the jobs: stage 3 finds a (view, link, tile) slot from the link's first job
+        // (every entry this wave may read here it has written itself, or a barrier lies in between: see above)
         if (!COVER) {
             for (int u = tid; u <= U; u += 256) PRM(jbase)[u] = upre[u];
             for (int u = tid; u < U; u += 256) PRM(jutile)[u] = utile[u];
@@ -1718,13 +1753,15 @@ vb_job_kernel(VbJobParams prm_) {
     // one per wave, in the next step.  Only when the machine is short of jobs (at most 1.5 per wave): with more, claiming
     // balances the waves anyway and the jobs are better off in their own XCD's eighth of the list (L2).
     const int med_t = max(PRM(med_t0), 1);
-    const int nmed = ((dbg & (64 | 128)) || total > 6 * (int)gridDim.x) ? 0 : min(PRM(hv.gen)[4 + hcur], PRM(hv.mcap));
+    const int nmed = ((dbg & (64 | 128)) || total > 6 * (int)gridDim.x) ? 0 : min(hcur ? hm5 : hm4, PRM(hv.mcap));
     auto remember_long = [&](int id) {
         const int at = atomicAdd(&PRM(hv.gen)[4 + hnxt], 1);
         if (at < VB_MED_CAP) PRM(hv.mlist)[hnxt * VB_MED_CAP + at] = id;
     };
-    if (tid < 2) s_heavy[tid] = 0;
-    __syncthreads();
+    if ((int)blockIdx.x < nheavy) {  // (workgroup-uniform: the others go straight on, without a barrier)
+        if (tid < 2) s_heavy[tid] = 0;
+        __syncthreads();
+    }
 #if VB_PRIO_HEAVY
     if ((int)blockIdx.x < nheavy) __builtin_amdgcn_s_setprio(VB_PRIO_HEAVY);
 #endif
@@ -1805,7 +1842,7 @@ vb_job_kernel(VbJobParams prm_) {
     const int nhw = min(nheavy, (int)gridDim.x);
     const int hk = (nhw > xcd) ? (nhw - xcd + 7) >> 3 : 0;
     const int kx = blockIdx.x >> 3;                      // this workgroup's index inside its XCD
-    const int nsw = ((gridDim.x >> 3) - hk) * 4;         // waves of this XCD that take a static first job
+    const int G8 = (int)gridDim.x >> 3;                  // workgroups per XCD
 #ifdef VB_TIMELINE
     const long long tl_heavy = wall_clock64();
     int tl_jobs = 0, tl_maxsurv = 0, tl_sumsurv = 0;
@@ -1818,20 +1855,21 @@ vb_job_kernel(VbJobParams prm_) {
         for (int k = 0; k < 8; k++) S.tl_c[k] = 0;
     }
 #endif
-    bool first_job = kx >= hk;
     // static first jobs: wave rx of this XCD's static waves (global rank 8 rx + xcd) takes long job number <rank> of the
     // previous step if there is one, else the (rx - nmx)-th job of the XCD's eighth; the rest of the eighth is claimed
+    const int nmx = (nmed > xcd) ? (nmed - xcd + 7) >> 3 : 0;  // long jobs that go to this XCD's waves (<= the static waves, see mcap)
     const int rx = (kx - hk) * 4 + wave;
-    const int nmx = (nmed > xcd) ? (nmed - xcd + 7) >> 3 : 0;  // long jobs that go to this XCD's waves (<= nsw, see mcap)
-    const int nsn = nsw - nmx;                                 // static jobs of the eighth itself
+    bool list_first = kx >= hk && rx < nmx;
+    bool first_job = kx >= hk && !list_first;
+    const int nsn = (G8 - hk) * 4 - nmx;                       // static jobs of the eighth itself
     int sjob = jbeg + rx - nmx;
     for (;;) {
 #ifdef VB_TIMELINE
         const long long tl_j0 = __builtin_readcyclecounter();
 #endif
         int job = 0, u = -1, tx = 0, ty = 0;
-        if (first_job && rx < nmx) {
-            first_job = false;
+        if (list_first) {
+            list_first = false;
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(VB_PRIO_LONG);
 #endif
@@ -1844,16 +1882,13 @@ vb_job_kernel(VbJobParams prm_) {
             const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
             job = upre[u] + (ty - ty0) * nx + (tx - tx0);
             if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
-#ifdef VB_EXPERIMENT_SKIP_LONG
-            continue;  // timing experiment only (results wrong): what the kernel costs without its long single-wave jobs
-#endif
         } else {
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(0);
 #endif
             if (first_job || (dbg & 8)) {
                 job = sjob;
-                sjob += nsn;
+                sjob += max(nsn, 1);
                 first_job = false;
                 if (job >= jbeg + nsn && !(dbg & 8)) job = jend;  // (more static waves than jobs)
             } else {  // whoever is done first takes the next one: the waves stuck with a heavy first job take no second
