@@ -272,9 +272,11 @@ class FusedPoseStep:
         counter stay untouched on a NaN), so the caller simply goes on stepping.  Raises on any other overflow."""
         with torch.cuda.device(self.glctx.device):
             rc = _lib.lib().ehr_fused_status(self.glctx.handle)
+        # (on every rank of a data-parallel job alike, whichever rank's views caused the report: the reduced loss was NaN for
+        #  all of them, none of them stepped, each of them recorded the unchanged pose once per reported step)
+        self._rewind_history()
         if rc == 0:
             return False
-        self._rewind_history()
         had_graph = bool(self._graph)
         if rc == _lib.EHR_ERR_RETRY:
             # the step met triangles for the general-triangle pass, which the chain had not been launching: the context
