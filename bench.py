@@ -237,14 +237,17 @@ def drop_in_step(p, dev, steps=20):
     # three_ops: this repo's optimised mirror of the reference's schedule (renderer.NVDiffrastRenderer); import_swap_only: the
     # reference's OWN renderer / solver statements with only the import swapped (renderer.ReferenceScheduleRenderer: three
     # colour channels, rast_db written, nothing cached or batched) -- the number INTEGRATION.md section 2 promises
-    for name, fusedflag, refsched, graphs in (("three_ops", False, False, (True,)), ("fused_op_autograd", True, False, (True,)),
+    # three_ops_batched: the same three ops called once per step over all (view, link) images (nvdiffrast's range mode)
+    for name, fusedflag, refsched, graphs in (("three_ops", False, False, (True,)), ("three_ops_batched", False, "batched", (True,)),
+                                              ("fused_op_autograd", True, False, (True,)),
                                               ("import_swap_only", False, True, (True, False))):
         for graph in graphs:
             cfg = Cfg()
             cfg.model.rbsolver.H, cfg.model.rbsolver.W = p["H"], p["W"]
             cfg.model.rbsolver.init_Tc_c2b = p["Tc_init"].tolist()
             cfg.model.rbsolver.use_fused = fusedflag
-            cfg.model.rbsolver.reference_schedule = refsched
+            cfg.model.rbsolver.reference_schedule = refsched is True
+            cfg.model.rbsolver.batched_ops = refsched == "batched"
             model = RBSolver(cfg, meshes=p["robot"].meshes).to(dev)
             batch = {k: tr0.batch[k] for k in ("mask", "link_poses", "K")}
             tr = RBSolverTrainer(cfg, model, batch, graph=graph)

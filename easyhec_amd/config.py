@@ -27,6 +27,10 @@ class RBSolverCfg:
     # rast not detached, no topology argument, one flip / stack / clamp per frame as written.  False = this repo's
     # optimised mirror of the same schedule (renderer.NVDiffrastRenderer: cached constants, one channel, batched glue)
     reference_schedule: bool = False
+    # use_fused=False only: the three ops called ONCE per step over all (view, link) images -- nvdiffrast's range mode: one
+    # concatenated vertex / triangle array, a (start, count) range per image -- instead of once per image.  Same ops, same
+    # arithmetic per image; what changes is that a call's latency chain is paid once for B x L images instead of B x L times
+    batched_ops: bool = False
 
 
 @dataclass

@@ -82,6 +82,9 @@ struct ehr_ctx {
     unsigned long long counts_clean = ~0ull;  // == counts.moves: the buffer is known to be all zero
     bool vb_slow_needed = false;  // a solver step met a triangle for the general path: vb_slow_kernel is launched from now on
     ehr::Scratch ranges;    // int32 [2 * B]: the per-image triangle ranges of a range-mode call
+    std::vector<int32_t> ranges_last;            // what `ranges` holds on the device (host copy): the same ranges again are not
+    unsigned long long ranges_moves = ~0ull;     // uploaded again -- a solve passes them every step, and an upload recorded
+                                                 // into a stream capture would be a memcpy node (see zero_words)
     ehr::Scratch rkeys;     // u64 [B * H * W]: key image of the drop-in rasterizer's direct form; ALL ONES between calls
     unsigned long long rkeys_clean = ~0ull;  // == rkeys.moves: known to be all ones
     ehr::Scratch offsets;   // int32 [nkeys]

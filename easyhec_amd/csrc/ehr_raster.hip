@@ -1,6 +1,8 @@
 // ehr_raster.hip -- drop-in dr.rasterize forward/backward (nvdiffrast_renderer.py:39) + context management.
 #include <stdarg.h>
 
+#include <string.h>
+
 #include <algorithm>
 
 #include "ehr_host.h"
@@ -620,7 +622,16 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     int tmax = T;
     if (ranges_host) {
         ranges_dev = (int2*)ctx->ranges.ptr;
-        EHR_HIP(hipMemcpyAsync(ranges_dev, ranges_host, (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+        const bool same = ctx->ranges_moves == ctx->ranges.moves && ctx->ranges_last.size() == 2 * (size_t)B &&
+                          memcmp(ctx->ranges_last.data(), ranges_host, 2 * (size_t)B * sizeof(int32_t)) == 0;
+        if (!same) {
+            // (from the context's own copy: the caller's array may be gone, or pageable, by the time the copy runs)
+            ctx->ranges_last.assign(ranges_host, ranges_host + 2 * (size_t)B);
+            ctx->ranges_moves = ~0ull;
+            EHR_HIP(hipMemcpyAsync(ranges_dev, ctx->ranges_last.data(), (size_t)B * 2 * sizeof(int), hipMemcpyHostToDevice, stream));
+            EHR_HIP(hipStreamSynchronize(stream));  // (once per new set of ranges: the host copy above must outlive the transfer)
+            ctx->ranges_moves = ctx->ranges.moves;
+        }
         tmax = 0;
         for (int b = 0; b < B; b++) tmax = std::max(tmax, ranges_host[2 * b + 1]);
         tmax = std::min(tmax, T);
@@ -642,7 +653,10 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     {
         const char* e = getenv("EHR_RASTER_DIRECT_MAX");
         const size_t direct_max = e ? (size_t)std::max(0ll, atoll(e)) : ((size_t)1 << 17);
-        if ((size_t)B * (size_t)tmax <= direct_max && (size_t)B * H * W <= ((size_t)1 << 26) && B <= 65535) {
+        // (range mode with small ranges -- a batch of (view, link) images over one concatenated mesh, the way nvdiffrast
+        //  batches -- is many small launches in one: the direct form's cost per image is a latency chain that a batch hides)
+        const bool small_ranges = ranges_host && tmax <= 16384 && (size_t)B * (size_t)tmax <= ((size_t)1 << 21) && !e;
+        if (((size_t)B * (size_t)tmax <= direct_max || small_ranges) && (size_t)B * H * W <= ((size_t)1 << 26) && B <= 65535) {
             const size_t npix = (size_t)B * H * W;
             if ((rc = ctx->rkeys.reserve(npix * sizeof(u64)))) return rc;
             if (ctx->rkeys_clean != ctx->rkeys.moves) {

@@ -125,6 +125,49 @@ class RBSolver(nn.Module):
             per_frame_loss.append(((composite - masks_ref[frame].float()) ** 2).sum())
         return torch.stack(per_frame_mask), torch.stack(per_frame_loss).mean()
 
+    def _batched_topology(self, B, dev):
+        """Static part of the batched schedule for B frames: the triangles of every (frame, link) image shifted to that image's
+        slice of the concatenated vertex array, the (start, count) range of every image (CPU int32, as dr.rasterize takes
+        them), the all-ones colour and the edge topology of the concatenated triangle array.  Cached per (B, device)."""
+        key = (B, str(dev))
+        ent = getattr(self, "_batched_cache", None)
+        if ent is not None and ent[0] == key:
+            return ent[1]
+        from . import dr
+        vs = [getattr(self, f"vertices_{k}") for k in range(self.nlinks)]
+        fs = [getattr(self, f"faces_{k}") for k in range(self.nlinks)]
+        tris, ranges, voff, toff = [], [], 0, 0
+        for _ in range(B):
+            for v, f in zip(vs, fs):
+                tris.append(f + voff)
+                ranges.append((toff, int(f.shape[0])))
+                voff += int(v.shape[0])
+                toff += int(f.shape[0])
+        tri = torch.cat(tris).to(torch.int32).contiguous()
+        ent = {"tri": tri, "ranges": torch.tensor(ranges, dtype=torch.int32),
+               "ones": torch.ones((voff, 1), dtype=torch.float32, device=dev),
+               "topology": dr.antialias_construct_topology_hash(tri)}
+        self._batched_cache = (key, ent)
+        return ent
+
+    def _forward_three_ops_batched(self, renderer, Tc_c2b, link_poses, K, masks_ref):
+        """``batched_ops``: the reference's three ops called once each over all B x L (frame, link) images (range mode), then
+        rb_solver.py:66-72's sum over links, clamp, SSE per frame and mean -- on [B, L, H, W] at once."""
+        from . import dr
+        B = masks_ref.shape[0]
+        st = self._batched_topology(B, masks_ref.device)
+        mvp_all = renderer.clip_matrices(K, Tc_c2b[None, None] @ link_poses)                     # [B, L, 4, 4]
+        per_link = [renderer.clip_positions_batched(m, getattr(self, f"vertices_{k}"))           # L x [B, V_k, 4]
+                    for k, m in enumerate(mvp_all.unbind(1))]
+        pos = torch.cat([per_link[k][b] for b in range(B) for k in range(self.nlinks)]).contiguous()   # [sum V, 4], image-major
+        rast, _ = dr.rasterize(renderer.glctx, pos, st["tri"], [self.H, self.W], ranges=st["ranges"], grad_db=False)
+        color, _ = dr.interpolate(st["ones"], dr.carry_tile_flags(rast, rast.detach()), st["tri"])
+        aa = dr.antialias(color, rast, pos, st["tri"], topology_hash=st["topology"])                 # [B L, H, W, 1]
+        si = aa.view(B, self.nlinks, self.H, self.W)
+        masks = torch.flip(si.sum(1).clamp(max=1), dims=[1])                                     # row 0 = top
+        loss = ((masks - masks_ref.float()) ** 2).sum(dim=(1, 2)).mean()
+        return masks, loss
+
     def _forward_reference_schedule(self, renderer, Tc_c2b, link_poses, K, masks_ref):
         """rb_solver.py:58-71 statement by statement (``cfg.model.rbsolver.reference_schedule``): per frame, per link
         ``Tc_c2b @ link_poses[bid, link]`` and one ``render_mask`` call; stack / sum / clamp; SSE; mean over frames."""
@@ -174,6 +217,9 @@ class RBSolver(nn.Module):
             all_frame_all_link_si = rendered if with_outputs else None
         elif isinstance(renderer, ReferenceScheduleRenderer):
             rendered, loss = self._forward_reference_schedule(renderer, Tc_c2b, link_poses, K, masks_ref)
+            all_frame_all_link_si = rendered
+        elif getattr(self.cfg, "batched_ops", False):
+            rendered, loss = self._forward_three_ops_batched(renderer, Tc_c2b, link_poses, K, masks_ref)
             all_frame_all_link_si = rendered
         else:
             rendered, loss = self._forward_three_ops(renderer, Tc_c2b, link_poses, K, masks_ref)

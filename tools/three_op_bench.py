@@ -34,15 +34,16 @@ def main():
     _, lp = make_views(rb, a.views)
     Tc = camera_Tc_c2b(radius=wl["radius"], lift=wl["lift"])
     out = {}
-    for fusedflag, refsched in ((False, False), (False, True), (True, False)):
-        name = "fused_autograd" if fusedflag else ("import_swap_only" if refsched else "three_ops")
+    for fusedflag, refsched in ((False, False), (False, "batched"), (False, True), (True, False)):
+        name = "fused_autograd" if fusedflag else ("import_swap_only" if refsched is True else ("three_ops_batched" if refsched else "three_ops"))
         if a.only and a.only != name:
             continue
         cfg = Cfg()
         cfg.model.rbsolver.H, cfg.model.rbsolver.W = H, W
         cfg.model.rbsolver.init_Tc_c2b = perturb_pose(Tc).tolist()
         cfg.model.rbsolver.use_fused = fusedflag
-        cfg.model.rbsolver.reference_schedule = refsched  # True: the reference's own statements, only the import swapped
+        cfg.model.rbsolver.reference_schedule = refsched is True  # True: the reference's own statements, only the import swapped
+        cfg.model.rbsolver.batched_ops = refsched == "batched"   # one call per op and step over all (view, link) images
         model = RBSolver(cfg, meshes=rb.meshes).to(dev)
         batch = {"mask": torch.zeros((a.views, H, W), device=dev), "link_poses": torch.tensor(lp, device=dev),
                  "K": torch.tensor(K, dtype=torch.float32, device=dev)[None].repeat(a.views, 1, 1)}
@@ -55,7 +56,7 @@ def main():
             tr.step()
         torch.cuda.synchronize()
         dt = (time.time() - t0) / a.steps
-        out[("fused_autograd" if fusedflag else ("import_swap_only" if refsched else "three_ops")) + ("_graph" if a.graph else "")] = {
+        out[name + ("_graph" if a.graph else "")] = {
             "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(a.views / dt, 1), "loss": round(float(tr.last_loss), 3)}
     print(json.dumps(out))
 
