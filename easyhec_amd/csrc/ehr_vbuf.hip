@@ -2179,16 +2179,29 @@ vb_refsum_kernel(BinGeom g, int B, const float* __restrict__ ref, int vec_ok, lo
     }
 }
 
+// a lane's four pixels of a mask tile row := 0 (the composite kernel's layout: lane -> row lane / 8, columns 4 (lane % 8)..+3)
+__device__ __forceinline__ void vb_zero_tile_row(float* __restrict__ mask, size_t im, bool row_in, int ix, int W, int vec_ok) {
+    if (!row_in) return;
+    if (vec_ok) {
+        if (ix < W) *reinterpret_cast<float4*>(mask + im) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (ix + j < W) mask[im + j] = 0.f;
+    }
+}
+
 // Stage 3: one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers): sums the links'
 // values in link order, clamps, accumulates the frame loss, writes the mask, and back-propagates the tile's blended
 // pairs to 12 numbers per link which go to the view's fixed-point accumulators.  Persistent waves over
 //   tsum == NULL: every tile of every view (tiles no link box touches just stream: mask = 0, loss += ref^2);
-//   tsum != NULL (bound reference mask, no mask output): the tiles of the views' link rectangles only; a tile that no
-//                 link contributes to is skipped without touching the image -- its cached sum is already in vtot.
+//   tsum != NULL (bound reference mask): the tiles of the views' link rectangles only; a tile that no link contributes
+//                 to is skipped without reading the reference -- its cached sum is already in vtot.  With a mask output
+//                 the tiles outside every rectangle are then filled with zeros (stores only, no reference read, no sums).
 // The workgroup that finishes LAST (a ticket per XCD, then one over the XCDs) runs the finish stage: accumulators ->
 // loss / grad_mvp [-> pose backward -> Adam], re-arms the link boxes.  vec_ok: W % 4 == 0 and 16-byte aligned images.
-template <bool TAIL>
-__global__ void __launch_bounds__(256, 6)
+template <bool TAIL, bool FILL>
+__global__ void __launch_bounds__(256, FILL ? 5 : 6)
 vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const float* __restrict__ verts,
                     int* __restrict__ lbox, const int* __restrict__ jn, const float* __restrict__ jval,
                     const VbItem* __restrict__ jitems, const int* __restrict__ jspill, const int* __restrict__ jbase,
@@ -2280,7 +2293,13 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
         }
         tmask = (unsigned)__ballot(myn >= 0);  // links that contribute a value here
     }
-    if (sparse && tmask == 0) continue;  // nothing drawn here: the tile's cached sum(ref^2) is part of vtot already
+    if (sparse && tmask == 0) {  // nothing drawn here: the tile's cached sum(ref^2) is part of vtot already
+        if (FILL) {
+            const int zx = tx * EHR_TILE_W + c4, zy = ty * EHR_TILE_H + r;
+            vb_zero_tile_row(mask, ((size_t)b * H + (H - 1 - (zy < H ? zy : 0))) * W + zx, zy < H, zx, W, vec_ok);
+        }
+        continue;
+    }
     const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
     const bool row_in = iy < H;
     const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
@@ -2398,6 +2417,29 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
         const float mine = wave_sum12(G, lane);
         if ((lane & 3) == 0 && (lane & 12) != 12) fix_add(&vacc[12 * l + wave_sum12_element(lane)], mine, meta);
     }
+    }
+    // ---- bound reference AND a mask output: the tiles that hold a job were written by their owners above; every other
+    //      tile of the images is zero.  The waves share them out (most have no item, or one): a wave tests a tile against
+    //      the links' tile ranges -- the predicate that decides whether the tile HAS an owner -- and stores 1 KB of zeros if
+    //      it has none.  Stores only: nothing here is waited for before the ticket's vmcnt.
+    if (FILL) {
+        const int total = B * g.nt;
+        for (int t = (int)blockIdx.x * 4 + wave; t < total; t += nwg * 4) {
+            const int b = t / g.nt, tile = t - b * g.nt;
+            const int ty = tile / g.ntx, tx = tile - ty * g.ntx;
+            bool owned = false;
+            if (lane < L) {
+                const int u = b * L + lane;
+                const unsigned ut = s_utile[u];
+                const int n = s_jbase[u + 1] - s_jbase[u];
+                const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
+                owned = n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && ty < ty0 + n / nx;
+            }
+            if (__ballot(owned)) continue;
+            const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;
+            const bool row_in = iy < H;
+            vb_zero_tile_row(mask, ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix, row_in, ix, W, vec_ok);
+        }
     }
     // ---- the workgroup whose atomics are performed last runs the finish stage.  Every wave first waits until its own
     //      atomics have been performed (vmcnt covers them), then one lane takes a ticket on the XCD's counter and the
@@ -2902,8 +2944,9 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     static const int xcd_align = getenv("EHR_VB_XCD") ? atoi(getenv("EHR_VB_XCD")) : 1;  // tuning knob
     static const int res_grid = getenv("EHR_VB_RESOLVE_GRID") ? atoi(getenv("EHR_VB_RESOLVE_GRID")) : 5;  // tuning knob (5 workgroups per CU are resident)
     static const int no_sparse = getenv("EHR_VB_NO_SPARSE") ? atoi(getenv("EHR_VB_NO_SPARSE")) : 0;  // A/B aid
+    static const int no_sparse_mask = getenv("EHR_VB_NO_SPARSE_MASK") ? atoi(getenv("EHR_VB_NO_SPARSE_MASK")) : 0;  // A/B aid
     static const int comp_grid = getenv("EHR_VB_COMPOSITE_GRID") ? atoi(getenv("EHR_VB_COMPOSITE_GRID")) : 6;  // tuning knob (6 resident per CU)
-    const bool sparse = !no_sparse && !mask && ctx->vb_ref != nullptr && ctx->vb_ref == ref;
+    const bool sparse = !no_sparse && (!mask || no_sparse_mask == 0) && ctx->vb_ref != nullptr && ctx->vb_ref == ref;
     const long long* const tsum_all = sparse ? (const long long*)ctx->vb_refsum.ptr : nullptr;
     const long long* const vtot_all = sparse ? tsum_all + (size_t)B * g.nt : nullptr;
     const int* const ref_flag = sparse ? (const int*)(vtot_all + B) : nullptr;
@@ -3041,18 +3084,20 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         const long long* tsum = sparse ? tsum_all + (size_t)b0 * g.nt : nullptr;
         const long long* vtot = sparse ? vtot_all + b0 : nullptr;
         const size_t dyn = (2 * (size_t)Bk * L + 1) * sizeof(int);  // link tables in LDS
+        const bool fill = sparse && mask_k != nullptr;  // (FILL: the zero fill of the tiles no job owns, a variant of its own
+                                                          //  so that the form without a mask output keeps its registers)
+#define VB_COMPOSITE(TAILV, FILLV, tailarg)                                                                                  \
+    vb_composite_kernel<TAILV, FILLV><<<nwg, 256, dyn, stream>>>(                                                            \
+        g, Bk, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, jutile, ctx->vb_jcap, ref_k, mask_k, facc,             \
+        VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss, grad_mvp,  \
+        tailarg, last_chunk ? 1 : 0, B, facc_all, vtot_all, lbox_all)
+        StepTail none = {};
         if (tail) {
-            vb_composite_kernel<true><<<nwg, 256, dyn, stream>>>(
-                g, Bk, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, jutile, ctx->vb_jcap, ref_k, mask_k, facc,
-                VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss, grad_mvp,
-                *tail, last_chunk ? 1 : 0, B, facc_all, vtot_all, lbox_all);
+            if (fill) VB_COMPOSITE(true, true, *tail); else VB_COMPOSITE(true, false, *tail);
         } else {
-            StepTail none = {};
-            vb_composite_kernel<false><<<nwg, 256, dyn, stream>>>(
-                g, Bk, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, jutile, ctx->vb_jcap, ref_k, mask_k, facc,
-                VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss, grad_mvp,
-                none, last_chunk ? 1 : 0, B, facc_all, vtot_all, lbox_all);
+            if (fill) VB_COMPOSITE(false, true, none); else VB_COMPOSITE(false, false, none);
         }
+#undef VB_COMPOSITE
         EHR_LAUNCH_CHECK();
     }
     if (ev) {

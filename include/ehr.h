@@ -152,12 +152,13 @@ int ehr_fused_status(ehr_ctx* ctx); /* synchronises the device; 0, EHR_ERR_OVERF
  * change (rb_solver.py:70 compares every step with the same dps['mask']), so the part of the frame loss that comes from
  * image tiles no link touches -- sum(ref^2) over those tiles, 90 % of a 1280x720 frame -- is a constant of the solve.
  * This call stores it once (one pass over ref: per tile the fixed-point value the composite stage would add, per view the
- * total); afterwards ehr_render_mask_loss / ehr_solver_step calls that pass THIS pointer and mask == NULL visit only the
- * tiles inside the views' link boxes and correct the cached total by integer differences.  The sums are 64-bit fixed
- * point, so loss and gradients are bit-identical to the unbound path; it is an exact algebraic saving, not skipped
- * work.  The caller promises not to modify ref's contents while it is bound: call again after changing them, or with
- * ref == NULL to unbind.  ehr_fused_plan unbinds.  Calls with another pointer or with a mask output take the unbound
- * path.  Enqueues on `stream`; not to be called inside a graph capture. */
+ * total); afterwards ehr_render_mask_loss / ehr_solver_step calls that pass THIS pointer visit only the tiles inside the
+ * views' link boxes and correct the cached total by integer differences (with a mask output they also store zeros to
+ * every other tile of `mask`, without reading ref there).  The sums are 64-bit fixed point, so loss, gradients and masks
+ * are bit-identical to the unbound path; it is an exact algebraic saving, not skipped work.  The caller promises not to
+ * modify ref's contents while it is bound: call again after changing them, or with ref == NULL to unbind.
+ * ehr_fused_plan unbinds.  Calls with another pointer take the unbound path.  Enqueues on `stream`; not to be called
+ * inside a graph capture. */
 int ehr_fused_bind_ref(ehr_ctx* ctx, const float* ref, void* stream);
 
 /* Measurement hook (bench.py's roofline leg): when enabled, every ehr_render_mask_loss / ehr_solver_step call records

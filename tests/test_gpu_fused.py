@@ -636,6 +636,37 @@ def test_solver_step_switches_the_general_triangle_pass_on_when_a_step_needs_it(
     assert torch.equal(ends[0][0], ends[1][0]) and torch.equal(ends[0][0], ends[2][0])
 
 
+@pytest.mark.parametrize("H,W,scale,B", [(720, 1280, 1.0, 8), (100, 150, 0.12, 3), (97, 131, 0.12, 2)])
+def test_bound_reference_with_a_mask_output_fills_the_unowned_tiles(env, xarm7, H, W, scale, B):
+    """Bound reference AND a mask output: the composite stage visits the job tiles only and stores zeros to every tile no
+    job owns, without reading the reference there.  The mask, the loss and the gradient must equal the unbound full pass
+    bit for bit -- into a buffer that held garbage, and again at another pose into the same buffer (tiles the robot left
+    must be zero again).  (97 x 131: partial tiles on both edges, the scalar store form.)"""
+    fused, _, scene, dev = env
+    from easyhec_amd import dr
+    ctx = dr.RasterizeCudaContext()
+    rng = np.random.default_rng(H)
+    ref = torch.tensor((rng.uniform(size=(B, H, W)) > 0.6).astype(np.float32), device=dev)
+    mask_b = torch.full((B, H, W), float("nan"), device=dev)
+    fused._ensure_plan(ctx, scene, B, H, W)
+    for seed in (3, 4, 3):
+        K, lp, Tc, mvp = workload(xarm7, H, W, scale, B, seed=seed)
+        tm = torch.tensor(mvp, device=dev)
+        res = []
+        for bound in (False, True):
+            fused.bind_ref(ctx, scene, ref if bound else None)
+            mask = mask_b if bound else torch.full((B, H, W), float("nan"), device=dev)
+            loss = torch.empty((B,), device=dev)
+            grad = torch.empty((B, scene.num_links, 4, 4), device=dev)
+            fused._launch(ctx, scene, tm, ref, mask, loss, grad)
+            torch.cuda.synchronize()
+            res.append((mask.clone(), loss.clone(), grad.clone()))
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a, b)
+        assert float(res[1][0].sum()) > 0 and float((res[1][0] == 0).float().mean()) > 0.5
+    fused.check_status(ctx)
+
+
 @pytest.mark.parametrize("H,W,scale,B", [(720, 1280, 1.0, 8), (100, 150, 0.12, 3)])
 def test_bound_reference_is_bit_identical(env, xarm7, H, W, scale, B):
     """ehr_fused_bind_ref caches, per tile, the fixed-point sum(ref^2) the composite stage would add for a tile no link
@@ -664,7 +695,7 @@ def test_bound_reference_is_bit_identical(env, xarm7, H, W, scale, B):
         assert float(res[0][0].min()) > 0
         outs.append(res[1][0])
     assert not torch.equal(outs[0], outs[1])
-    # new contents + re-bind; and the mask-output form (always the full pass) agrees with both
+    # new contents + re-bind; and the mask-output form agrees with both
     ref2 = torch.tensor((rng.uniform(size=(B, H, W)) > 0.7).astype(np.float32), device=dev)
     ref.copy_(ref2)
     fused.bind_ref(ctx, scene, ref)
