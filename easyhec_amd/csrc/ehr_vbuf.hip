@@ -526,6 +526,44 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
 
 // ---- stage 2: one wave per job: cull, coverage into LDS, depth only where the silhouette analysis will look ---------
 
+// ---- wave scans without LDS (DPP): four shifts inside the rows of 16 lanes, then the rows' totals into the rows above
+#ifndef VB_FAST_SEARCH
+#define VB_FAST_SEARCH 1  // 0: the scans as six ds_bpermute steps and the walkers' start as a binary search over the prefix table
+#endif
+#define VB_DPP_(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ int vb_scan_add(int v) {  // inclusive sum
+#if VB_FAST_SEARCH
+    v += VB_DPP_(v, 0x111, 0xf);  // row_shr:1
+    v += VB_DPP_(v, 0x112, 0xf);  // row_shr:2
+    v += VB_DPP_(v, 0x114, 0xf);  // row_shr:4
+    v += VB_DPP_(v, 0x118, 0xf);  // row_shr:8
+    v += VB_DPP_(v, 0x142, 0xa);  // row_bcast:15 -> rows 1 and 3
+    v += VB_DPP_(v, 0x143, 0xc);  // row_bcast:31 -> rows 2 and 3
+#else
+    const int lane = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+#endif
+    return v;
+}
+__device__ __forceinline__ int vb_scan_max(int v) {  // inclusive maximum of values >= 0
+    v = max(v, VB_DPP_(v, 0x111, 0xf));
+    v = max(v, VB_DPP_(v, 0x112, 0xf));
+    v = max(v, VB_DPP_(v, 0x114, 0xf));
+    v = max(v, VB_DPP_(v, 0x118, 0xf));
+    v = max(v, VB_DPP_(v, 0x142, 0xa));
+    v = max(v, VB_DPP_(v, 0x143, 0xc));
+    return v;
+}
+// x / d for 0 <= x < 2^16, 1 <= d <= 128 (inv = 1 / d to an ulp): (x + 0.5) / d is at least 0.5 / d away from the next
+// integer, the float product at most 2^16 * 2^-22 -- exact
+__device__ __forceinline__ int vb_div_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+// the next set bit of m above position j (there is one)
+__device__ __forceinline__ int vb_next_set(u64 m, int j) { return j + __ffsll((unsigned long long)(m >> (j + 1))); }
+
 struct VbRegion {
     int x0, y0, x1, y1;  // pixels of the region inside the image (inclusive); region origin = (rx0, ry0) below
 };
@@ -722,7 +760,7 @@ template <bool WIDE, bool COVER = false>
 __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned srel, const VbRecs& rc, const VbRegion& rg,
                                                int rx0, int ry0, int W, int H, VbWaveLds& S, u64* key, u64* cov, int n,
                                                const float4* __restrict__ pv, const int4* __restrict__ cvidx_link, bool& full,
-                                               int& cost) {
+                                               int& cost, int qh) {
     VbRaster& R = S.R;
     const int lane = lane_id();
     VB_TL_BEGIN();
@@ -795,14 +833,12 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
     if ((!WIDE || COVER) && __ballot(wide)) return -1;  // the lean instantiation hands the whole job to vb_job_slow
     // one scan for both walkers: units in the low half (<= 64 x 90), span rows in the high half (<= 64 x 10)
     const int packed = units | (srows << 16);
-    int incl = packed;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += v;
-    }
+    const int incl = vb_scan_add(packed);
     const int Ptot = vb_readlane(incl, 63);
     const int Stot = Ptot & 0xffff, Wtot = Ptot >> 16;
+#if VB_FAST_SEARCH
+    const u64 nzu = __ballot(units > 0), nzs = __ballot(srows > 0);  // triangles with units / with span rows
+#endif
     cost += Stot + 3 * Wtot + 256;  // what the job costs a wave: a step per 64 units, three per 64 span rows, about four per round
 #ifdef VB_TIMELINE
     if (lane == 0) {
@@ -821,6 +857,24 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
         int j = 0, bw = 1, bh = 1, gw = 1, gx = 0, dy = 0, crow = 0, ccol0 = 0;
         unsigned eb = 0;
         int e0 = -1, e1 = -1, e2 = -1, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0, er0 = 0, er1 = 0, er2 = 0;
+#if VB_FAST_SEARCH
+        // Which triangle does a lane start in?  Asked the other way round: triangle j's units begin at pre[j]; the first
+        // lane to start at or after that is ceil(pre[j] / K), and if that start still lies inside the triangle, j puts its
+        // number there.  A lane's triangle is the last number at or below its own place: a max-scan.  (One LDS round
+        // trip instead of the six of a binary search over pre[] -- in every round of every job.  The table is the half of
+        // the survivor ring this round has just emptied.)
+        unsigned* const own = S.sq + qh;
+        {
+            const float invK = __builtin_amdgcn_rcpf((float)K);
+            const int pj = (incl - packed) & 0xffff, uj = packed & 0xffff;
+            const int wf = vb_div_small(pj + K - 1, invK);
+            own[lane] = 0u;
+            if (uj > 0 && wf * K < pj + uj) own[wf] = (unsigned)lane + 1u;
+            VB_WAVE_SYNC();
+            j = vb_scan_max((int)own[lane]) - 1;
+        }
+        if (start < end) {
+#else
         if (start < end) {
             int lo = 0, hi = 63;
 #pragma unroll
@@ -832,6 +886,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                     hi = mid - 1;
             }
             j = lo;
+#endif
             const unsigned b4 = R.box[j];
             ccol0 = b4 & 255;
             const int y0r = (b4 >> 8) & 255;
@@ -844,7 +899,11 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             sx1 = -16 * (int)(short)(w1 >> 16); sy1 = 16 * (int)(short)(w1 & 0xffffu);
             sx2 = -16 * (int)(short)(w2 >> 16); sy2 = 16 * (int)(short)(w2 & 0xffffu);
             const int o = start - (R.pre[j] & 0xffff);
+#if VB_FAST_SEARCH
+            dy = vb_div_small(o, __builtin_amdgcn_rcpf((float)gw));
+#else
             dy = o / gw;
+#endif
             gx = o - dy * gw;
             er0 = R.e[j][0] + dy * sy0;
             er1 = R.e[j][1] + dy * sy1;
@@ -855,8 +914,9 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             crow = y0r + dy;
         }
         VB_TL_END(S, 1);
+#ifdef VB_TIMELINE
         const long long tl_w0 = __builtin_readcyclecounter();
-        (void)tl_w0;
+#endif
         for (int it0 = 0; it0 < K;) {
             // the deferred list takes at most 64 entries per step: walk as many steps as it has room for
             const int room = (VB_DL - n) >> 6;
@@ -911,9 +971,13 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                         e1 = er1;
                         e2 = er2;
                         if (dy == bh) {  // next job with a non-empty box
+#if VB_FAST_SEARCH
+                            j = vb_next_set(nzu, j);
+#else
                             do {
                                 j++;
                             } while (((R.pre[j + 1] ^ R.pre[j]) & 0xffff) == 0);
+#endif
                             const unsigned b4 = R.box[j];
                             ccol0 = b4 & 255;
                             crow = (b4 >> 8) & 255;
@@ -966,6 +1030,19 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                 er2 = R.e[jj][2];
                 dy = 0;
             };
+#if VB_FAST_SEARCH
+            {
+                const float invK = __builtin_amdgcn_rcpf((float)K2);
+                const int pj = (incl - packed) >> 16, uj = packed >> 16;
+                const int wf = vb_div_small(pj + K2 - 1, invK);
+                VB_WAVE_SYNC();  // (the unit walker's reads of the table are complete)
+                own[lane] = 0u;
+                if (uj > 0 && wf * K2 < pj + uj) own[wf] = (unsigned)lane + 1u;
+                VB_WAVE_SYNC();
+                j = vb_scan_max((int)own[lane]) - 1;
+            }
+            if (s2 < e2) {
+#else
             if (s2 < e2) {
                 int lo = 0, hi = 63;
 #pragma unroll
@@ -977,6 +1054,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                         hi = mid - 1;
                 }
                 j = lo;
+#endif
                 load_tri(j);
                 dy = s2 - (R.pre[j] >> 16);
                 er0 += dy * sy0;
@@ -1024,9 +1102,13 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                         er1 += sy1;
                         er2 += sy2;
                         if (dy == bh) {
+#if VB_FAST_SEARCH
+                            j = vb_next_set(nzs, j);
+#else
                             do {
                                 j++;
                             } while ((R.pre[j + 1] >> 16) == (R.pre[j] >> 16));
+#endif
                             load_tri(j);
                         }
                     }
@@ -1037,12 +1119,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                 const u64 md = rm ? ((rm & ~S.intr[crow]) >> c0) : 0ull;
                 u64 nz = (md | (md >> 1) | (md >> 2) | (md >> 3)) & 0x1111111111111111ull;
                 const int cnt = __popcll(nz);
-                int inc = cnt;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int v = __shfl_up(inc, o, 64);
-                    if (lane >= o) inc += v;
-                }
+                const int inc = vb_scan_add(cnt);
                 const int T = vb_readlane(inc, 63);
                 if (n + T > VB_DL) {  // no room for this step's entries: flush, then take the step again
                     vb_flush<COVER>(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
@@ -1064,9 +1141,13 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                     er1 += sy1;
                     er2 += sy2;
                     if (dy == bh) {  // next triangle of this class
+#if VB_FAST_SEARCH
+                        j = vb_next_set(nzs, j);
+#else
                         do {
                             j++;
                         } while ((R.pre[j + 1] >> 16) == (R.pre[j] >> 16));
+#endif
                         load_tri(j);
                     }
                 }
@@ -1110,6 +1191,12 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 }
 
 // Kernel-wide arguments of a job (what the job kernel's helpers need besides the job itself).
+#ifndef VB_CULL_BATCHES
+#define VB_CULL_BATCHES 2  // batches of 64 cluster boxes requested together
+#endif
+#ifndef VB_CULL_GROUP
+#define VB_CULL_GROUP 4  // candidate clusters whose triangle boxes are requested together
+#endif
 struct VbJobArgs {
     VbRecs rc;
     const float4* posc;   // [B][V] clip-space vertices
@@ -1137,7 +1224,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
     const uint2* const cb = A.rc.cbox + (size_t)b * A.NC;
     const unsigned rlo = (unsigned)rg.x0 | ((unsigned)rg.y0 << 16), rhi = (unsigned)rg.x1 | ((unsigned)rg.y1 << 16);
     // Survivors of the triangle-box test are queued (record slots) until 64 are waiting, so that every round of
-    // the rasterizer is full; the triangle boxes of up to four candidate clusters are fetched per round trip.
+    // the rasterizer is full; the triangle boxes of up to VB_CULL_GROUP candidate clusters are fetched per round trip.
     const size_t vbase = (size_t)b * A.NC * 64;
     const float4* const pv = A.posc + (size_t)b * A.V;
     const int4* const cvl = A.cvidx + (size_t)c0 * 64;  // the link's first cluster slot
@@ -1146,61 +1233,84 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
     int qh = 0, qn = 0;  // wave-uniform ring state
     int cord = 0;        // running ordinal of the candidate clusters
     bool drawn = false;
-    for (int cbase = c0; cbase < c1; cbase += 64) {
-        const int c = cbase + lane;
-        bool hit = false;
-        if (c < c1) {
-            const uint2 bx = cb[c];
-            hit = (bx.x & 0xffffu) <= (rhi & 0xffffu) && (bx.y & 0xffffu) >= (rlo & 0xffffu) &&
-                  (bx.x >> 16) <= (rhi >> 16) && (bx.y >> 16) >= (rlo >> 16);
-        }
-        u64 cm = __ballot(hit);
-        if (nshare > 1) {  // cooperative job: this wave takes every nshare-th candidate cluster
-            u64 mine = 0;
-            u64 all = cm;
-            while (all) {
-                const u64 low = all & (~all + 1);
-                if ((cord++ % nshare) == share) mine |= low;
-                all ^= low;
-            }
-            cm = mine;
-        }
-        while (cm) {  // wave-uniform
-            int cc[4];
-            uint2 tb[4];
+    // The cluster boxes of VB_CULL_BATCHES x 64 clusters are requested together (one round trip under load is ~1-2 us, and
+    // all but one of the xArm7's links have between 65 and 128 clusters), then the batches are worked off one by one.
+    for (int cb0 = c0; cb0 < c1; cb0 += 64 * VB_CULL_BATCHES) {
+        u64 cmk[VB_CULL_BATCHES];
+        {
+            uint2 bxk[VB_CULL_BATCHES];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                cc[k] = -1;
-                tb[k] = VB_BOX_EMPTY;
-                if (cm) {
-                    cc[k] = cbase + __ffsll((unsigned long long)cm) - 1;
-                    cm &= cm - 1;
-                    tb[k] = A.rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
-                }
+            for (int k = 0; k < VB_CULL_BATCHES; k++) {
+                const int c = cb0 + 64 * k + lane;
+                bxk[k] = VB_BOX_EMPTY;
+                if (c < c1) bxk[k] = cb[c];
             }
-            u64 smk[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                smk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
-                                  (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
-            // not unrolled: one copy of the rasterizer round per call site (the kernel was 69 KB of code, more
-            // than the instruction cache two CUs share)
+            for (int k = 0; k < VB_CULL_BATCHES; k++)
+                cmk[k] = __ballot((bxk[k].x & 0xffffu) <= (rhi & 0xffffu) && (bxk[k].y & 0xffffu) >= (rlo & 0xffffu) &&
+                                  (bxk[k].x >> 16) <= (rhi >> 16) && (bxk[k].y >> 16) >= (rlo >> 16));
+        }
 #pragma nounroll
-            for (int k = 0; k < 4; k++) {
-                const u64 sm = (k == 0) ? smk[0] : (k == 1) ? smk[1] : (k == 2) ? smk[2] : smk[3];
-                const int ck = (k == 0) ? cc[0] : (k == 1) ? cc[1] : (k == 2) ? cc[2] : cc[3];
-                if (!sm) continue;  // wave-uniform (an unused batch entry holds the empty box)
-                if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
-                qn += __popcll(sm);
-                drawn = true;
-                if (qn >= 64) {
-                    VB_WAVE_SYNC();
-                    const unsigned sl = W_.sq[(qh + lane) & 127];
-                    dln = vb_raster_round<WIDE, COVER>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
-                    if (dln < 0) return -1;
-                    if (full) return 1;  // every pixel of the region is interior: nothing can change any more
-                    qh = (qh + 64) & 127;
-                    qn -= 64;
+        for (int kb = 0; kb < VB_CULL_BATCHES; kb++) {
+            const int cbase = cb0 + 64 * kb;
+            u64 cm = cmk[0];
+#pragma unroll
+            for (int kk = 1; kk < VB_CULL_BATCHES; kk++)
+                if (kb == kk) cm = cmk[kk];
+            if (!cm) continue;
+            if (nshare > 1) {  // cooperative job: this wave takes every nshare-th candidate cluster
+                u64 mine = 0;
+                u64 all = cm;
+                while (all) {
+                    const u64 low = all & (~all + 1);
+                    if ((cord++ % nshare) == share) mine |= low;
+                    all ^= low;
+                }
+                cm = mine;
+            }
+            while (cm) {  // wave-uniform
+                int cc[VB_CULL_GROUP];
+                uint2 tb[VB_CULL_GROUP];
+#pragma unroll
+                for (int k = 0; k < VB_CULL_GROUP; k++) {
+                    cc[k] = -1;
+                    tb[k] = VB_BOX_EMPTY;
+                    if (cm) {
+                        cc[k] = cbase + __ffsll((unsigned long long)cm) - 1;
+                        cm &= cm - 1;
+                        tb[k] = A.rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
+                    }
+                }
+                u64 smk[VB_CULL_GROUP];
+#pragma unroll
+                for (int k = 0; k < VB_CULL_GROUP; k++)
+                    smk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
+                                      (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
+                // not unrolled: one copy of the rasterizer round per call site (the kernel was 69 KB of code, more
+                // than the instruction cache two CUs share)
+#pragma nounroll
+                for (int k = 0; k < VB_CULL_GROUP; k++) {
+                    u64 sm = smk[0];
+                    int ck = cc[0];
+#pragma unroll
+                    for (int kk = 1; kk < VB_CULL_GROUP; kk++)
+                        if (k == kk) {
+                            sm = smk[kk];
+                            ck = cc[kk];
+                        }
+                    if (!sm) continue;  // wave-uniform (an unused batch entry holds the empty box)
+                    if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
+                    qn += __popcll(sm);
+                    drawn = true;
+                    if (qn >= 64) {
+                        VB_WAVE_SYNC();
+                        const unsigned sl = W_.sq[(qh + lane) & 127];
+                        dln = vb_raster_round<WIDE, COVER>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
+                        if (dln < 0) return -1;
+                        if (full) return 1;  // every pixel of the region is interior: nothing can change any more
+                        qh = (qh + 64) & 127;
+                        qn -= 64;
+                    }
                 }
             }
         }
@@ -1209,7 +1319,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
         VB_WAVE_SYNC();
         const bool sv = lane < qn;
         const unsigned sl = sv ? W_.sq[(qh + lane) & 127] : srel0;
-        dln = vb_raster_round<WIDE, COVER>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv);
+        dln = vb_raster_round<WIDE, COVER>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
         if (dln < 0) return -1;
     }
     return drawn ? 1 : 0;
@@ -1650,12 +1760,7 @@ vb_job_kernel(VbJobParams prm_) {
             cnt = ne ? nx * ny : 0;
             utile[lane] = (unsigned)tx0 | ((unsigned)ty0 << 10) | ((unsigned)(ne ? nx : 1) << 22);
         }
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += v;
-        }
+        const int incl = vb_scan_add(cnt);
         if (lane < U) upre[lane + 1] = incl;
         if (lane == 0) upre[0] = 0;
         total = vb_readlane(incl, 63);
