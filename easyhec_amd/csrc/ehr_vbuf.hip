@@ -526,6 +526,9 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
 
 // ---- stage 2: one wave per job: cull, coverage into LDS, depth only where the silhouette analysis will look ---------
 
+// i / VB_RW for 0 <= i < 4096 by one full-rate 24-bit multiply (1928 = ceil(2^16 / 34), 1928 * 34 - 2^16 = 16)
+__device__ __forceinline__ int vb_div_rw(int i) { return (int)(__umul24((unsigned)i, 1928u) >> 16); }
+static_assert(VB_RW == 34, "vb_div_rw");
 // ---- wave scans without LDS (DPP): four shifts inside the rows of 16 lanes, then the rows' totals into the rows above
 #ifndef VB_FAST_SEARCH
 #define VB_FAST_SEARCH 1  // 0: the scans as six ds_bpermute steps and the walkers' start as a binary search over the prefix table
@@ -703,7 +706,7 @@ __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n
         bool keep = false;
         if (i < n) {
             e = S.dl[i];
-            const int pix = e & 511u, row = pix / VB_RW, col = pix - row * VB_RW;
+            const int pix = e & 511u, row = vb_div_rw(pix), col = pix - row * VB_RW;
             const unsigned m4 = (e >> 9) & 15u;
             const unsigned m = (e & (1u << 13)) ? m4 : (m4 & (unsigned)(S.need[row] >> col));
             keep = m != 0;
@@ -720,7 +723,7 @@ __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n
             const unsigned e = S.dl[i];
             const int4 vi = cvidx_link[e >> 14];
             const float4 p[3] = {pv[vi.x], pv[vi.y], pv[vi.z]};
-            const int pix = e & 511u, row = pix / VB_RW, col = pix - row * VB_RW;
+            const int pix = e & 511u, row = vb_div_rw(pix), col = pix - row * VB_RW;
             const unsigned m = (e >> 9) & 15u;
             const bool flag = (e >> 13) & 1u;
             // (one pass per set bit of the fullest mask in the wave: after the filter a unit has one or two pixels left)
@@ -807,7 +810,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int dX = (int)(short)(w[k] & 0xffffu), dY = (int)(short)(w[k] >> 16);
-                R.e[lane][k] = ev[k] - 16 * dY * ox + 16 * dX * oy;
+                R.e[lane][k] = ev[k] - 16 * __mul24(dY, ox) + 16 * __mul24(dX, oy);  // (24-bit operands: full-rate multiplies)
                 R.dxy[lane][k] = w[k];
             }
             R.box[lane] = (unsigned)(cx0 - rx0) | ((unsigned)(cy0 - ry0) << 8) | ((unsigned)bw << 16) | ((unsigned)bh << 24);
@@ -853,7 +856,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
         if (lane == 63) R.pre[64] = Ptot;
         VB_WAVE_SYNC();
         const int K = (Stot + 63) >> 6;
-        const int start = lane * K, end = min(start + K, Stot);
+        const int start = __mul24(lane, K), end = min(start + K, Stot);
         int j = 0, bw = 1, bh = 1, gw = 1, gx = 0, dy = 0, crow = 0, ccol0 = 0;
         unsigned eb = 0;
         int e0 = -1, e1 = -1, e2 = -1, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0, er0 = 0, er1 = 0, er2 = 0;
@@ -869,7 +872,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             const int pj = (incl - packed) & 0xffff, uj = packed & 0xffff;
             const int wf = vb_div_small(pj + K - 1, invK);
             own[lane] = 0u;
-            if (uj > 0 && wf * K < pj + uj) own[wf] = (unsigned)lane + 1u;
+            if (uj > 0 && __mul24(wf, K) < pj + uj) own[wf] = (unsigned)lane + 1u;
             VB_WAVE_SYNC();
             j = vb_scan_max((int)own[lane]) - 1;
         }
@@ -904,13 +907,13 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
 #else
             dy = o / gw;
 #endif
-            gx = o - dy * gw;
-            er0 = R.e[j][0] + dy * sy0;
-            er1 = R.e[j][1] + dy * sy1;
-            er2 = R.e[j][2] + dy * sy2;
-            e0 = er0 + 4 * gx * sx0;
-            e1 = er1 + 4 * gx * sx1;
-            e2 = er2 + 4 * gx * sx2;
+            gx = o - __mul24(dy, gw);  // (|s*| < 2^20, dy < 2^7, gx < 4: 24-bit operands, full-rate multiplies)
+            er0 = R.e[j][0] + __mul24(dy, sy0);
+            er1 = R.e[j][1] + __mul24(dy, sy1);
+            er2 = R.e[j][2] + __mul24(dy, sy2);
+            e0 = er0 + __mul24(4 * gx, sx0);
+            e1 = er1 + __mul24(4 * gx, sx1);
+            e2 = er2 + __mul24(4 * gx, sx2);
             crow = y0r + dy;
         }
         VB_TL_END(S, 1);
@@ -952,7 +955,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                         md = COVER ? ((eb & (1u << 13)) ? m4 : 0u) : (m4 & ~(unsigned)(S.intr[crow] >> ccol));
                     }
                     const u64 ma = __ballot(md != 0);
-                    if (md) S.dl[n + vb_mbcnt(ma)] = eb | (unsigned)(crow * VB_RW + ccol0 + 4 * gx) | (md << 9);
+                    if (md) S.dl[n + vb_mbcnt(ma)] = eb | (unsigned)(__mul24(crow, VB_RW) + ccol0 + 4 * gx) | (md << 9);
                     n += __popcll(ma);
                 }
                 if (act && start + it + 1 < end) {
@@ -1006,7 +1009,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
         //      span goes into the bitmap with one OR; its 4-pixel units that are not interior are deferred as usual.
         if (Wtot > 0) {
             const int K2 = (Wtot + 63) >> 6;
-            const int s2 = lane * K2, e2 = min(s2 + K2, Wtot);
+            const int s2 = __mul24(lane, K2), e2 = min(s2 + K2, Wtot);
             int j = 0, bw = 1, bh = 1, dy = 0, crow = 0, ccol0 = 0;
             unsigned eb = 0;
             int sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0, er0 = 0, er1 = 0, er2 = 0;
@@ -1037,7 +1040,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                 const int wf = vb_div_small(pj + K2 - 1, invK);
                 VB_WAVE_SYNC();  // (the unit walker's reads of the table are complete)
                 own[lane] = 0u;
-                if (uj > 0 && wf * K2 < pj + uj) own[wf] = (unsigned)lane + 1u;
+                if (uj > 0 && __mul24(wf, K2) < pj + uj) own[wf] = (unsigned)lane + 1u;
                 VB_WAVE_SYNC();
                 j = vb_scan_max((int)own[lane]) - 1;
             }
@@ -1057,9 +1060,9 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
 #endif
                 load_tri(j);
                 dy = s2 - (R.pre[j] >> 16);
-                er0 += dy * sy0;
-                er1 += dy * sy1;
-                er2 += dy * sy2;
+                er0 += __mul24(dy, sy0);
+                er1 += __mul24(dy, sy1);
+                er2 += __mul24(dy, sy2);
                 crow += dy;
             }
 #pragma nounroll
@@ -1346,7 +1349,7 @@ __device__ __forceinline__ void vb_publish(const VbJobArgs& A, const u64* key_, 
     for (int k = 0; k < VB_WORDS; k++) {
         if (nparts > 1 && (k % nparts) != part) continue;
         const unsigned i = 64u * k + lane;
-        const unsigned row = i / VB_RW, col = i - row * VB_RW;
+        const unsigned row = (unsigned)vb_div_rw((int)i), col = i - row * VB_RW;
         const u64 w = __ballot(i < (unsigned)VB_RN && ((cov_[row < (unsigned)VB_RH ? row : 0] >> col) & 1ull));
         if (lane == 0) A.jcov[(size_t)job * VB_WORDS + k] = w;
     }
@@ -1458,7 +1461,7 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
 #pragma unroll
     for (int k = 0; k < VB_WORDS; k++) {
         const unsigned i = 64u * k + lane;
-        const int qy = (int)(i / VB_RW), qx = (int)(i - qy * VB_RW);
+        const int qy = vb_div_rw((int)i), qx = (int)i - qy * VB_RW;
         const int x = rx0 + qx, y = ry0 + qy;
         Iw[k] = __ballot(i < (unsigned)VB_RN && x >= 0 && x < W && y >= 0 && y < H);
     }
@@ -1524,7 +1527,7 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
             if (h < nh) {
                 const int hq = hits[h];
                 const int d = hq >> 15, q = hq & 0x7fff;
-                const int qy = q / VB_RW, qx = q - qy * VB_RW;
+                const int qy = vb_div_rw(q), qx = q - qy * VB_RW;
                 const int nq = q + (d ? VB_RW : 1);
                 const unsigned k0 = KT(q), k1 = KT(nq);
                 const bool chose0 = k0 != 0xffffffffu;  // exactly one of the two is covered
@@ -1546,7 +1549,7 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
                     pairA[d * VB_RN + q] = a.alpha;
                     // keep for the backward pass if the destination pixel is interior to this tile
                     const int oq = (a.alpha > 0.f) ? q : nq;
-                    const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+                    const int oy = vb_div_rw(oq), ox = oq - oy * VB_RW;
                     const bool oi = ox >= 1 && ox <= EHR_TILE_W && oy >= 1 && oy <= EHR_TILE_H;
                     if (oi && a.alpha != 0.f) {
                         it.packed = q | (d << 10) | (a.di << 11) | (a.tri1 << 13) | ((chose0 ? 0 : 1) << 14);
@@ -1633,7 +1636,7 @@ __device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWa
 #pragma unroll
     for (int k = 0; k < VB_WORDS; k++) {
         const unsigned i = 64u * k + lane;
-        const unsigned row = i / VB_RW, col = i - row * VB_RW;
+        const unsigned row = (unsigned)vb_div_rw((int)i), col = i - row * VB_RW;
         const bool in = i < (unsigned)VB_RN;
         const bool cv = in && ((cov[in ? row : 0] >> col) & 1ull);
         const unsigned id = in ? (unsigned)key[i] : 0xffffffffu;  // low word = triangle id; all-ones stays all-ones
@@ -2498,11 +2501,11 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
             const float dc = ((itm.packed >> 14) & 1) ? 1.f : -1.f;
             const int nq = q + (d ? VB_RW : 1);
             const int oq = (itm.alpha > 0.f) ? q : nq;
-            const int oy = oq / VB_RW, ox = oq - oy * VB_RW;
+            const int oy = vb_div_rw(oq), ox = oq - oy * VB_RW;
             const float gi = gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
             const float dd = gi * dc;
             if (gi == 0.f || dd == 0.f) continue;
-            const int qy = q / VB_RW, qx = q - qy * VB_RW;
+            const int qy = vb_div_rw(q), qx = q - qy * VB_RW;
             int px = rx0 + qx, py = ry0 + qy;
             if (tri1) {
                 px += 1 - d;
