@@ -1197,8 +1197,11 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 #ifndef VB_CULL_BATCHES
 #define VB_CULL_BATCHES 2  // batches of 64 cluster boxes requested together
 #endif
+#ifndef VB_CULL_STASH
+#define VB_CULL_STASH 1  // 0: the group's masks and cluster numbers in scalar registers (the form up to round 5's r05_d)
+#endif
 #ifndef VB_CULL_GROUP
-#define VB_CULL_GROUP 4  // candidate clusters whose triangle boxes are requested together
+#define VB_CULL_GROUP (VB_CULL_STASH ? 8 : 4)  // candidate clusters whose triangle boxes are requested together
 #endif
 struct VbJobArgs {
     VbRecs rc;
@@ -1272,6 +1275,39 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
                 cm = mine;
             }
             while (cm) {  // wave-uniform
+#if VB_CULL_STASH
+                // The group's cluster numbers and survivor masks wait in the LANES of three vector registers (lane k: entry
+                // k) instead of 3 x VB_CULL_GROUP scalar registers that would have to live across the rasterizer rounds.
+                int ccv = 0, ng = 0;
+                unsigned mlo = 0, mhi = 0;
+                {
+                    uint2 tb[VB_CULL_GROUP];
+#pragma unroll
+                    for (int k = 0; k < VB_CULL_GROUP; k++) {
+                        tb[k] = VB_BOX_EMPTY;
+                        if (cm) {
+                            const int c = cbase + __ffsll((unsigned long long)cm) - 1;
+                            cm &= cm - 1;
+                            ccv = (lane == k) ? c : ccv;
+                            tb[k] = A.rc.tbox[vbase + (size_t)c * 64 + lane];
+                            ng = k + 1;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < VB_CULL_GROUP; k++) {
+                        if (k < ng) {
+                            const u64 m = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
+                                                   (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
+                            mlo = (lane == k) ? (unsigned)m : mlo;
+                            mhi = (lane == k) ? (unsigned)(m >> 32) : mhi;
+                        }
+                    }
+                }
+#pragma nounroll
+                for (int k = 0; k < ng; k++) {
+                    const u64 sm = (u64)(unsigned)__builtin_amdgcn_readlane((int)mlo, k) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)mhi, k) << 32);
+                    const int ck = __builtin_amdgcn_readlane(ccv, k);
+#else
                 int cc[VB_CULL_GROUP];
                 uint2 tb[VB_CULL_GROUP];
 #pragma unroll
@@ -1301,6 +1337,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
                             sm = smk[kk];
                             ck = cc[kk];
                         }
+#endif
                     if (!sm) continue;  // wave-uniform (an unused batch entry holds the empty box)
                     if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
                     qn += __popcll(sm);
