@@ -149,6 +149,13 @@ struct VbHeavy {
                      // with the ~500 heaviest shared); it sinks back when fewer than half as many are recorded
 };
 
+// A remembered job in the hint lists: tile column | tile row << 10 | (view, link) << 22 -- no division on the way from a
+// list entry to the first cluster box (the long jobs the kernel ends on start from these).
+__device__ __forceinline__ int vb_hint_pack(int u, int tx, int ty) { return tx | (ty << 10) | (u << 22); }
+__device__ __forceinline__ int vb_hint_dense(int id, int nt, int ntx) {
+    return (int)((unsigned)id >> 22) * nt + ((id >> 10) & 4095) * ntx + (id & 1023);
+}
+static_assert(VB_MAX_UNITS <= 1024, "vb_hint_pack");
 struct VbClusters {          // static acceleration index built by ehr_fused_plan (host): triangles grouped into
     const int32_t* ctri;     // [NC * 64] clusters of <= 64 spatially close triangles of one link (-1 = padding)
     const int32_t* clink;    // [NC] link of every cluster
@@ -376,9 +383,9 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         {
             const int gen = s_gen, cur = (gen - 1) & 1;
             const int n = min(hv.gen[1 + cur], VB_HEAVY_CAP);
-            for (int i = tid; i < n; i += 256) hv.stamp[hv.list[cur * VB_HEAVY_CAP + i]] = gen;
+            for (int i = tid; i < n; i += 256) hv.stamp[min(vb_hint_dense(hv.list[cur * VB_HEAVY_CAP + i], g.nt, g.ntx), B * L * g.nt - 1)] = gen;
             const int n2 = min(hv.gen[4 + cur], hv.mcap);
-            for (int i = tid; i < n2; i += 256) hv.stamp[hv.mlist[cur * VB_MED_CAP + i]] = -gen;
+            for (int i = tid; i < n2; i += 256) hv.stamp[min(vb_hint_dense(hv.mlist[cur * VB_MED_CAP + i], g.nt, g.ntx), B * L * g.nt - 1)] = -gen;
         }
         if (tid < 8) meta[tid] = 0;                          // overflow flag, spill cursor
         if (tid < VB_LINES) *vb_line(meta, tid) = 0;         // job cursors of the 8 XCDs, tickets, slow-job count
@@ -1785,6 +1792,7 @@ vb_job_kernel(VbJobParams prm_) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbWaveLds& S = lds_all[wave];
     const int U = B * L;
+    const float invL = __builtin_amdgcn_rcpf((float)L);  // (u / L by vb_div_small)
     // ---- prologue (every workgroup, redundantly): tile range and job count of every (view, link), prefix sum
     int total;
     if (U <= 64) {
@@ -1913,13 +1921,13 @@ vb_job_kernel(VbJobParams prm_) {
     int hres_job = -1, hres_b = 0, hres_rx0 = 0, hres_ry0 = 0;  // the heavy job wave 0 resolves once the workgroup has split up again
     for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform (at most one turn: nheavy <= gridDim.x)
         const int id = (hj == (int)blockIdx.x) ? hid_first : PRM(hv.list)[hcur * VB_HEAVY_CAP + hj];
-        const int u = id / gnt, tile = id - u * gnt;
-        const int tx = tile % gntx, ty = tile / gntx;
+        const int u = min((int)((unsigned)id >> 22), U - 1), tx = id & 1023, ty = (id >> 10) & 4095;
         const unsigned ut = utile[u];
         const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
         const int job = upre[u] + (ty - ty0) * nx + (tx - tx0);
-        if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
-        const int b = u / L, l = u - b * L;
+        // (n is nx times the rows: ty inside the rows <=> the tile's job number inside the link's jobs)
+        if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || (ty - ty0) * nx >= n || job >= total) continue;  // the link moved away
+        const int b = vb_div_small(u, invL), l = u - b * L;
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
         VbRegion rg;
         rg.x0 = max(rx0, 0);
@@ -2019,14 +2027,13 @@ vb_job_kernel(VbJobParams prm_) {
             __builtin_amdgcn_s_setprio(VB_PRIO_LONG);
 #endif
             const int id = PRM(hv.mlist)[hcur * VB_MED_CAP + 8 * rx + xcd];
-            u = id / gnt;
-            const int tile = id - u * gnt;
-            tx = tile % gntx;
-            ty = tile / gntx;
+            u = min((int)((unsigned)id >> 22), U - 1);
+            tx = id & 1023;
+            ty = (id >> 10) & 4095;
             const unsigned ut = utile[u];
             const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22, n = upre[u + 1] - upre[u];
             job = upre[u] + (ty - ty0) * nx + (tx - tx0);
-            if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || ty >= ty0 + n / nx || job >= total) continue;  // the link moved away
+            if (n <= 0 || tx < tx0 || tx >= tx0 + nx || ty < ty0 || (ty - ty0) * nx >= n || job >= total) continue;  // the link moved away
         } else {
 #if VB_PRIO_LONG
             __builtin_amdgcn_s_setprio(0);
@@ -2041,7 +2048,9 @@ vb_job_kernel(VbJobParams prm_) {
                 job = __builtin_amdgcn_readfirstlane(job);
             }
             if (job >= jend) break;
-            {
+            if (U <= 64) {  // the last (view, link) whose first job is <= job: one LDS read per lane and a ballot
+                u = __popcll(__ballot(lane < U && upre[lane] <= job)) - 1;
+            } else {
                 int lo = 0, hi = U - 1;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
@@ -2055,16 +2064,17 @@ vb_job_kernel(VbJobParams prm_) {
             {
                 const unsigned ut = utile[u];
                 const int nx = (int)(ut >> 22), k = job - upre[u];
-                ty = (int)((ut >> 10) & 4095u) + k / nx;
-                tx = (int)(ut & 1023u) + k - (k / nx) * nx;
+                const int kr = vb_div_small(k, __builtin_amdgcn_rcpf((float)nx));  // (k < 2^16 tiles, nx <= 128: exact)
+                ty = (int)((ut >> 10) & 4095u) + kr;
+                tx = (int)(ut & 1023u) + k - kr * nx;
             }
             const int st = (nheavy > 0 || nmed > 0) ? PRM(hv.stamp)[u * gnt + ty * gntx + tx] : 0;
             // a workgroup took this one in the heavy phase / it is some wave's first job
             if ((nheavy > 0 && st == gen) || (nmed > 0 && st == -gen)) continue;
         }
-        const int b = u / L, l = u - b * L;
+        const int b = vb_div_small(u, invL), l = u - b * L;
         const size_t slot = (size_t)job;
-        const int dense_id = u * gnt + ty * gntx + tx;
+        const int hint_id = vb_hint_pack(u, tx, ty);
         const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
         VbRegion rg;  // tile + 1-pixel halo, inside the image (coverage-only form: the tile alone, same origin)
         rg.x0 = COVER ? rx0 + 1 : max(rx0, 0);
@@ -2120,9 +2130,9 @@ vb_job_kernel(VbJobParams prm_) {
 #endif
         if (lane == 0) {
             if (nsurv >= heavy_t)
-                remember_heavy(dense_id);
+                remember_heavy(hint_id);
             else if (nsurv >= med_t)
-                remember_long(dense_id);
+                remember_long(hint_id);
         }
         if (drawn == 0) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
