@@ -2395,22 +2395,29 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     const int istep = (nwg >> 3) * 4;
     const int acc_stride = 12 * L + nls * VB_LOSS_STRIDE;
     const int r = lane >> 3, c4 = (lane & 7) * 4;
+    const float invL = __builtin_amdgcn_rcpf((float)L);  // (u / L by vb_div_small)
     for (int item = ibeg + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += istep) {
     int b, tx, ty;
     if (sparse) {
-        int lo = 0, hi = U - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_jbase[mid] <= item)
-                lo = mid;
-            else
-                hi = mid - 1;
+        int lo = 0;
+        if (U <= 64) {  // the last (view, link) whose first job is <= item: one LDS read per lane and a ballot
+            lo = __popcll(__ballot(lane < U && s_jbase[lane] <= item)) - 1;
+        } else {
+            int hi = U - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_jbase[mid] <= item)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
         }
-        b = lo / L;
+        b = vb_div_small(lo, invL);
         const unsigned ut = s_utile[lo];
         const int nx = (int)(ut >> 22), k = item - s_jbase[lo];
-        ty = (int)((ut >> 10) & 4095u) + k / nx;
-        tx = (int)(ut & 1023u) + k - (k / nx) * nx;
+        const int kr = vb_div_small(k, __builtin_amdgcn_rcpf((float)nx));  // (k < 2^16 tiles, nx <= 128: exact)
+        ty = (int)((ut >> 10) & 4095u) + kr;
+        tx = (int)(ut & 1023u) + k - kr * nx;
         // owner of the tile = the job of the first link that has one there
         bool prior = false;
         if (lane < lo - b * L) {
@@ -2418,7 +2425,7 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
             const unsigned u2t = s_utile[u2];
             const int n2 = s_jbase[u2 + 1] - s_jbase[u2];
             const int ax0 = u2t & 1023u, ay0 = (u2t >> 10) & 4095u, anx = u2t >> 22;
-            prior = n2 > 0 && tx >= ax0 && tx < ax0 + anx && ty >= ay0 && ty < ay0 + n2 / anx;
+            prior = n2 > 0 && tx >= ax0 && tx < ax0 + anx && ty >= ay0 && (ty - ay0) * anx < n2;  // (n2 = anx x the rows)
         }
         if (__ballot(prior)) continue;
     } else {
@@ -2441,7 +2448,7 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
             const unsigned ut = s_utile[u];
             const int j0 = s_jbase[u], n = s_jbase[u + 1] - j0;
             const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
-            if (n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && ty < ty0 + n / nx) {
+            if (n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && (ty - ty0) * nx < n) {
                 myslot = j0 + (ty - ty0) * nx + (tx - tx0);
                 if (myslot < jcap) myn = jn[myslot];
             }
@@ -2588,7 +2595,7 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
                 const unsigned ut = s_utile[u];
                 const int n = s_jbase[u + 1] - s_jbase[u];
                 const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
-                owned = n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && ty < ty0 + n / nx;
+                owned = n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && (ty - ty0) * nx < n;
             }
             if (__ballot(owned)) continue;
             const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;
