@@ -349,9 +349,53 @@ __device__ __forceinline__ bool tile_occupied(const unsigned char* __restrict__ 
 
 __device__ __forceinline__ int lane_id() { return __lane_id(); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// The value of lane (id ^ K), K a power of two, without LDS (__shfl_xor is a ds_bpermute: an LDS round trip per step of every
+// wave reduction): inside a row of 16 lanes by DPP (quad permutes, a shift either way and a select, a half rotation),
+// across rows by gfx950's v_permlane16_swap / v_permlane32_swap (both operands the value itself: one result holds the
+// even rows / lower half twice, the other the odd rows / upper half twice; a lane takes the one it is not in).
+#ifndef EHR_DPP_XOR
+#define EHR_DPP_XOR 1  // 0: __shfl_xor (the A/B reference)
+#endif
+template <int K>
+__device__ __forceinline__ unsigned wave_xor_u32(unsigned v) {
+#if EHR_DPP_XOR
+    const int iv = (int)v;
+    if (K == 1) return (unsigned)__builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+    if (K == 2) return (unsigned)__builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+    if (K == 4) {
+        const int up = __builtin_amdgcn_update_dpp(iv, iv, 0x104, 0xf, 0xf, false);  // row_shl:4: lane i <- lane i + 4
+        const int dn = __builtin_amdgcn_update_dpp(iv, iv, 0x114, 0xf, 0xf, false);  // row_shr:4: lane i <- lane i - 4
+        return (unsigned)((__lane_id() & 4) ? dn : up);
+    }
+    if (K == 8) return (unsigned)__builtin_amdgcn_update_dpp(iv, iv, 0x128, 0xf, 0xf, false);  // row_ror:8
+    if (K == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (__lane_id() & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (__lane_id() & 32) ? r[0] : r[1];
+#else
+    return (unsigned)__shfl_xor((int)v, K, 64);
+#endif
+}
+template <int K>
+__device__ __forceinline__ float wave_xor(float v) { return __uint_as_float(wave_xor_u32<K>(__float_as_uint(v))); }
+template <int K>
+__device__ __forceinline__ int wave_xor(int v) { return (int)wave_xor_u32<K>((unsigned)v); }
+template <int K>
+__device__ __forceinline__ double wave_xor(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = wave_xor_u32<K>((unsigned)u), hi = wave_xor_u32<K>((unsigned)(u >> 32));
+    return __longlong_as_double((long long)((unsigned long long)lo | ((unsigned long long)hi << 32)));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {  // (offsets 32, 16, ..., 1: the order is part of the arithmetic contract)
+    v += wave_xor<32>(v);
+    v += wave_xor<16>(v);
+    v += wave_xor<8>(v);
+    v += wave_xor<4>(v);
+    v += wave_xor<2>(v);
+    v += wave_xor<1>(v);
     return v;
 }
 
@@ -368,23 +412,23 @@ __device__ __forceinline__ float wave_sum12(const float v[12], int lane) {
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const float keep = b32 ? v[6 + i] : v[i], send = b32 ? v[i] : v[6 + i];
-        a[i] = keep + __shfl_xor(send, 32, 64);
+        a[i] = keep + wave_xor<32>(send);
     }
     float b[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         const float keep = b16 ? a[3 + i] : a[i], send = b16 ? a[i] : a[3 + i];
-        b[i] = keep + __shfl_xor(send, 16, 64);
+        b[i] = keep + wave_xor<16>(send);
     }
     // 3 -> (2 | 1): lanes with bit 8 clear keep b[0], b[1]; the others b[2]
-    const float r0 = __shfl_xor(b8 ? b[0] : b[2], 8, 64);  // clear lanes receive b[0], set lanes b[2]
-    const float r1 = __shfl_xor(b[1], 8, 64);              // (only the clear lanes use it)
+    const float r0 = wave_xor<8>(b8 ? b[0] : b[2]);  // clear lanes receive b[0], set lanes b[2]
+    const float r1 = wave_xor<8>(b[1]);             // (only the clear lanes use it)
     const float c0 = (b8 ? b[2] : b[0]) + r0, c1 = b[1] + r1;
     // clear lanes: 2 -> 1 over bit 4; set lanes: their one value summed over bit 4
     const float keep = b8 ? c0 : (b4 ? c1 : c0), send = b8 ? c0 : (b4 ? c0 : c1);
-    float d = keep + __shfl_xor(send, 4, 64);
-    d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 1, 64);
+    float d = keep + wave_xor<4>(send);
+    d += wave_xor<2>(d);
+    d += wave_xor<1>(d);
     return d;
 }
 

@@ -177,8 +177,12 @@ __device__ __forceinline__ void mvp_from_pose(const float* Tc, const float* P, c
 // (no store -> barrier -> reload round trip).  red_lds (optional, LDS float[8]) receives a copy of red for a
 // following pose_adam_apply in the same workgroup.
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v += wave_xor<32>(v);
+    v += wave_xor<16>(v);
+    v += wave_xor<8>(v);
+    v += wave_xor<4>(v);
+    v += wave_xor<2>(v);
+    v += wave_xor<1>(v);
     return v;
 }
 template <class GetG, class GetLoss>
@@ -235,15 +239,15 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
     //  c = 2 b32 + b16 of row r ends up in lane r + 16 b16 + 32 b32)
     {
         const bool b32 = lane & 32, b16 = lane & 16;
-        const double a0 = (b32 ? acc[2] : acc[0]) + __shfl_xor(b32 ? acc[0] : acc[2], 32, 64);
-        const double a1 = (b32 ? acc[3] : acc[1]) + __shfl_xor(b32 ? acc[1] : acc[3], 32, 64);
-        double v = (b16 ? a1 : a0) + __shfl_xor(b16 ? a0 : a1, 16, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 4, 64);
+        const double a0 = (b32 ? acc[2] : acc[0]) + wave_xor<32>(b32 ? acc[0] : acc[2]);
+        const double a1 = (b32 ? acc[3] : acc[1]) + wave_xor<32>(b32 ? acc[1] : acc[3]);
+        double v = (b16 ? a1 : a0) + wave_xor<16>(b16 ? a0 : a1);
+        v += wave_xor<8>(v);
+        v += wave_xor<4>(v);
         if ((lane & 12) == 0) S[wave][4 * (lane & 3) + 2 * (b32 ? 1 : 0) + (b16 ? 1 : 0)] = v;
     }
     {
-        const double s = la_lanes_0_32 ? la + __shfl_xor(la, 32, 64) : wave_sum_f64(la);
+        const double s = la_lanes_0_32 ? la + wave_xor<32>(la) : wave_sum_f64(la);
         if (lane == 0) S[wave][16] = s;
     }
     __syncthreads();

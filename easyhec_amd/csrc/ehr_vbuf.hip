@@ -498,14 +498,17 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     }
     const bool ne = x0 <= x1;
     int a = ne ? x0 : INT_MAX, bq = ne ? y0 : INT_MAX, cc = ne ? x1 : -1, d = ne ? y1 : -1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a = min(a, __shfl_xor(a, off, 64));
-        bq = min(bq, __shfl_xor(bq, off, 64));
-        cc = max(cc, __shfl_xor(cc, off, 64));
-        d = max(d, __shfl_xor(d, off, 64));
-    }
-    if (lane == 0) {
+    // the cluster's box: a DPP reduction (four shifts inside the rows of 16 lanes, then the rows' results upwards: lane 63
+    // ends up with everything; integers, so the order is free), no LDS
+#define VB_BOX_STEP(ctrl, rows)                                                    \
+    a = min(a, __builtin_amdgcn_update_dpp(a, a, ctrl, rows, 0xf, false));        \
+    bq = min(bq, __builtin_amdgcn_update_dpp(bq, bq, ctrl, rows, 0xf, false));    \
+    cc = max(cc, __builtin_amdgcn_update_dpp(cc, cc, ctrl, rows, 0xf, false));    \
+    d = max(d, __builtin_amdgcn_update_dpp(d, d, ctrl, rows, 0xf, false));
+    VB_BOX_STEP(0x111, 0xf) VB_BOX_STEP(0x112, 0xf) VB_BOX_STEP(0x114, 0xf) VB_BOX_STEP(0x118, 0xf)
+    VB_BOX_STEP(0x142, 0xa) VB_BOX_STEP(0x143, 0xc)
+#undef VB_BOX_STEP
+    if (lane == 63) {
         const bool cne = cvalid && a <= cc;
         if (cvalid) rc.cbox[(size_t)b * cl.NC + c] = cne ? vb_pack_box(a, bq, cc, d) : VB_BOX_EMPTY;
         if (cne && lv) {  // link box: merged over everything this workgroup sees (LDS), published once at the end
