@@ -383,6 +383,12 @@ __device__ __forceinline__ float wave_xor(float v) { return __uint_as_float(wave
 template <int K>
 __device__ __forceinline__ int wave_xor(int v) { return (int)wave_xor_u32<K>((unsigned)v); }
 template <int K>
+__device__ __forceinline__ long long wave_xor(long long v) {
+    const unsigned long long u = (unsigned long long)v;
+    const unsigned lo = wave_xor_u32<K>((unsigned)u), hi = wave_xor_u32<K>((unsigned)(u >> 32));
+    return (long long)((unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+template <int K>
 __device__ __forceinline__ double wave_xor(double v) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
     const unsigned lo = wave_xor_u32<K>((unsigned)u), hi = wave_xor_u32<K>((unsigned)(u >> 32));

@@ -101,8 +101,11 @@ __device__ __forceinline__ void finish_body(const BinGeom& g, int B, const long 
                 const int b = base + 8 * j + (tid >> 5);
                 if (base + 8 * j >= B) break;  // (workgroup-uniform)
                 long long s = s4[j];
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                s += wave_xor<16>(s);  // (the 32 slots of a view: half a wave)
+                s += wave_xor<8>(s);
+                s += wave_xor<4>(s);
+                s += wave_xor<2>(s);
+                s += wave_xor<1>(s);
                 if (k == 0 && b < B) {
                     const float lv = bad ? nanv : fix_get(s + (vtot ? vtot[b] : 0ll));
                     loss[b] = lv;
