@@ -599,7 +599,8 @@ struct VbRegion {
 // of the camera.  The others (kind 2: edge-on slivers, geometry at the far plane) take the same walker, but their
 // units do not enter the bitmap: they are always depth tested, and a pixel that passes sets its coverage bit then.
 #define VB_SPAN_GW 4                   // boxes from this many 4-pixel units per row are walked by rows (solved spans), not by units
-constexpr int VB_DL = 768;             // deferred units per wave (LDS); a full list is flushed against the partial coverage
+constexpr int VB_DL = 640;             // deferred units per wave (LDS); a full list is flushed against the partial coverage
+constexpr int VB_SQ = 256;             // ring of culling survivors per wave (LDS): a whole group of candidate clusters' worth
 constexpr unsigned VB_ID_COVERED = 0xfffffffeu;  // published id of a covered pixel whose triangle nobody will ask for
 constexpr u64 VB_ROW_MASK = (1ull << VB_RW) - 1ull;
 
@@ -617,11 +618,12 @@ struct alignas(16) VbWaveLds {   // per wave of the job kernel
     u64 intr[VB_RH];             // rounds: covered pixels whose four neighbours are covered too (as of the round's start)
     VbRaster R;
     unsigned dl[VB_DL];          // deferred units: pixel (9 bits) | 4-bit coverage << 9 | R.ent
-    unsigned sq[128];            // survivors of the box culling waiting for a full round: record slots (ring)
+    unsigned sq[VB_SQ];          // survivors of the box culling waiting for a full round: record slots (ring)
     int bad;                     // scoring op: a flagged unit's pixel was drawn with a depth <= 0 (coverage cannot decide)
 #ifdef VB_TIMELINE
     int tl_units, tl_rounds;     // profiling build: 4-pixel units walked / rounds run by this wave
     int tl_flushes, tl_tested, tl_deferred;
+    int tl_cands, tl_groups;     // candidate clusters / groups of them (one round trip each)
     long long tl_c[8];           // cycles: staging, prefix + search, walk, flush, job total, claim + set-up, publish, -
 #endif
 };
@@ -1207,11 +1209,8 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 #ifndef VB_CULL_BATCHES
 #define VB_CULL_BATCHES 2  // batches of 64 cluster boxes requested together
 #endif
-#ifndef VB_CULL_STASH
-#define VB_CULL_STASH 1  // 0: the group's masks and cluster numbers in scalar registers (the form up to round 5's r05_d)
-#endif
 #ifndef VB_CULL_GROUP
-#define VB_CULL_GROUP (VB_CULL_STASH ? 8 : 4)  // candidate clusters whose triangle boxes are requested together
+#define VB_CULL_GROUP 8  // candidate clusters whose triangle boxes are requested together
 #endif
 struct VbJobArgs {
     VbRecs rc;
@@ -1285,81 +1284,89 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
                 cm = mine;
             }
             while (cm) {  // wave-uniform
-#if VB_CULL_STASH
-                // The group's cluster numbers and survivor masks wait in the LANES of three vector registers (lane k: entry
-                // k) instead of 3 x VB_CULL_GROUP scalar registers that would have to live across the rasterizer rounds.
-                int ccv = 0, ng = 0;
+                // A group of up to VB_CULL_GROUP candidate clusters: their triangle boxes in one round trip, the survivors
+                // of ALL of them pushed in one unrolled pass when the ring has room for them (the rule: the ring holds 256),
+                // then as many rounds as are full.  Masks and cluster numbers are scalar registers that die before the
+                // first round starts.  (Per cluster -- read the mask back, test, push, count, test for a round -- the loop
+                // was ~30 instructions x 33 k candidates a step, and 25 of the 94 kcycles of the jobs the kernel ends on.)
+                // Only when the ring cannot take the whole group do they wait in the LANES of three vector registers
+                // (lane k: entry k) and go in one by one, a round whenever 64 are waiting.
+                int ccv = 0, ng = 0, knext = 0;
                 unsigned mlo = 0, mhi = 0;
+#ifdef VB_TIMELINE
+                const long long tl_g0 = __builtin_readcyclecounter();
+#endif
                 {
+                    int cks[VB_CULL_GROUP];
                     uint2 tb[VB_CULL_GROUP];
 #pragma unroll
                     for (int k = 0; k < VB_CULL_GROUP; k++) {
                         tb[k] = VB_BOX_EMPTY;
+                        cks[k] = 0;
                         if (cm) {
-                            const int c = cbase + __ffsll((unsigned long long)cm) - 1;
+                            cks[k] = cbase + __ffsll((unsigned long long)cm) - 1;
                             cm &= cm - 1;
-                            ccv = (lane == k) ? c : ccv;
-                            tb[k] = A.rc.tbox[vbase + (size_t)c * 64 + lane];
+                            tb[k] = A.rc.tbox[vbase + (size_t)cks[k] * 64 + lane];
                             ng = k + 1;
                         }
                     }
+                    u64 mk[VB_CULL_GROUP];
+                    int total = 0;
 #pragma unroll
                     for (int k = 0; k < VB_CULL_GROUP; k++) {
+                        mk[k] = 0;
                         if (k < ng) {
-                            const u64 m = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
-                                                   (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
-                            mlo = (lane == k) ? (unsigned)m : mlo;
-                            mhi = (lane == k) ? (unsigned)(m >> 32) : mhi;
+                            mk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
+                                             (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
+                            total += __popcll(mk[k]);
                         }
                     }
-                }
-#pragma nounroll
-                for (int k = 0; k < ng; k++) {
-                    const u64 sm = (u64)(unsigned)__builtin_amdgcn_readlane((int)mlo, k) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)mhi, k) << 32);
-                    const int ck = __builtin_amdgcn_readlane(ccv, k);
-#else
-                int cc[VB_CULL_GROUP];
-                uint2 tb[VB_CULL_GROUP];
-#pragma unroll
-                for (int k = 0; k < VB_CULL_GROUP; k++) {
-                    cc[k] = -1;
-                    tb[k] = VB_BOX_EMPTY;
-                    if (cm) {
-                        cc[k] = cbase + __ffsll((unsigned long long)cm) - 1;
-                        cm &= cm - 1;
-                        tb[k] = A.rc.tbox[vbase + (size_t)cc[k] * 64 + lane];
+#ifdef VB_TIMELINE
+                    if (lane == 0) {
+                        W_.tl_c[7] += __builtin_readcyclecounter() - tl_g0;
+                        W_.tl_cands += ng;
+                        W_.tl_groups += 1;
                     }
-                }
-                u64 smk[VB_CULL_GROUP];
-#pragma unroll
-                for (int k = 0; k < VB_CULL_GROUP; k++)
-                    smk[k] = __ballot((tb[k].x & 0xffffu) <= (rhi & 0xffffu) && (tb[k].y & 0xffffu) >= (rlo & 0xffffu) &&
-                                      (tb[k].x >> 16) <= (rhi >> 16) && (tb[k].y >> 16) >= (rlo >> 16));
-                // not unrolled: one copy of the rasterizer round per call site (the kernel was 69 KB of code, more
-                // than the instruction cache two CUs share)
-#pragma nounroll
-                for (int k = 0; k < VB_CULL_GROUP; k++) {
-                    u64 sm = smk[0];
-                    int ck = cc[0];
-#pragma unroll
-                    for (int kk = 1; kk < VB_CULL_GROUP; kk++)
-                        if (k == kk) {
-                            sm = smk[kk];
-                            ck = cc[kk];
-                        }
 #endif
-                    if (!sm) continue;  // wave-uniform (an unused batch entry holds the empty box)
-                    if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & 127] = (unsigned)(ck * 64 + lane);
-                    qn += __popcll(sm);
+                    if (total == 0) continue;
                     drawn = true;
-                    if (qn >= 64) {
+                    if (qn + total <= VB_SQ) {
+#pragma unroll
+                        for (int k = 0; k < VB_CULL_GROUP; k++) {
+                            if (mk[k]) {
+                                if ((mk[k] >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(mk[k])) & (VB_SQ - 1)] = (unsigned)(cks[k] * 64 + lane);
+                                qn += __popcll(mk[k]);
+                            }
+                        }
+                        knext = ng;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < VB_CULL_GROUP; k++) {
+                            ccv = (lane == k) ? cks[k] : ccv;
+                            mlo = (lane == k) ? (unsigned)mk[k] : mlo;
+                            mhi = (lane == k) ? (unsigned)(mk[k] >> 32) : mhi;
+                        }
+                    }
+                }
+                for (;;) {
+                    // not unrolled, one call site: one copy of the rasterizer round (the kernel was 69 KB of code, more
+                    // than the instruction cache two CUs share)
+                    while (qn >= 64) {
                         VB_WAVE_SYNC();
-                        const unsigned sl = W_.sq[(qh + lane) & 127];
+                        const unsigned sl = W_.sq[(qh + lane) & (VB_SQ - 1)];
                         dln = vb_raster_round<WIDE, COVER>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
                         if (dln < 0) return -1;
                         if (full) return 1;  // every pixel of the region is interior: nothing can change any more
-                        qh = (qh + 64) & 127;
+                        qh = (qh + 64) & (VB_SQ - 1);
                         qn -= 64;
+                    }
+                    if (knext >= ng) break;
+                    const u64 sm = (u64)(unsigned)__builtin_amdgcn_readlane((int)mlo, knext) | ((u64)(unsigned)__builtin_amdgcn_readlane((int)mhi, knext) << 32);
+                    const int ck = __builtin_amdgcn_readlane(ccv, knext);
+                    knext++;
+                    if (sm) {
+                        if ((sm >> lane) & 1) W_.sq[(qh + qn + vb_mbcnt(sm)) & (VB_SQ - 1)] = (unsigned)(ck * 64 + lane);
+                        qn += __popcll(sm);
                     }
                 }
             }
@@ -1368,7 +1375,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
     if (qn) {
         VB_WAVE_SYNC();
         const bool sv = lane < qn;
-        const unsigned sl = sv ? W_.sq[(qh + lane) & 127] : srel0;
+        const unsigned sl = sv ? W_.sq[(qh + lane) & (VB_SQ - 1)] : srel0;
         dln = vb_raster_round<WIDE, COVER>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
         if (dln < 0) return -1;
     }
@@ -1676,7 +1683,7 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
 __device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWaveLds& S, u64* key, const u64* cov, size_t slot,
                                                     int b, int rx0, int ry0) {
     const int lane = lane_id();
-    static_assert(2 * VB_RN <= VB_DL, "ids + hit list live in the deferred list's storage");
+    static_assert(VB_RN <= VB_DL && 2 * VB_RN * sizeof(unsigned short) <= sizeof(VbRaster), "ids live in the deferred list's storage, the hit list in the rounds' staging area");
     VB_WAVE_SYNC();
     u64 C[VB_WORDS];
     unsigned idw[VB_WORDS];
@@ -1698,7 +1705,7 @@ __device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWa
         const unsigned i = 64u * k + lane;
         if (i < (unsigned)VB_RN) ids[i] = idw[k];
     }
-    vb_resolve_job(Q, ids, reinterpret_cast<float*>(key), reinterpret_cast<unsigned short*>(S.dl + VB_RN), C, slot, b, rx0, ry0);
+    vb_resolve_job(Q, ids, reinterpret_cast<float*>(key), reinterpret_cast<unsigned short*>(&S.R), C, slot, b, rx0, ry0);
     VB_WAVE_SYNC();
 }
 
@@ -2007,7 +2014,7 @@ vb_job_kernel(VbJobParams prm_) {
     const int tl_hcost = (wave == 0) ? lds_all[0].tl_flushes : 0;
     VB_WAVE_SYNC();
     if (lane == 0) {
-        S.tl_units = S.tl_rounds = S.tl_flushes = S.tl_tested = S.tl_deferred = 0;
+        S.tl_units = S.tl_rounds = S.tl_flushes = S.tl_tested = S.tl_deferred = S.tl_cands = S.tl_groups = 0;
         for (int k = 0; k < 8; k++) S.tl_c[k] = 0;
     }
 #endif
@@ -2178,6 +2185,7 @@ vb_job_kernel(VbJobParams prm_) {
         for (int k = 0; k < 4; k++) tx[3 + k] = S.tl_c[k];
         tx[7] = tl_hcost;
         for (int k = 0; k < 3; k++) tx[8 + k] = S.tl_c[4 + k];
+        tx[11] = (S.tl_c[7] & 0xffffffffll) | ((long long)S.tl_cands << 32) | ((long long)S.tl_groups << 48);
     }
 #else
     
@@ -3004,10 +3012,10 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                 const long long x = tl[4 * i + 3];
                 const unsigned hw = (unsigned)(x >> 32) & 0xffff;
                 const long long* tx = &tl[4 * (size_t)nw + 12 * i];
-                fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; %lld units in %lld rounds ; %lld flushes: %lld of %lld units tested ; kcycles stage %.0f search %.0f walk %.0f flush %.0f resolve %.0f ; xcc %lld cu %u simd %u\n", i, i / 4,
+                fprintf(stderr, "   %5d (%4d): %5.1f %5.1f %5.1f ; %lld jobs, %lld / %lld ; %lld units in %lld rounds ; %lld flushes: %lld of %lld units tested ; kcycles stage %.0f search %.0f walk %.0f flush %.0f resolve %.0f total %.0f cull-wait %.0f (%lld clusters, %lld groups) ; xcc %lld cu %u simd %u\n", i, i / 4,
                         (tl[4 * i] - t0) * 0.01, (tl[4 * i + 2] - t0) * 0.01, (tl[4 * i + 1] - t0) * 0.01, x & 0xff, (x >> 8) & 0xfff,
                         (x >> 20) & 0xfff, tx[0], tx[1], tx[2] & 0xffff, (tx[2] >> 16) & 0xffffff, tx[2] >> 40, tx[3] * 1e-3, tx[4] * 1e-3, tx[5] * 1e-3,
-                        tx[6] * 1e-3, tx[10] * 1e-3, (x >> 48) & 0xf, (hw >> 8) & 15, (hw >> 4) & 3);
+                        tx[6] * 1e-3, tx[10] * 1e-3, tx[8] * 1e-3, (tx[11] & 0xffffffffll) * 1e-3, (tx[11] >> 32) & 0xffff, (tx[11] >> 48) & 0xffff, (x >> 48) & 0xf, (hw >> 8) & 15, (hw >> 4) & 3);
             }
             long long mx = 0, sum = 0;
             int used = 0;
@@ -3020,7 +3028,8 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
             {
                 long long us = 0, rs = 0, umax = 0;
                 long long fl = 0, te = 0, de = 0;
-                double cyc[4] = {0, 0, 0, 0}, jc[3] = {0, 0, 0};
+                double cyc[4] = {0, 0, 0, 0}, jc[3] = {0, 0, 0}, cw = 0;
+                long long ncand = 0, ngrp = 0;
                 for (int i = 0; i < nw; i++) {
                     const long long* tx = &tl[4 * (size_t)nw + 12 * i];
                     us += tx[0];
@@ -3031,6 +3040,9 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                     de += tx[2] >> 40;
                     for (int k = 0; k < 4; k++) cyc[k] += (double)tx[3 + k];
                     for (int k = 0; k < 3; k++) jc[k] += (double)tx[8 + k];
+                    cw += (double)(tx[11] & 0xffffffffll);
+                    ncand += (tx[11] >> 32) & 0xffff;
+                    ngrp += (tx[11] >> 48) & 0xffff;
                 }
                 fprintf(stderr, "[ehr timeline] single-wave jobs: %lld units in %lld rounds (%.0f units per round), at most %lld units on one wave\n", us, rs, rs ? (double)us / rs : 0.0, umax);
                 {   // heavy phase: cost of the job a workgroup shared vs the time it took
@@ -3045,7 +3057,7 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                     if (!hp.empty()) fprintf(stderr, " (%.1f, %lld)", hp.back().first * 0.01, hp.back().second);
                     fprintf(stderr, "\n");
                 }
-                fprintf(stderr, "[ehr timeline] single-wave jobs (drawn ones): %.1f wave-Mcycles in total, claim + set-up %.1f, publish / resolve %.1f\n", jc[0] * 1e-6, jc[1] * 1e-6, jc[2] * 1e-6);
+                fprintf(stderr, "[ehr timeline] single-wave jobs (drawn ones): %.1f wave-Mcycles in total, claim + set-up %.1f, publish / resolve %.1f; triangle boxes of %lld candidate clusters in %lld groups: %.1f waiting\n", jc[0] * 1e-6, jc[1] * 1e-6, jc[2] * 1e-6, ncand, ngrp, cw * 1e-6);
                 fprintf(stderr, "[ehr timeline] flushes %lld, deferred units %lld, depth-tested units %lld; wave-Mcycles: staging %.1f, prefix+search %.1f, walk %.1f, flush %.1f (of %.1f in total)\n",
                         fl, de, te, cyc[0] * 1e-6, cyc[1] * 1e-6, cyc[2] * 1e-6, cyc[3] * 1e-6, busy * 0.01 * 2100.0 * 1e-6);
             }
