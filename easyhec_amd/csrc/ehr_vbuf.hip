@@ -219,7 +219,7 @@ __device__ __forceinline__ VbEdges vb_edges(int X0, int Y0, int X1, int Y1, int 
 struct VbRecs {
     uint2* tbox;   // [B][NC][64] pixel box, VB_BOX_EMPTY if the triangle cannot cover a pixel centre
     uint2* cbox;   // [B][NC] union over the cluster
-    int4* trec;    // [2][B][NC][64]: component-major, so that consecutive slots read consecutive 16-byte words
+    int4* trec;    // [B][NC][64][2]: the two halves of a record side by side
     size_t n;      // B * NC * 64 (component stride)
 };
 
@@ -493,8 +493,8 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     const size_t slot = ((size_t)b * cl.NC + (cvalid ? c : 0)) * 64 + lane;
     if (cvalid) rc.tbox[slot] = vb_pack_box(x0, y0, x1, y1);
     if (cvalid && x0 <= x1) {
-        rc.trec[slot] = r0;
-        rc.trec[rc.n + slot] = r1;
+        rc.trec[2 * slot] = r0;  // (the two halves side by side: one 32-byte piece of a cache line per triangle)
+        rc.trec[2 * slot + 1] = r1;
     }
     const bool ne = x0 <= x1;
     int a = ne ? x0 : INT_MAX, bq = ne ? y0 : INT_MAX, cc = ne ? x1 : -1, d = ne ? y1 : -1;
@@ -785,8 +785,8 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
     int4 r0 = make_int4(0, 0, 0, 0), r1 = r0;
     if (sv) {
         bx = rc.tbox[slot];
-        r0 = rc.trec[slot];
-        r1 = rc.trec[rc.n + slot];
+        r0 = rc.trec[2 * slot];
+        r1 = rc.trec[2 * slot + 1];
     }
     // Interior of the coverage so far: covered pixels whose four neighbours (inside the region) are covered too.  Nobody
     // will ever ask which triangle is visible there, and coverage cannot change there: a triangle whose box lies inside
