@@ -616,6 +616,7 @@ struct alignas(16) VbWaveLds {   // per wave of the job kernel
     u64 cov[VB_RH];              // coverage bitmap, one word per region row (bit x = region column x)
     u64 need[VB_RH];             // flush: covered pixels with an uncovered 4-neighbour
     u64 intr[VB_RH];             // rounds: covered pixels whose four neighbours are covered too (as of the round's start)
+    u64 intr_and[3][VB_RH];      // ... AND-ed over the rows r .. r + 2^k - 1 (k = 1, 2, 3; past the last row: all ones)
     VbRaster R;
     unsigned dl[VB_DL];          // deferred units: pixel (9 bits) | 4-bit coverage << 9 | R.ent
     unsigned sq[VB_SQ];          // survivors of the box culling waiting for a full round: record slots (ring)
@@ -802,6 +803,19 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             in = COVER ? (c & VB_ROW_MASK) : (c & ((c >> 1) | (1ull << (VB_RW - 1))) & ((c << 1) | 1ull) & up & dn & VB_ROW_MASK);
             S.intr[lane] = in;
         }
+        {
+            // a sparse table over the rows (lanes 0-9 hold the rows; lanes 10-15 the identity): "is this box inside the
+            // interior" is then two reads and an AND per triangle instead of a pass over all ten rows
+            unsigned lo = (lane < VB_RH) ? (unsigned)in : 0xffffffffu, hi = (lane < VB_RH) ? (unsigned)(in >> 32) : 0xffffffffu;
+#define VB_ROWS_AND(k, ctrl)                                                                              \
+    lo &= (unsigned)__builtin_amdgcn_update_dpp(-1, (int)lo, ctrl, 0xf, 0xf, false);                      \
+    hi &= (unsigned)__builtin_amdgcn_update_dpp(-1, (int)hi, ctrl, 0xf, 0xf, false);                      \
+    if (lane < VB_RH) S.intr_and[k][lane] = (u64)lo | ((u64)hi << 32);
+            VB_ROWS_AND(0, 0x101)  // row_shl:1: lane i <- lane i + 1
+            VB_ROWS_AND(1, 0x102)  // row_shl:2
+            VB_ROWS_AND(2, 0x104)  // row_shl:4
+#undef VB_ROWS_AND
+        }
         if (__ballot(lane < VB_RH && in != VB_ROW_MASK) == 0) {
             full = true;
             return n;
@@ -830,11 +844,11 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             const u64 bm = ((1ull << bw) - 1ull) << (cx0 - rx0);
             bool hidden = has_in;
             if (has_in) {
-#pragma unroll
-                for (int r = 0; r < VB_RH; r++) {
-                    const bool mine = (unsigned)(r - (cy0 - ry0)) < (unsigned)bh;
-                    hidden = hidden && (!mine || (S.intr[r] & bm) == bm);
-                }
+                // rows y0 .. y0 + bh - 1 = the 2^k rows from y0 and the 2^k rows up to the last, k = floor(log2(bh))
+                const int y0r = cy0 - ry0, k = 31 - __clz(bh);
+                const u64* const tab = (k == 0) ? S.intr : S.intr_and[k - 1];
+                const u64 all = tab[y0r] & tab[y0r + bh - (1 << k)];
+                hidden = (all & bm) == bm;
             }
             // a box of VB_SPAN_GW or more units per row goes to the span walker: work = its rows
             if (!hidden) {
