@@ -884,7 +884,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
         const int K = (Stot + 63) >> 6;
         const int start = __mul24(lane, K), end = min(start + K, Stot);
         int j = 0, bw = 1, bh = 1, gw = 1, gx = 0, dy = 0, crow = 0, ccol0 = 0;
-        unsigned eb = 0;
+        unsigned eb = 0, lastm = 15u;  // lastm: the pixels of a row's last unit that lie inside the box
         int e0 = -1, e1 = -1, e2 = -1, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0, er0 = 0, er1 = 0, er2 = 0;
 #if VB_FAST_SEARCH
         // Which triangle does a lane start in?  Asked the other way round: triangle j's units begin at pre[j]; the first
@@ -922,6 +922,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             bw = (b4 >> 16) & 255;
             bh = b4 >> 24;
             gw = (bw + 3) >> 2;
+            lastm = (1u << (bw - 4 * (gw - 1))) - 1u;
             eb = R.ent[j];
             const unsigned w0 = R.dxy[j][0], w1 = R.dxy[j][1], w2 = R.dxy[j][2];
             sx0 = -16 * (int)(short)(w0 >> 16); sy0 = 16 * (int)(short)(w0 & 0xffffu);
@@ -963,10 +964,13 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                     const int a1 = e0 + sx0, a2 = a1 + sx0, a3 = a2 + sx0;
                     const int b1 = e1 + sx1, b2 = b1 + sx1, b3 = b2 + sx1;
                     const int c1 = e2 + sx2, c2 = c1 + sx2, c3 = c2 + sx2;
-                    m4 = ((e0 | e1 | e2) >= 0 ? 1u : 0u) | ((a1 | b1 | c1) >= 0 ? 2u : 0u) | ((a2 | b2 | c2) >= 0 ? 4u : 0u) |
-                         ((a3 | b3 | c3) >= 0 ? 8u : 0u);
-                    const int rem = bw - 4 * gx;  // pixels of this unit that lie inside the box
-                    if (rem < 4) m4 &= (1u << rem) - 1u;
+                    // a pixel is inside if none of its three edge values is negative: the four sign bits, funnelled into
+                    // one word by three double-word shifts
+                    unsigned sg = (unsigned)(a3 | b3 | c3) >> 31;
+                    sg = __builtin_amdgcn_alignbit(sg, (unsigned)(a2 | b2 | c2), 31);
+                    sg = __builtin_amdgcn_alignbit(sg, (unsigned)(a1 | b1 | c1), 31);
+                    sg = __builtin_amdgcn_alignbit(sg, (unsigned)(e0 | e1 | e2), 31);
+                    m4 = ~sg & ((gx == gw - 1) ? lastm : 15u);  // (the row's last unit: only its pixels inside the box)
                 }
                 const bool inside = m4 != 0;
                 const u64 m = __ballot(inside);
@@ -1013,6 +1017,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                             bw = (b4 >> 16) & 255;
                             bh = b4 >> 24;
                             gw = (bw + 3) >> 2;
+                            lastm = (1u << (bw - 4 * (gw - 1))) - 1u;
                             eb = R.ent[j];
                             const unsigned w0 = R.dxy[j][0], w1 = R.dxy[j][1], w2 = R.dxy[j][2];
                             sx0 = -16 * (int)(short)(w0 >> 16); sy0 = 16 * (int)(short)(w0 & 0xffffu);
