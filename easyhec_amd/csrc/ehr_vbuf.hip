@@ -599,7 +599,11 @@ struct VbRegion {
 // of the camera.  The others (kind 2: edge-on slivers, geometry at the far plane) take the same walker, but their
 // units do not enter the bitmap: they are always depth tested, and a pixel that passes sets its coverage bit then.
 #define VB_SPAN_GW 4                   // boxes from this many 4-pixel units per row are walked by rows (solved spans), not by units
+#ifdef VB_TIMELINE
+constexpr int VB_DL = 576;             // (profiling build: its per-wave counters need the room -- four workgroups per CU must still fit)
+#else
 constexpr int VB_DL = 640;             // deferred units per wave (LDS); a full list is flushed against the partial coverage
+#endif
 constexpr int VB_SQ = 256;             // ring of culling survivors per wave (LDS): a whole group of candidate clusters' worth
 constexpr unsigned VB_ID_COVERED = 0xfffffffeu;  // published id of a covered pixel whose triangle nobody will ask for
 constexpr u64 VB_ROW_MASK = (1ull << VB_RW) - 1ull;
