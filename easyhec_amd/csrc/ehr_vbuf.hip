@@ -7,7 +7,8 @@
 // project to micro-triangles (median bounding box 8 px, a fifth of the non-empty boxes cover no pixel centre at all), for
 // which building and draining per-tile queues cost more than the coverage tests themselves.  Instead ehr_fused_plan
 // groups every link's triangles ONCE into clusters of 64 spatially close ones (recursive median split of the centroids
-// in object space, valid for every pose), and a step is four or five launches per chunk of views:
+// in object space, valid for every pose), and a step is three launches per chunk of views (a fourth and a fifth only after a
+// step has met a triangle for the general path):
 //
 //   vb_vertex_kernel    [pose forward] + clip-space vertices (posc) + one wave per cluster: transforms the cluster's
 //                       triangles, snaps them, tests small boxes exactly (a triangle that covers no pixel centre is
@@ -24,12 +25,18 @@
 //                       on whole workgroups, its long ones as the waves' static first jobs.
 //   vb_slow_kernel      jobs that met a triangle for the general path: near-plane clipping, 64-bit edges (normally none; the
 //                       solver step launches it only once a step has needed it, see vb_put_aside).
-//   vb_resolve_kernel   one wave per drawn job: covered/uncovered pixel pairs by bit arithmetic on the coverage bitmap,
-//                       silhouette analysis of the hits, the link's 256 antialiased values + the blended pairs -> job slot.
+//   (resolve stage)     covered/uncovered pixel pairs by bit arithmetic on the coverage bitmap, silhouette analysis of the
+//                       hits, the link's 256 antialiased values + the blended pairs -> job slot: done by the job kernel's
+//                       wave for the job it has just drawn, from LDS (vb_resolve_from_lds); vb_resolve_kernel, one wave per
+//                       job, only for the jobs vb_slow_kernel redrew.
 //   vb_composite_kernel one wave per tile that holds a job (every tile without a bound reference mask): sums the links'
 //                       values in link order, clamps, frame loss, mask write, back-propagates the tile's blended pairs
 //                       to 12 numbers per link in the view's fixed-point accumulators; its last-arriving workgroup runs
 //                       the finish stage (accumulators -> loss / grad_mvp [-> pose backward -> Adam]).
+//
+// What runs once per rasterizer round or once per candidate cluster inside vb_job_kernel is kept free of LDS shuffles,
+// integer divisions and searches: wave scans and reductions by DPP / v_permlane*_swap,
+// a lane's first triangle by a scatter and a max-scan, packed hint ids, 24-bit multiplies.
 //
 // An earlier form kept the depth/id image in HBM and resolved visibility with one 64-bit global atomic-min per covered
 // pixel; global atomics execute memory-side on this part (4.6 G/s with raster locality: 272 us for the 1.26 M fragments
