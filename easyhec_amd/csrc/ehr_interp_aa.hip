@@ -21,16 +21,17 @@ __global__ void __launch_bounds__(256) interp_fwd_kernel(const float* __restrict
                                                          const int32_t* __restrict__ tri, int B, int Ba, int V, int T,
                                                          int A, size_t P, float* __restrict__ out, int H, int W,
                                                          const unsigned char* __restrict__ flags) {
-    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= P * B) return;
-    int b = (int)(pix / P);
+    // one workgroup per (image, 32 x 8 tile): grid (tiles in x, tiles in y, images) -- a pixel's coordinates without a
+    // division (the linear form spent ~150 instructions per pixel on a 64-bit and a 32-bit one before it knew its tile)
+    const int ix = (int)blockIdx.x * EHR_FLAG_TW + ((int)threadIdx.x & (EHR_FLAG_TW - 1));
+    const int iy = (int)blockIdx.y * EHR_FLAG_TH + ((int)threadIdx.x / EHR_FLAG_TW);
+    const int b = (int)blockIdx.z;
+    if (ix >= W || iy >= H) return;
+    const size_t pix = (size_t)b * P + (size_t)iy * W + ix;
     float* o = out + pix * A;
-    if (flags) {  // a tile nothing was drawn into: zeros, and `rast` is not read
-        const int rem = (int)(pix - (size_t)b * P), iy = rem / W, ix = rem - iy * W;
-        if (!tile_occupied(flags, b, ix, iy, W, H)) {
-            for (int k = 0; k < A; k++) o[k] = 0.f;
-            return;
-        }
+    if (flags && !flags[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) {  // a tile nothing was drawn into:
+        for (int k = 0; k < A; k++) o[k] = 0.f;                                              // zeros, and `rast` is not read
+        return;
     }
     float4 r = rast[pix];
     int t = float_to_tri(r.w) - 1;
@@ -58,15 +59,14 @@ __global__ void __launch_bounds__(256) interp_grad_kernel(const float* __restric
                                                           int B, int Ba, int V, int T, int A, size_t P,
                                                           float* __restrict__ grad_attr, float4* __restrict__ grad_rast, int H,
                                                           int W, const unsigned char* __restrict__ flags) {
-    size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= P * B) return;
-    int b = (int)(pix / P);
-    if (flags) {  // a tile nothing was drawn into: no gradient, neither `rast` nor dy is read
-        const int rem = (int)(pix - (size_t)b * P), iy = rem / W, ix = rem - iy * W;
-        if (!tile_occupied(flags, b, ix, iy, W, H)) {
-            grad_rast[pix] = make_float4(0.f, 0.f, 0.f, 0.f);
-            return;
-        }
+    const int ix = (int)blockIdx.x * EHR_FLAG_TW + ((int)threadIdx.x & (EHR_FLAG_TW - 1));  // (grid as interp_fwd_kernel's)
+    const int iy = (int)blockIdx.y * EHR_FLAG_TH + ((int)threadIdx.x / EHR_FLAG_TW);
+    const int b = (int)blockIdx.z;
+    if (ix >= W || iy >= H) return;
+    const size_t pix = (size_t)b * P + (size_t)iy * W + ix;
+    if (flags && !flags[((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) {  // a tile nothing was drawn into:
+        grad_rast[pix] = make_float4(0.f, 0.f, 0.f, 0.f);                                    // no gradient, nothing is read
+        return;
     }
     float4 r = rast[pix];
     int t = float_to_tri(r.w) - 1;
@@ -347,8 +347,11 @@ __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ c
     __shared__ float s_alpha[AA_MAXP];     // 0 = nothing lands anywhere
     __shared__ short s_slot[4][AA_TW * AA_TH];  // per pixel: slot of its R, U, L, D pair or -1
     const int tid = threadIdx.x;
-    const int tile = blockIdx.x % (ntx * nty), b = blockIdx.x / (ntx * nty);
-    const int tx0 = (tile % ntx) * AA_TW, ty0 = (tile / ntx) * AA_TH;
+    // grid (tiles in x, tiles in y, images): no division between a workgroup and its tile
+    const int ttx = (int)blockIdx.x, tty = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int tile = tty * ntx + ttx;
+    const int segi = b * ntx * nty + tile;  // the tile's segment of `work`
+    const int tx0 = ttx * AA_TW, ty0 = tty * AA_TH;
     const int lx = tid % AA_TW, ly = tid / AA_TW;
     const int px = tx0 + lx, py = ty0 + ly;
     const size_t P = (size_t)H * W;
@@ -358,14 +361,13 @@ __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ c
         // Pairs need two different triangle ids: a tile that holds no triangle, and none of whose four neighbours does,
         // has no pair and is part of none (its first column / row looks at the left / lower tile, its last at the right /
         // upper one).  Its pixels keep their colour; `rast` is not read.  (workgroup-uniform: five bytes)
-        const int ttx = tile % ntx, tty = tile / ntx;
         const unsigned char* const f = flags + (size_t)b * ntx * nty;
         const bool any = f[tile] | (ttx > 0 ? f[tile - 1] : 0) | (ttx + 1 < ntx ? f[tile + 1] : 0) |
                          (tty > 0 ? f[tile - ntx] : 0) | (tty + 1 < nty ? f[tile + ntx] : 0);
         if (!any) {
             if (in)
                 for (int k = 0; k < C; k++) out[idx * C + k] = color[idx * C + k];
-            if (tid == 0) work[(size_t)blockIdx.x * AA_SEG] = make_int4(0, 0, 0, 0);
+            if (tid == 0) work[(size_t)segi * AA_SEG] = make_int4(0, 0, 0, 0);
             return;
         }
     }
@@ -402,7 +404,7 @@ __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ c
     __syncthreads();
     // ---- 2. analyse them, one per lane
     const int np = s_npair;
-    int4* const seg = work + (size_t)blockIdx.x * AA_SEG;
+    int4* const seg = work + (size_t)segi * AA_SEG;
     for (int i = tid; i < np; i += 256) {
         const unsigned pr = s_pair[i];
         const int qx = tx0 + (int)(pr & 63u) - 1, qy = ty0 + (int)((pr >> 6) & 15u) - 1, d = (int)(pr >> 10);
@@ -512,8 +514,8 @@ int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri
     if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: attr batch %d must be 1 or %d", Ba, B);
     size_t P = (size_t)H * W, n = P * B;
     if (n == 0) return EHR_OK;
-    interp_fwd_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(attr, (const float4*)rast, tri, B, Ba,
-                                                                                  V, T, A, P, out, H, W, tile_flags);
+    interp_fwd_kernel<<<dim3(flag_ntx(W), flag_nty(H), B), EHR_FLAG_TW * EHR_FLAG_TH, 0, (hipStream_t)stream_>>>(
+        attr, (const float4*)rast, tri, B, Ba, V, T, A, P, out, H, W, tile_flags);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }
@@ -526,7 +528,7 @@ int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tr
     if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: attr batch %d must be 1 or %d", Ba, B);
     size_t P = (size_t)H * W, n = P * B;
     if (n == 0) return EHR_OK;
-    interp_grad_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream_>>>(
+    interp_grad_kernel<<<dim3(flag_ntx(W), flag_nty(H), B), EHR_FLAG_TW * EHR_FLAG_TH, 0, (hipStream_t)stream_>>>(
         attr, (const float4*)rast, tri, dy, B, Ba, V, T, A, P, grad_attr, (float4*)grad_rast, H, W, tile_flags);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
@@ -597,9 +599,9 @@ int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, c
     hipStream_t stream = (hipStream_t)stream_;
     size_t n = (size_t)B * H * W;
     if (n == 0) return EHR_OK;
-    aa_fwd_kernel<<<(unsigned)aa_segments(B, H, W), 256, 0, stream>>>(color, (const float4*)rast, (const float4*)pos, tri, opp,
-                                                                      range_mode, B, V, T, H, W, C, (W + AA_TW - 1) / AA_TW,
-                                                                      (H + AA_TH - 1) / AA_TH, out, (int4*)work, tile_flags);
+    aa_fwd_kernel<<<dim3((W + AA_TW - 1) / AA_TW, (H + AA_TH - 1) / AA_TH, B), 256, 0, stream>>>(
+        color, (const float4*)rast, (const float4*)pos, tri, opp, range_mode, B, V, T, H, W, C, (W + AA_TW - 1) / AA_TW,
+        (H + AA_TH - 1) / AA_TH, out, (int4*)work, tile_flags);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }
