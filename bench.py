@@ -105,18 +105,24 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(p, budget_s=10.0):
+def cpu_baseline(p, budget_s=8.0):
     """The CPU oracle (oracle/, kind "port": the reference has no CPU renderer) on the same 8-view batch
-    at the initial pose, fwd+bwd, OpenMP over views: all host cores the oracle can use (`value`) and one thread
-    (`value_1thread`, SURVEY 8d asks for both).  Bounded samples: each leg repeats until ~budget_s of wall time."""
+    at the initial pose, fwd+bwd, OpenMP over the (view, link) images, then rows: every hardware thread the
+    process may use (`value`: os.sched_getaffinity, i.e. the cgroup / affinity limit of the box, stated as `cores`; at most
+    views x links images are in flight), 8 threads (`value_8thread`, one per view: round 5's figure) and one thread
+    (`value_1thread`).  Bounded samples: each leg repeats until ~budget_s of wall time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers
     from oracle import oracle
     verts, tris, toff, voff = helpers.scene_arrays(p["robot"])
     mvp = helpers.mvp_numpy(p["K"], p["H"], p["W"], p["Tc_init"], p["link_poses"])
     ref = p["ref"].cpu().numpy()
-    nthreads = oracle.num_threads()
-    cores = min(nthreads, mvp.shape[0])
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = os.cpu_count() or 1
+    images = mvp.shape[0] * mvp.shape[1]
+    nthreads = max(1, min(allowed, images))
 
     def leg(threads, views):
         oracle.set_num_threads(threads)
@@ -131,12 +137,15 @@ def cpu_baseline(p, budget_s=10.0):
         return reps * views / el, reps, el
 
     fps, reps, el = leg(nthreads, mvp.shape[0])
+    fps8, reps8, el8 = leg(min(8, nthreads), mvp.shape[0])
     fps1, reps1, el1 = leg(1, 1)
-    oracle.set_num_threads(nthreads)
-    return {"value": round(fps, 3), "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "value_1thread": round(fps1, 3), "cpu_model": cpu_model(), "host_cores": os.cpu_count(),
+    oracle.set_num_threads(allowed)
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": int(nthreads), "kind": "port",
+            "value_8thread": round(fps8, 3), "value_1thread": round(fps1, 3), "cpu_model": cpu_model(),
+            "host_cores": os.cpu_count(), "allowed_cores": int(allowed),
             "sample": f"{reps} x ({mvp.shape[0]} views 1280x720, fwd+bwd) of the same batch at the initial pose, {el:.1f} s "
-                      f"wall, OpenMP over views ({cores} threads busy); 1-thread leg: {reps1} x 1 view, {el1:.1f} s; "
+                      f"wall, OpenMP over the {images} (view, link) images then rows ({nthreads} threads); 8-thread leg: "
+                      f"{reps8} x {mvp.shape[0]} views, {el8:.1f} s; 1-thread leg: {reps1} x 1 view, {el1:.1f} s; "
                       "oracle built with gcc -O2 -mfma -ffp-contract=off (oracle/Makefile; not -O3 -march=native: the "
                       "library is built in the CPU container and must run on the GPU box's host)"}
 
@@ -235,7 +244,7 @@ def drop_in_step(p, dev, steps=20):
     tr0 = p["trainer"]
     res = {}
     # three_ops: this repo's optimised mirror of the reference's schedule (renderer.NVDiffrastRenderer); import_swap_only: the
-    # reference's OWN renderer / solver statements with only the import swapped (renderer.ReferenceScheduleRenderer: three
+    # call pattern an import swap alone gives (renderer.NVDiffrastRenderer(plain=True) + RBSolver._forward_per_call: three
     # colour channels, rast_db written, nothing cached or batched) -- the number INTEGRATION.md section 2 promises
     # three_ops_batched: the same three ops called once per step over all (view, link) images (nvdiffrast's range mode)
     for name, fusedflag, refsched, graphs in (("three_ops", False, False, (True,)), ("three_ops_batched", False, "batched", (True,)),

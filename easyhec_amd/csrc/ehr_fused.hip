@@ -91,6 +91,8 @@ int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     head.history_rows = history_rows;
     head.n = near_;
     head.f = far_;
+    head.adam_step = step;
+    head.hstate = (int*)ctx->vb_hstate.ptr;
     StepTail tail;
     tail.K = K;
     tail.link_poses = link_poses;

@@ -183,6 +183,12 @@ struct StepHead {  // inputs of the merged first stage (pose forward inside the 
     float* history;
     int history_rows;
     float n, f;
+    // A REPORTED step (overflow: loss NaN, pose and optimiser untouched -- on every rank of a data-parallel job, the NaN
+    // travels with the exchanged sum) has written the unchanged pose to a row; the next step's head sees that Adam's
+    // counter has not moved since the previous head and takes the same row again: the history keeps one row per EFFECTIVE
+    // step with no host-side rewind (which had to guess which rows to give back).
+    const int* adam_step;  // [1] the optimiser's step counter
+    int* hstate;           // [2] ctx->vb_hstate
 };
 
 

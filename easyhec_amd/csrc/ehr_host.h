@@ -117,6 +117,8 @@ struct ehr_ctx {
     int vb_spill_cap = 0;    // ... in items
     ehr::Scratch vb_refsum;  // cached sums of the bound reference mask: tsum i64 [B][nt] | vtot i64 [B] | flag
     const float* vb_ref = nullptr;  // the reference mask those sums belong to (ehr_fused_bind_ref), or NULL
+    ehr::Scratch vb_hstate;  // i32 [16], survives re-plans: [0] Adam's step counter + 1 as the previous solver step's head saw
+                             // it, [1] whether that head advanced the history cursor, [2] where it left it (a REPORTED step's row is reused)
     // space-explorer scoring (ehr_mask_variance) keeps its own scratch so that it never disturbs a solver plan
     ehr::Scratch sc_counts, sc_offsets, sc_entries, sc_posc;
     size_t sc_entries_cap = 0;
@@ -138,7 +140,7 @@ struct ehr_ctx {
     unsigned long long scratch_moves() const {
         unsigned long long n = 0;
         for (const ehr::Scratch* s : {&counts, &offsets, &entries, &vb_clus, &vb_heavy, &vb_idx, &vb_boxes, &vb_units, &vb_acc,
-                                      &vb_posc, &vb_jobs, &vb_spill, &vb_refsum, &sc_counts, &sc_offsets, &sc_entries, &sc_posc, &sc_clus, &sc_misc})
+                                      &vb_posc, &vb_jobs, &vb_spill, &vb_refsum, &vb_hstate, &sc_counts, &sc_offsets, &sc_entries, &sc_posc, &sc_clus, &sc_misc})
             n += s->moves;
         return n;
     }

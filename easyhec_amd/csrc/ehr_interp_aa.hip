@@ -512,6 +512,7 @@ int ehr_interpolate_fwd(const float* attr, const float* rast, const int32_t* tri
                         int H, int W, float* out, const unsigned char* tile_flags, void* stream_) {
     if (!attr || !rast || !tri || !out) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: NULL tensor");
     if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: attr batch %d must be 1 or %d", Ba, B);
+    if (B > 65535) return fail(EHR_ERR_INVALID, "ehr_interpolate_fwd: %d images in one call (the grid's z extent holds 65535): split the batch", B);
     size_t P = (size_t)H * W, n = P * B;
     if (n == 0) return EHR_OK;
     interp_fwd_kernel<<<dim3(flag_ntx(W), flag_nty(H), B), EHR_FLAG_TW * EHR_FLAG_TH, 0, (hipStream_t)stream_>>>(
@@ -526,6 +527,7 @@ int ehr_interpolate_grad(const float* attr, const float* rast, const int32_t* tr
     if (!attr || !rast || !tri || !dy || !grad_rast)
         return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: NULL tensor");
     if (Ba != 1 && Ba != B) return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: attr batch %d must be 1 or %d", Ba, B);
+    if (B > 65535) return fail(EHR_ERR_INVALID, "ehr_interpolate_grad: %d images in one call (the grid's z extent holds 65535): split the batch", B);
     size_t P = (size_t)H * W, n = P * B;
     if (n == 0) return EHR_OK;
     interp_grad_kernel<<<dim3(flag_ntx(W), flag_nty(H), B), EHR_FLAG_TW * EHR_FLAG_TH, 0, (hipStream_t)stream_>>>(

@@ -557,6 +557,7 @@ int ehr_ctx_destroy(ehr_ctx* c) {
     c->vb_spill.release();
     c->vb_units.release();
     c->vb_refsum.release();
+    c->vb_hstate.release();
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; k++)
@@ -572,7 +573,7 @@ size_t ehr_ctx_scratch_bytes(ehr_ctx* c) {
     if (!c) return 0;
     size_t n = 0;
     for (const Scratch* s : {&c->counts, &c->ranges, &c->rkeys, &c->offsets, &c->entries, &c->vb_clus, &c->vb_heavy, &c->vb_idx, &c->vb_boxes, &c->vb_units,
-                             &c->vb_acc, &c->vb_posc, &c->vb_jobs, &c->vb_spill, &c->vb_refsum, &c->sc_counts, &c->sc_offsets,
+                             &c->vb_acc, &c->vb_posc, &c->vb_jobs, &c->vb_spill, &c->vb_refsum, &c->vb_hstate, &c->sc_counts, &c->sc_offsets,
                              &c->sc_entries, &c->sc_posc, &c->sc_clus, &c->sc_misc})
         n += s->cap;
     return n;
@@ -588,11 +589,15 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     if (!pos || (!tri && T > 0) || !rast) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: NULL tensor");
     if (B <= 0 || V < 0 || T < 0 || H <= 0 || W <= 0) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: bad sizes");
     if (H > 32768 || W > 32768) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: resolution above 32768 is unsupported");
+    if (B > 65535) return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: %d images in one call (a grid extent holds 65535): split the batch", B);
     hipStream_t stream = (hipStream_t)stream_;
-    {   // a call recorded into a stream capture bakes the scratch pointers into the graph: from then on they stay where they are
+    bool capturing = false;
+    {   // a call recorded into a stream capture bakes the scratch pointers into the graph: from then on they stay where they
+        // are, for the life of the context (the graph is the caller's: the library never learns that it was destroyed)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cs);
-        if (cs != hipStreamCaptureStatusNone)
+        capturing = cs != hipStreamCaptureStatusNone;
+        if (capturing)
             for (Scratch* sc : {&ctx->counts, &ctx->offsets, &ctx->entries, &ctx->rkeys, &ctx->ranges}) sc->pinned = true;
     }
     BinGeom g;
@@ -625,6 +630,16 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
         const bool same = ctx->ranges_moves == ctx->ranges.moves && ctx->ranges_last.size() == 2 * (size_t)B &&
                           memcmp(ctx->ranges_last.data(), ranges_host, 2 * (size_t)B * sizeof(int32_t)) == 0;
         if (!same) {
+            // The ranges live in ONE device buffer per context, and a captured graph holds no upload node:
+            // new ranges under a capture would need a copy + a synchronisation on the capturing stream (which invalidates
+            // the capture with an opaque HIP error), and new ranges on a context whose buffer a captured graph reads would
+            // silently change what every later replay rasterizes.  Both are refused by name.
+            if (capturing)
+                return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: these ranges were not seen before the stream capture began; call once "
+                            "with them outside the capture (warm-up), then capture");
+            if (ctx->ranges.pinned && !ctx->ranges_last.empty())
+                return fail(EHR_ERR_INVALID, "ehr_rasterize_fwd: this context's ranges are read by a captured graph; a call with other "
+                            "ranges would change what its replays draw: use a RasterizeCudaContext of its own for them");
             // (from the context's own copy: the caller's array may be gone, or pageable, by the time the copy runs)
             ctx->ranges_last.assign(ranges_host, ranges_host + 2 * (size_t)B);
             ctx->ranges_moves = ~0ull;
@@ -706,9 +721,6 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
     // call after it sees the size and grows the storage.  Otherwise (first calls, new shape, tight storage) synchronise
     // once and grow, like nvdiffrast's own rasterizer.  Inside a stream capture (a torch.cuda.graphs capture of a whole
     // solver step) nothing on the host may wait or reallocate: the call is recorded with the storage as it is.
-    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream, &cap_status);
-    const bool capturing = cap_status != hipStreamCaptureStatusNone;
     if (!capturing) {
         const int slot = ctx->size_slot ^= 1;
         if (!ctx->ev_size[0]) {
@@ -730,7 +742,9 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
         if (wait) {
             EHR_HIP(hipStreamSynchronize(stream));
             size_t total = (size_t)ctx->host_pinned[6 + slot];
-            if (2 * total + 1024 > ctx->entries_cap) {
+            // (storage a captured graph points into stays where it is: raster_tile_kernel's fallback for undersized storage
+            //  renders the frame all the same -- slower, never incomplete)
+            if (2 * total + 1024 > ctx->entries_cap && !ctx->entries.pinned) {
                 size_t want = 2 * total + total / 2 + 4096;
                 if ((rc = ctx->entries.reserve(want * sizeof(int4)))) return rc;
                 ctx->entries_cap = want;

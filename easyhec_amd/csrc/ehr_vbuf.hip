@@ -360,10 +360,22 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
                 head.tc_jac[16 * (tid + 1) + i] = T6[i].d[0];
             }
             if (tid == 0 && head.history && head.hist_row) {  // rb_solver.py:50-51: the pose goes to the next free row
-                const int row = head.hist_row[0];
-                if (row >= 0 && row < head.history_rows) {
+                int row = head.hist_row[0];
+                if (head.hstate && head.adam_step) {
+                    // no Adam step since the previous head: that step was reported, its row (the same pose) is this step's
+                    // (and nobody has moved the cursor either -- a state loaded from outside sets both)
+                    const int t1 = head.adam_step[0] + 1;
+                    if (head.hstate[0] == t1 && head.hstate[1] && head.hstate[2] == row && row > 0) row -= 1;
+                    head.hstate[0] = t1;
+                }
+                const bool adv = row >= 0 && row < head.history_rows;
+                if (adv) {
                     for (int k = 0; k < 6; k++) head.history[6 * row + k] = dofv[k];
                     head.hist_row[0] = row + 1;
+                }
+                if (head.hstate) {
+                    head.hstate[1] = adv ? 1 : 0;
+                    head.hstate[2] = adv ? row + 1 : row;
                 }
             }
         }
@@ -2976,6 +2988,10 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
         vb_pad_kernel<<<(T + 255) / 256, 256>>>(tris, T, (int4*)ctx->vb_idx.ptr);
         vb_pad_kernel<<<(T + 255) / 256, 256>>>(opp, T, (int4*)ctx->vb_idx.ptr + T);
         EHR_LAUNCH_CHECK();
+    }
+    if (!ctx->vb_hstate.ptr) {  // (once per context: a re-plan after a reported step must not forget that step)
+        if ((rc = ctx->vb_hstate.reserve(16 * sizeof(int)))) return rc;
+        EHR_HIP(hipMemset(ctx->vb_hstate.ptr, 0, 16 * sizeof(int)));
     }
     ctx->vb_plan_tris = tris;
     ctx->vb_plan_opp = opp;

@@ -39,21 +39,33 @@ def _require(cond, msg):
 _FLAGS_ATTR = "_ehr_tile_flags"
 
 
+_FLAGS_OF = "_ehr_tile_flags_of"   # (storage address, version counter) of the rasterizer output the flags describe
+
+
+def _attach_flags(rast, flags):
+    # (a `rast` edited in place afterwards -- ids composited into empty tiles, say -- or flags carried onto another tensor's
+    #  storage are not trusted any more: interpolate / antialias then process every pixel)
+    setattr(rast, _FLAGS_ATTR, flags)
+    setattr(rast, _FLAGS_OF, (rast.data_ptr(), rast._version))
+
+
 def _flags_of(rast):
-    f = getattr(rast, _FLAGS_ATTR, None)
-    if f is None:
+    f, of = getattr(rast, _FLAGS_ATTR, None), getattr(rast, _FLAGS_OF, None)
+    if f is None or of is None:
         return None
     B, H, W = rast.shape[0], rast.shape[1], rast.shape[2]
-    ok = f.is_cuda and f.device == rast.device and f.numel() == _lib.lib().ehr_tile_flags_bytes(B, H, W)
+    ok = (f.is_cuda and f.device == rast.device and f.numel() == _lib.lib().ehr_tile_flags_bytes(B, H, W)
+          and of == (rast.data_ptr(), rast._version))
     return f if ok else None
 
 
 def carry_tile_flags(src, dst):
     """Hand ``src``'s tile flags (if any) on to ``dst`` -- a detached or otherwise re-wrapped tensor over the SAME rasterizer
-    output -- and return ``dst``."""
-    f = getattr(src, _FLAGS_ATTR, None)
-    if f is not None and dst.shape[:3] == src.shape[:3]:
+    output (same storage, same version counter) -- and return ``dst``."""
+    f, of = getattr(src, _FLAGS_ATTR, None), getattr(src, _FLAGS_OF, None)
+    if f is not None and of is not None and dst.shape[:3] == src.shape[:3] and dst.data_ptr() == of[0]:
         setattr(dst, _FLAGS_ATTR, f)
+        setattr(dst, _FLAGS_OF, of)
     return dst
 
 
@@ -178,7 +190,7 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
     flags = torch.empty((_lib.lib().ehr_tile_flags_bytes(B, int(resolution[0]), int(resolution[1])),), dtype=torch.uint8,
                         device=pos.device)
     rast, db = _RasterizeFunc.apply(glctx, pos.contiguous(), tri.contiguous(), resolution, ranges, bool(grad_db), flags)
-    setattr(rast, _FLAGS_ATTR, flags)
+    _attach_flags(rast, flags)
     return rast, db
 
 

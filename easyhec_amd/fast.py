@@ -210,18 +210,13 @@ class FusedPoseStep:
         measures the reported -- i.e. not taken -- steps against.  Called wherever the Adam counter is set from outside."""
         self._calls0, self._steps0 = self._calls, int(self.step_t.item())
 
-    def _rewind_history(self):
-        """The reported steps each wrote the (unchanged) pose to a new row of ``history_ops``: give those rows back, so that
-        the history holds one row per EFFECTIVE step (the space explorer samples camera poses from it)."""
+    def _count_reported(self):
+        """How many step() calls since ``mark_counts`` were REPORTED steps (NaN loss: pose, Adam moments and counter
+        untouched).  Their ``history_ops`` rows need no rewinding: the chain's head notices that Adam's counter has not moved
+        since the previous step and writes the (unchanged) pose to the SAME row again, so the history holds one row per
+        effective step on every rank, however late a rank looks (include/ehr.h, ehr_solver_step)."""
         lost = (self._calls - self._calls0) - (int(self.step_t.item()) - self._steps0)
-        if lost > 0:
-            hist = self.model.history_ops
-            row = int(self.hist_row.item())
-            lo = max(0, row - lost)
-            with torch.no_grad():
-                hist[lo:row].zero_()
-                self.hist_row.fill_(lo)
-            self.model._hist_n = None
+        self.model._hist_n = None
         self.mark_counts()
         return max(lost, 0)
 
@@ -273,8 +268,8 @@ class FusedPoseStep:
         with torch.cuda.device(self.glctx.device):
             rc = _lib.lib().ehr_fused_status(self.glctx.handle)
         # (on every rank of a data-parallel job alike, whichever rank's views caused the report: the reduced loss was NaN for
-        #  all of them, none of them stepped, each of them recorded the unchanged pose once per reported step)
-        self._rewind_history()
+        #  all of them, none of them stepped, and each of them kept recording the unchanged pose in one and the same row)
+        self._count_reported()
         if rc == 0:
             return False
         had_graph = bool(self._graph)

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import fused
 from .mesh_io import load_mesh
-from .renderer import NVDiffrastRenderer, ReferenceScheduleRenderer
+from .renderer import NVDiffrastRenderer
 from .se3 import se3_exp_map, se3_log_map
 
 __all__ = ["RBSolver"]
@@ -84,8 +84,8 @@ class RBSolver(nn.Module):
             if dev.type != "cuda":
                 raise RuntimeError("RBSolver renders on a HIP device only: move the module with .cuda() first "
                                    "(there is no CPU render path)")
-            ref_sched = bool(getattr(self.cfg, "reference_schedule", False)) and not self.cfg.use_fused
-            self.renderer = (ReferenceScheduleRenderer if ref_sched else NVDiffrastRenderer)([self.H, self.W], device=dev)
+            plain = bool(getattr(self.cfg, "reference_schedule", False)) and not self.cfg.use_fused
+            self.renderer = NVDiffrastRenderer([self.H, self.W], device=dev, plain=plain)
             self._scene = None
         return self.renderer
 
@@ -168,25 +168,18 @@ class RBSolver(nn.Module):
         loss = ((masks - masks_ref.float()) ** 2).sum(dim=(1, 2)).mean()
         return masks, loss
 
-    def _forward_reference_schedule(self, renderer, Tc_c2b, link_poses, K, masks_ref):
-        """rb_solver.py:58-71 statement by statement (``cfg.model.rbsolver.reference_schedule``): per frame, per link
-        ``Tc_c2b @ link_poses[bid, link]`` and one ``render_mask`` call; stack / sum / clamp; SSE; mean over frames."""
-        losses = []
-        all_frame_all_link_si = []
-        batch_size = masks_ref.shape[0]
-        for bid in range(batch_size):
-            all_link_si = []
-            for link_idx in range(self.nlinks):
-                Tc_c2l = Tc_c2b @ link_poses[bid, link_idx]
-                verts, faces = getattr(self, f"vertices_{link_idx}"), getattr(self, f"faces_{link_idx}")
-                si = renderer.render_mask(verts, faces, K=K, object_pose=Tc_c2l)
-                all_link_si.append(si)
-            all_link_si = torch.stack(all_link_si).sum(0).clamp(max=1)
-            all_frame_all_link_si.append(all_link_si)
-            loss = torch.sum((all_link_si - masks_ref[bid].float()) ** 2)
-            losses.append(loss)
-        loss = torch.stack(losses).mean()
-        return torch.stack(all_frame_all_link_si), loss
+    def _forward_per_call(self, renderer, Tc_c2b, link_poses, K, masks_ref):
+        """``cfg.model.rbsolver.reference_schedule``: the schedule of rb_solver.py:58-71 with no host-side batching -- one
+        pose product and one ``render_mask`` call (flip included) per (frame, link), the links stacked, summed and clamped
+        per frame, a squared-error sum per frame, their mean."""
+        meshes = [(getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}")) for k in range(self.nlinks)]
+        frames, sse = [], []
+        for f, target in enumerate(masks_ref):
+            layers = torch.stack([renderer.render_mask(v, t, K=K, object_pose=Tc_c2b @ link_poses[f, k])
+                                  for k, (v, t) in enumerate(meshes)])
+            frames.append(layers.sum(0).clamp(max=1))
+            sse.append(((frames[-1] - target.float()) ** 2).sum())
+        return torch.stack(frames), torch.stack(sse).mean()
 
     # -- forward -------------------------------------------------------------------------------------------------
     def forward(self, dps, with_outputs=True):
@@ -215,8 +208,8 @@ class RBSolver(nn.Module):
                                                       want_mask=with_outputs)
             loss = losses.mean()
             all_frame_all_link_si = rendered if with_outputs else None
-        elif isinstance(renderer, ReferenceScheduleRenderer):
-            rendered, loss = self._forward_reference_schedule(renderer, Tc_c2b, link_poses, K, masks_ref)
+        elif renderer.plain:
+            rendered, loss = self._forward_per_call(renderer, Tc_c2b, link_poses, K, masks_ref)
             all_frame_all_link_si = rendered
         elif getattr(self.cfg, "batched_ops", False):
             rendered, loss = self._forward_three_ops_batched(renderer, Tc_c2b, link_poses, K, masks_ref)

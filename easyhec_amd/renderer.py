@@ -10,12 +10,16 @@ import torch
 from . import dr
 from .nvdiffrast_utils import K_to_projection, opencv2blender, transform_pos
 
-__all__ = ["NVDiffrastRenderer", "ReferenceScheduleRenderer"]
+__all__ = ["NVDiffrastRenderer"]
 
 
 class NVDiffrastRenderer:
-    def __init__(self, image_size, device=None):
-        """image_size: H,W"""
+    def __init__(self, image_size, device=None, plain=False):
+        """image_size: H,W.  ``plain=True`` switches every saving of this file off, which leaves the call pattern an import
+        swap alone produces (``cfg.model.rbsolver.reference_schedule``): intrinsics projected and
+        vertices made homogeneous on every call, a three-channel colour, ``rast_db`` written (``grad_db=True``), the
+        rasterizer output fed to ``dr.interpolate`` undetached, no topology handed to ``dr.antialias``."""
+        self.plain = bool(plain)
         self.H, self.W = image_size
         self.resolution = image_size
         self.glctx = dr.RasterizeCudaContext(device=device)
@@ -38,7 +42,7 @@ class NVDiffrastRenderer:
         return ent[2]
 
     def _cached(self, kind, t, make):
-        if not torch.is_tensor(t) or t.requires_grad:
+        if self.plain or not torch.is_tensor(t) or t.requires_grad:
             return make()
         key = (kind, id(t))
         ent = self._const.get(key)
@@ -65,6 +69,9 @@ class NVDiffrastRenderer:
         # proj @ (opencv2blender @ object_pose) with the constant product taken once: opencv2blender = diag(1, -1, -1, 1)
         # only flips signs, so (proj @ o2b) @ pose has the same products and sums, bit for bit, one matmul (and its
         # backward node) less per call
+        if self.plain:  # the three products in the reference's association, nothing kept between calls
+            pos_clip = transform_pos(K_to_projection(K, self.H, self.W) @ (self.opencv2blender @ object_pose), verts)
+            return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
         po = self._cached("po", K, lambda: self._projection(K, verts.device) @ self.opencv2blender)
         pos_clip = self._clip_positions(po @ object_pose, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
@@ -87,12 +94,17 @@ class NVDiffrastRenderer:
 
     def batch_render_mask(self, verts, faces, K, anti_aliasing=True):
         """Vertices already in the camera frame (nvdiffrast_renderer.py:49-72)."""
-        proj = self._projection(K, verts.device)
-        pose = self.opencv2blender
-        pos_clip = self._clip_positions(proj @ pose, verts)
+        pos_clip = self._clip_positions(self._projection(K, verts.device) @ self.opencv2blender, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
     def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing, flip=True):
+        if self.plain:
+            rast, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=[self.H, self.W])
+            if not anti_aliasing:
+                return torch.flip(rast[0, :, :, 2] > 0, dims=[0])
+            rgb = torch.ones((1,) + tuple(verts.shape), dtype=torch.float, device=verts.device)
+            shaded, _ = dr.interpolate(rgb, rast, faces)
+            return torch.flip(dr.antialias(shaded, rast, pos_clip, faces)[0, :, :, 0], dims=[0])
         # (grad_db=False: the reference takes the default and throws rast_db away -- `rast_out, _ = ...`,
         #  nvdiffrast_renderer.py:39 -- so the 16 B per pixel are not written here)
         rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution, grad_db=False)
@@ -109,41 +121,7 @@ class NVDiffrastRenderer:
             color = dr.antialias(color, rast_out, pos_clip, faces, topology_hash=self._topology(faces))
             mask = color.view(color.shape[1], color.shape[2])  # [1, H, W, 1]: a view both ways (indexing = fill + copy in backward)
         else:
-            mask = rast_out[0, :, :, 2] > 0
+            mask = rast_out[0, ..., 2] > 0  # (no antialiasing: a bool mask)
         if flip:
             mask = torch.flip(mask, dims=[0])
-        return mask
-
-
-class ReferenceScheduleRenderer:
-    """The reference's renderer file with ONLY its import swapped: every statement of
-    /root/reference/easyhec/structures/nvdiffrast_renderer.py:10-47 as it stands there -- the projection of K rebuilt per
-    call, ``torch.ones(verts.shape)`` (three channels) per call, ``dr.rasterize`` with its default ``grad_db=True``,
-    ``dr.interpolate`` on the undetached rasterizer output, ``dr.antialias`` without a topology argument, channel 0, flip.
-    Nothing is cached or batched on this side of the ``dr`` boundary; what the library does behind it (it remembers the edge
-    topology of the last few ``tri`` tensors, it never synchronises) is what an import swap gives a maintainer.
-    ``RBSolver(cfg.model.rbsolver.reference_schedule=True)`` drives it with rb_solver.py:58-71's own loop; bench.py reports
-    that step as ``drop_in.import_swap_only_*``."""
-
-    def __init__(self, image_size, device=None):
-        self.H, self.W = image_size
-        self.resolution = image_size
-        self.glctx = dr.RasterizeCudaContext(device=device)
-        self.device = self.glctx.device
-        blender2opencv = opencv2blender(device=self.device)
-        self.opencv2blender = torch.inverse(blender2opencv)
-
-    def render_mask(self, verts, faces, K, object_pose, anti_aliasing=True):
-        proj = K_to_projection(K, self.H, self.W)
-        pose = self.opencv2blender @ object_pose
-        pos_clip = transform_pos(proj @ pose, verts)
-        rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution)
-        if anti_aliasing:
-            vtx_color = torch.ones(verts.shape, dtype=torch.float, device=verts.device)
-            color, _ = dr.interpolate(vtx_color[None, ...], rast_out, faces)
-            color = dr.antialias(color, rast_out, pos_clip, faces)
-            mask = color[0, :, :, 0]
-        else:
-            mask = rast_out[0, :, :, 2] > 0
-        mask = torch.flip(mask, dims=[0])
         return mask

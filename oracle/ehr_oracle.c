@@ -953,6 +953,7 @@ int ehro_render_mask_loss(const float* verts, const int32_t* tris, const int32_t
     /* topology per link (local vertex indices) */
     int32_t** opp = (int32_t**)calloc(L, sizeof(int32_t*));
     int32_t** ltri = (int32_t**)calloc(L, sizeof(int32_t*));
+#pragma omp parallel for schedule(dynamic, 1)
     for (int l = 0; l < L; l++) {
         int Tl = tri_off[l + 1] - tri_off[l];
         ltri[l] = (int32_t*)malloc((size_t)(Tl > 0 ? Tl : 1) * 3 * sizeof(int32_t));
@@ -962,78 +963,103 @@ int ehro_render_mask_loss(const float* verts, const int32_t* tris, const int32_t
     }
     if (grad_mvp) memset(grad_mvp, 0, (size_t)B * L * 16 * sizeof(float));
 
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int b = 0; b < B; b++) {
-        float* si = (float*)malloc((size_t)L * P * sizeof(float)); /* per-link AA masks, GL row order */
+    /* Parallel over the (view, link) IMAGES, then over rows ("OpenMP over (view, link) images then rows"): every
+     * image's chain transform -> rasterize -> colour -> antialias is independent, so a host with more cores than views is
+     * used up to views x links threads.  Results do not depend on the thread count: every image is computed by one thread,
+     * the composite is per pixel, and the frame loss is summed from per-row partial sums in row order. */
+    int Vmax = 1;
+    for (int l = 0; l < L; l++)
+        if (vert_off[l + 1] - vert_off[l] > Vmax) Vmax = vert_off[l + 1] - vert_off[l];
+    float* si_all = (float*)malloc((size_t)B * L * P * sizeof(float));   /* per-(view, link) AA masks, GL row order */
+    float* gimg_all = (float*)malloc((size_t)B * P * sizeof(float));      /* d loss_b / d composite, GL row order */
+    double* rowsum = (double*)malloc((size_t)B * H * sizeof(double));
+    if (!si_all || !gimg_all || !rowsum) {
+        free(si_all); free(gimg_all); free(rowsum);
+        for (int l = 0; l < L; l++) { free(opp[l]); free(ltri[l]); }
+        free(opp); free(ltri);
+        return -2;
+    }
+#pragma omp parallel
+    {
         float* rast = (float*)malloc(P * 4 * sizeof(float));
         float* color = (float*)malloc(P * sizeof(float));
-        float* acc = (float*)malloc(P * sizeof(float));
-        float* gimg = (float*)malloc(P * sizeof(float));
         float* gcol = (float*)malloc(P * sizeof(float));
-        int Vmax = 1;
-        for (int l = 0; l < L; l++)
-            if (vert_off[l + 1] - vert_off[l] > Vmax) Vmax = vert_off[l + 1] - vert_off[l];
         float* pos = (float*)malloc((size_t)Vmax * 4 * sizeof(float));
         float* gpos = (float*)malloc((size_t)Vmax * 4 * sizeof(float));
         float* ones = (float*)malloc((size_t)Vmax * sizeof(float));
         for (int i = 0; i < Vmax; i++) ones[i] = 1.f;
-
-        for (int l = 0; l < L; l++) {
-            int Vl = vert_off[l + 1] - vert_off[l], Tl = tri_off[l + 1] - tri_off[l];
-            const float* M = mvp + ((size_t)b * L + l) * 16;
-            ehro_transform_pos(M, verts + 3 * (size_t)vert_off[l], Vl, pos);
-            ehro_rasterize_fwd(pos, ltri[l], NULL, 1, Vl, Tl, H, W, rast, NULL);
-            if (exact_interp)
-                ehro_interpolate_fwd(ones, rast, ltri[l], 1, 1, Vl, Tl, 1, H, W, color);
-            else
-                for (size_t i = 0; i < P; i++) color[i] = rast[4 * i + 3] != 0.f ? 1.f : 0.f;
-            ehro_antialias_fwd(color, rast, pos, ltri[l], opp[l], 0, 1, Vl, Tl, H, W, 1, si + (size_t)l * P);
-        }
-        /* composite (link order), clamp, loss; image row r = H-1-iy */
-        double lsum = 0.0;
-        for (int iy = 0; iy < H; iy++)
-            for (int ix = 0; ix < W; ix++) {
-                size_t gl = (size_t)iy * W + ix, im = (size_t)(H - 1 - iy) * W + ix;
-                float s = 0.f;
-                for (int l = 0; l < L; l++) s += si[(size_t)l * P + gl];
-                acc[gl] = s;
-                float m = s > 1.f ? 1.f : s;
-                if (mask) mask[(size_t)b * P + im] = m;
-                float e = m - ref[(size_t)b * P + im];
-                lsum += (double)e * (double)e;
-                gimg[gl] = (s <= 1.f) ? 2.f * e : 0.f;
-            }
-        if (loss) loss[b] = (float)lsum;
-
-        if (grad_mvp) {
+#pragma omp for collapse(2) schedule(dynamic, 1)
+        for (int b = 0; b < B; b++)
             for (int l = 0; l < L; l++) {
                 int Vl = vert_off[l + 1] - vert_off[l], Tl = tri_off[l + 1] - tri_off[l];
                 const float* M = mvp + ((size_t)b * L + l) * 16;
-                const float* vl = verts + 3 * (size_t)vert_off[l];
-                ehro_transform_pos(M, vl, Vl, pos);
+                ehro_transform_pos(M, verts + 3 * (size_t)vert_off[l], Vl, pos);
                 ehro_rasterize_fwd(pos, ltri[l], NULL, 1, Vl, Tl, H, W, rast, NULL);
                 if (exact_interp)
                     ehro_interpolate_fwd(ones, rast, ltri[l], 1, 1, Vl, Tl, 1, H, W, color);
                 else
                     for (size_t i = 0; i < P; i++) color[i] = rast[4 * i + 3] != 0.f ? 1.f : 0.f;
-                memset(gpos, 0, (size_t)Vl * 4 * sizeof(float));
-                ehro_antialias_grad(color, rast, pos, ltri[l], opp[l], gimg, 0, 1, Vl, Tl, H, W, 1, gcol, gpos);
-                /* transform_pos backward: dL/dM[r][c] = sum_v gpos[v][r] * [x,y,z,1][c] (accumulated in double) */
-                double G[16];
-                for (int i = 0; i < 16; i++) G[i] = 0.0;
-                for (int v = 0; v < Vl; v++) {
-                    const float* g = gpos + 4 * (size_t)v;
-                    if (g[0] == 0.f && g[1] == 0.f && g[3] == 0.f) continue;
-                    double h[4] = {vl[3 * v], vl[3 * v + 1], vl[3 * v + 2], 1.0};
-                    for (int r = 0; r < 4; r++)
-                        for (int c = 0; c < 4; c++) G[4 * r + c] += (double)g[r] * h[c];
-                }
-                float* out = grad_mvp + ((size_t)b * L + l) * 16;
-                for (int i = 0; i < 16; i++) out[i] = (float)G[i];
+                ehro_antialias_fwd(color, rast, pos, ltri[l], opp[l], 0, 1, Vl, Tl, H, W, 1, si_all + ((size_t)b * L + l) * P);
             }
+        /* composite (link order), clamp, loss; image row r = H-1-iy */
+#pragma omp for collapse(2) schedule(static)
+        for (int b = 0; b < B; b++)
+            for (int iy = 0; iy < H; iy++) {
+                const float* si = si_all + (size_t)b * L * P;
+                double rs = 0.0;
+                for (int ix = 0; ix < W; ix++) {
+                    size_t gl = (size_t)iy * W + ix, im = (size_t)(H - 1 - iy) * W + ix;
+                    float sm = 0.f;
+                    for (int l = 0; l < L; l++) sm += si[(size_t)l * P + gl];
+                    float m = sm > 1.f ? 1.f : sm;
+                    if (mask) mask[(size_t)b * P + im] = m;
+                    float e = m - ref[(size_t)b * P + im];
+                    rs += (double)e * (double)e;
+                    gimg_all[(size_t)b * P + gl] = (sm <= 1.f) ? 2.f * e : 0.f;
+                }
+                rowsum[(size_t)b * H + iy] = rs;
+            }
+#pragma omp single
+        {
+            if (loss)
+                for (int b = 0; b < B; b++) {
+                    double lsum = 0.0;
+                    for (int iy = 0; iy < H; iy++) lsum += rowsum[(size_t)b * H + iy];
+                    loss[b] = (float)lsum;
+                }
         }
-        free(si); free(rast); free(color); free(acc); free(gimg); free(gcol); free(pos); free(gpos); free(ones);
+        if (grad_mvp) {
+#pragma omp for collapse(2) schedule(dynamic, 1)
+            for (int b = 0; b < B; b++)
+                for (int l = 0; l < L; l++) {
+                    int Vl = vert_off[l + 1] - vert_off[l], Tl = tri_off[l + 1] - tri_off[l];
+                    const float* M = mvp + ((size_t)b * L + l) * 16;
+                    const float* vl = verts + 3 * (size_t)vert_off[l];
+                    ehro_transform_pos(M, vl, Vl, pos);
+                    ehro_rasterize_fwd(pos, ltri[l], NULL, 1, Vl, Tl, H, W, rast, NULL);
+                    if (exact_interp)
+                        ehro_interpolate_fwd(ones, rast, ltri[l], 1, 1, Vl, Tl, 1, H, W, color);
+                    else
+                        for (size_t i = 0; i < P; i++) color[i] = rast[4 * i + 3] != 0.f ? 1.f : 0.f;
+                    memset(gpos, 0, (size_t)Vl * 4 * sizeof(float));
+                    ehro_antialias_grad(color, rast, pos, ltri[l], opp[l], gimg_all + (size_t)b * P, 0, 1, Vl, Tl, H, W, 1, gcol, gpos);
+                    /* transform_pos backward: dL/dM[r][c] = sum_v gpos[v][r] * [x,y,z,1][c] (accumulated in double) */
+                    double G[16];
+                    for (int i = 0; i < 16; i++) G[i] = 0.0;
+                    for (int v = 0; v < Vl; v++) {
+                        const float* g = gpos + 4 * (size_t)v;
+                        if (g[0] == 0.f && g[1] == 0.f && g[3] == 0.f) continue;
+                        double h[4] = {vl[3 * v], vl[3 * v + 1], vl[3 * v + 2], 1.0};
+                        for (int r = 0; r < 4; r++)
+                            for (int c = 0; c < 4; c++) G[4 * r + c] += (double)g[r] * h[c];
+                    }
+                    float* out = grad_mvp + ((size_t)b * L + l) * 16;
+                    for (int i = 0; i < 16; i++) out[i] = (float)G[i];
+                }
+        }
+        free(rast); free(color); free(gcol); free(pos); free(gpos); free(ones);
     }
+    free(si_all); free(gimg_all); free(rowsum);
     for (int l = 0; l < L; l++) {
         free(opp[l]);
         free(ltri[l]);

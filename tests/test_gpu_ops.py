@@ -389,6 +389,30 @@ def test_tile_flags_follow_the_rasterizer_and_change_no_result(env, oracle):
     assert (outs[0][0].cpu().numpy() == c_ref).all()
 
 
+def test_tile_flags_are_dropped_when_the_rasterizer_output_is_edited_or_swapped(env):
+    """the flags ride on the `rast` tensor object; they are only believed while that tensor still is the
+    rasterizer's output -- same storage, same version.  An in-place edit (here: a triangle id written into an empty tile) or
+    flags carried onto another tensor must make interpolate look at every pixel again."""
+    dr, _, dev = env
+    ctx = dr.RasterizeCudaContext()
+    H, W = 64, 128
+    rng = np.random.default_rng(3)
+    pos, tri = helpers.random_mesh(rng, 60, shared=True, size=0.1)
+    pos[:, 0] = pos[:, 0] * 0.3 - 0.5 * pos[:, 3]
+    tp, tt = t(pos[None], dev), t(tri, dev)
+    attr = torch.ones((1, pos.shape[0], 1), device=dev)
+    r, _ = dr.rasterize(ctx, tp, tt, [H, W], grad_db=False)
+    assert dr._flags_of(r) is not None and dr._flags_of(dr.carry_tile_flags(r, r.detach())) is not None
+    other = r.clone()
+    assert dr._flags_of(dr.carry_tile_flags(r, other)) is None           # another storage: not carried
+    empty = (r[0, :, :, 3] == 0).nonzero()
+    y, x = int(empty[-1, 0]), int(empty[-1, 1])                          # a pixel of a tile nothing was drawn in
+    r[0, y, x] = torch.tensor([0.25, 0.25, 0.5, 1.0], device=dev)        # triangle 0, edited in place
+    assert dr._flags_of(r) is None
+    c, _ = dr.interpolate(attr, r, tt)
+    assert float(c[0, y, x, 0]) == 1.0                                   # the edited pixel is shaded, not skipped
+
+
 def test_a_context_whose_calls_were_captured_refuses_to_move_its_scratch():
     """a torch.cuda.CUDAGraph that recorded dr.rasterize holds the context's scratch pointers.  A later call
     that would have to GROW that scratch must fail loudly instead of freeing what the graph's replays write into."""
