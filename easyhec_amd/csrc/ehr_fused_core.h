@@ -66,7 +66,8 @@ __device__ __forceinline__ void finish_body(const BinGeom& g, int B, const long 
                                             const long long* __restrict__ vtot, float* __restrict__ loss,
                                             float* __restrict__ grad_mvp, int* __restrict__ meta, const StepTail& tail,
                                             int nls, int* __restrict__ lbox, int lstride, float* vloss /* LDS [256] */,
-                                            double (*S)[17] /* LDS [4][17] */, float* red_lds /* LDS [8] */) {
+                                            double (*S)[17] /* LDS [4][17] */, float* red_lds /* LDS [8] */,
+                                            float (*Js)[16] /* LDS [6][16] */) {
     const int tid = threadIdx.x, L = g.L;
     const int acc_stride = 12 * L + nls * lstride;
     if (lbox)  // the links' screen boxes start "empty" in the next step
@@ -155,7 +156,7 @@ __device__ __forceinline__ void finish_body(const BinGeom& g, int B, const long 
                 for (int e = 0; e < 16; e++) grad_mvp[(size_t)i * 16 + e] = G[e];
         },
         [&](int) { return 0.f; }, tail.K, tail.link_poses, tail.tc_jac, B, L, g.H, g.W, tail.n, tail.f, tail.red, S, red_lds,
-        &la_mine, nls == 32);
+        &la_mine, nls == 32, Js);
     __syncthreads();
     if (!tail.defer_adam)
         pose_adam_apply(st, tail.dof, tail.m, tail.v, tail.step, red_lds, tail.lr, tail.b1, tail.b2, tail.eps, tail.wd,

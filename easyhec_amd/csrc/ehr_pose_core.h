@@ -190,13 +190,14 @@ __device__ __forceinline__ void pose_backward_block_t(GetG get_g, GetLoss get_lo
                                                       const float* __restrict__ link_poses,
                                                       const float* __restrict__ tc_jac, int B, int L, int H, int W,
                                                       float n, float f, float* __restrict__ red, double (*S)[17],
-                                                      float* red_lds, const double* la_pre = nullptr,
-                                                      bool la_lanes_0_32 = false) {
+                                                      float* red_lds, const double* la_pre,
+                                                      bool la_lanes_0_32, float (*Js_lds)[16]) {
     // (la_pre: this thread's share of sum_b loss_b, already known to the caller -- get_loss is not called then;
     //  la_lanes_0_32: only lanes 0 and 32 of a wave hold a share, the wave's sum is one shuffle instead of six)
     // Jacobian rows are needed last but depend on nothing computed here: fetch them first (into LDS, not registers:
     // this body also runs inside the composite kernel, which is compiled for 80 registers)
-    __shared__ float Js[6][16];
+    // (Js_lds: 6 x 16 floats of the caller's LDS -- the merged job kernel has none to spare, it lends a job's work area)
+    float (*const Js)[16] = Js_lds;
     if (threadIdx.x < 96) Js[threadIdx.x >> 4][threadIdx.x & 15] = tc_jac[16 + threadIdx.x];
     float P[16];
     projection(K, H, W, n, f, P);
@@ -270,11 +271,12 @@ __device__ __forceinline__ void pose_backward_block(const float* __restrict__ gr
                                                     const float* __restrict__ K, const float* __restrict__ link_poses,
                                                     const float* __restrict__ tc_jac, int B, int L, int H, int W,
                                                     float n, float f, float* __restrict__ red, double (*S)[17]) {
+    __shared__ float Js[6][16];
     pose_backward_block_t(
         [&](int i, float* G) {
             for (int k = 0; k < 16; k++) G[k] = grad_mvp[(size_t)i * 16 + k];
         },
-        [&](int b) { return loss[b]; }, K, link_poses, tc_jac, B, L, H, W, n, f, red, S, nullptr);
+        [&](int b) { return loss[b]; }, K, link_poses, tc_jac, B, L, H, W, n, f, red, S, nullptr, nullptr, false, Js);
 }
 
 // torch.optim.Adam with L2 weight decay on dof, gradient of the MEAN per-frame loss = red[0..5] / red[7].

@@ -78,7 +78,8 @@ constexpr u64 VB_EMPTY = ~0ull;
 
 // Counters that many waves hit with atomics each get a 128-byte line of their own behind the meta block (atomics on
 // one line serialise memory-side at ~12 ns each): line xcd = job cursor of that XCD.
-#define VB_LINES 24   // 0-7 job cursors of the XCDs, 8-15 composite arrival tickets of the XCDs, 16 the top ticket, 17 jobs put aside for vb_slow_kernel
+#define VB_LINES 36   // 0-7 job cursors of the XCDs, 8-15 composite arrival tickets of the XCDs, 16 the top ticket, 17 jobs put aside for vb_slow_kernel;
+                      // merged kernel: 18-25 "this XCD's workgroups are through their jobs", 26 the same over the XCDs, 27-34 the XCDs' go flags (= generation)
 __host__ __device__ __forceinline__ int* vb_line(int* meta, int k) {
     return (int*)((((uintptr_t)(meta + EHR_META_INTS)) + 127) & ~(uintptr_t)127) + 32 * k;
 }
@@ -134,6 +135,75 @@ __device__ __forceinline__ float4 vb_readlane(const float4& v, int lane) {
 }
 __device__ __forceinline__ int vb_mbcnt(u64 m) {  // set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// ---- accesses that are coherent between the eight XCDs INSIDE one launch ------------------------------------------
+// The XCDs' L2s are not coherent with each other; between two launches the kernel boundary writes back and invalidates.
+// The merged job + composite kernel (round 6) hands job slots from the wave that resolved a job to whichever wave
+// composites its tile, possibly through another XCD's L2, in the middle of a launch: those words are written and read at
+// AGENT scope (relaxed atomics: the stores write through, the loads miss the non-coherent levels), ordered by the arrival
+// counters of the grid-wide barrier in between.  COH = false: plain accesses (the separate-launch forms).
+template <bool COH>
+__device__ __forceinline__ void vb_st_u64(void* p, u64 v) {
+    if (COH)
+        __hip_atomic_store((u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *(u64*)p = v;
+}
+template <bool COH>
+__device__ __forceinline__ u64 vb_ld_u64(const void* p) {
+    return COH ? __hip_atomic_load((const u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *(const u64*)p;
+}
+template <bool COH>
+__device__ __forceinline__ void vb_st_i32(int* p, int v) {
+    if (COH)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+template <bool COH>
+__device__ __forceinline__ int vb_ld_i32(const int* p) {
+    return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH>
+__device__ __forceinline__ void vb_st_f4(float* p, const float4& v) {  // (16-byte aligned)
+    if (COH) {
+        vb_st_u64<true>(p, (u64)__float_as_uint(v.x) | ((u64)__float_as_uint(v.y) << 32));
+        vb_st_u64<true>(p + 2, (u64)__float_as_uint(v.z) | ((u64)__float_as_uint(v.w) << 32));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
+template <bool COH>
+__device__ __forceinline__ float4 vb_ld_f4(const float* p) {
+    if (COH) {
+        const u64 a = vb_ld_u64<true>(p), b = vb_ld_u64<true>(p + 2);
+        return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                           __uint_as_float((unsigned)(b >> 32)));
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <bool COH>
+__device__ __forceinline__ void vb_st_item(VbItem* p, const VbItem& it) {
+    if (COH) {
+        vb_st_u64<true>(p, (u64)(unsigned)it.packed | ((u64)(unsigned)it.v1 << 32));
+        vb_st_u64<true>((char*)p + 8, (u64)(unsigned)it.v2 | ((u64)__float_as_uint(it.alpha) << 32));
+    } else {
+        *p = it;
+    }
+}
+template <bool COH>
+__device__ __forceinline__ VbItem vb_ld_item(const VbItem* p) {
+    if (COH) {
+        const u64 a = vb_ld_u64<true>(p), b = vb_ld_u64<true>((const char*)p + 8);
+        VbItem it;
+        it.packed = (int)(unsigned)a;
+        it.v1 = (int)(unsigned)(a >> 32);
+        it.v2 = (int)(unsigned)b;
+        it.alpha = __uint_as_float((unsigned)(b >> 32));
+        return it;
+    }
+    return *p;
 }
 
 // ---- stage 1: vertices, screen boxes of triangles / clusters / links ---------------------------------------------
@@ -1497,13 +1567,14 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
 // overflow bit 4, so loss and gradient come out NaN and the optimiser state stays as it was; ehr_fused_status() returns
 // EHR_ERR_RETRY and switches the pass on for the context's later calls.
 #define VB_FLAG_NEED_SLOW 4
+template <bool COH = false>
 __device__ __forceinline__ void vb_put_aside(int4* __restrict__ slow_list, int* __restrict__ meta, int* __restrict__ jn,
                                              int* __restrict__ jdesc, int job, int u, int tx, int ty) {
     if (slow_list) {
         slow_list[atomicAdd(vb_line(meta, 17), 1)] = make_int4(job, u, tx, ty);
     } else {
         atomicOr(&meta[EHR_META_OVERFLOW], VB_FLAG_NEED_SLOW);
-        jn[job] = -1;
+        vb_st_i32<COH>(&jn[job], -1);
         jdesc[job] = -1;
     }
 }
@@ -1530,6 +1601,7 @@ struct VbResolveArgs {
 // (jitems) and their number (jn; -1 = the link contributes nothing here).  pairA [2 * VB_RN] and hits [2 * VB_RN] are the
 // wave's LDS work areas.  Called by the job kernel right after a job's depth tests (the ids never leave LDS) and by
 // vb_resolve_kernel for the jobs vb_slow_kernel drew.
+template <bool COH = false>
 __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const unsigned* ids, float* pairA,
                                                unsigned short* hits, const u64 (&C)[VB_WORDS], size_t slot, int b,
                                                int rx0, int ry0) {
@@ -1670,9 +1742,11 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
                 if (spill_base >= 0 && spill_base < spill_cap) room += min(VB_SPILL_BLOCK, spill_cap - spill_base);
                 if (keep) {
                     if (at < VB_JOB_ITEMS)
-                        jitems[slot * VB_JOB_ITEMS + at] = it;
+                        vb_st_item<COH>(&jitems[slot * VB_JOB_ITEMS + at], it);
                     else if (at < room)
-                        spill[spill_base + (at - VB_JOB_ITEMS)] = it;
+                        vb_st_item<COH>(&spill[spill_base + (at - VB_JOB_ITEMS)], it);
+                    else if (COH)
+                        atomicOr(&meta[EHR_META_OVERFLOW], 1);
                     else
                         meta[EHR_META_OVERFLOW] = 1;  // reported through loss = NaN, never silent
                 }
@@ -1709,10 +1783,10 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
     }
     // ---- publish: the link's value at the tile's pixels (tile-local row-major), the number of blended pairs
     const bool nz = __ballot(val[0] != 0.f || val[1] != 0.f || val[2] != 0.f || val[3] != 0.f) != 0;
-    if (nz) *reinterpret_cast<float4*>(jval + slot * 256 + r * EHR_TILE_W + c4) = make_float4(val[0], val[1], val[2], val[3]);
+    if (nz) vb_st_f4<COH>(jval + slot * 256 + r * EHR_TILE_W + c4, make_float4(val[0], val[1], val[2], val[3]));
     if (lane == 0) {
-        jn[slot] = nz ? nitems : -1;
-        if (nitems > VB_JOB_ITEMS) jspill[slot] = spill_base;
+        vb_st_i32<COH>(&jn[slot], nz ? nitems : -1);
+        if (nitems > VB_JOB_ITEMS) vb_st_i32<COH>(&jspill[slot], spill_base);
     }
 #undef KT
 }
@@ -1722,6 +1796,7 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
 // Nothing of the job's region goes through global memory, and the resolve stage needs no launch of its own: it was a
 // 10 us kernel of one dependent chain per job behind a boundary; here the chain runs while other waves still rasterize.
 // (Resolve and rasterizer never overlap inside a wave: the live ranges of the two are disjoint, unlike round 2's fusion.)
+template <bool COH = false>
 __device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWaveLds& S, u64* key, const u64* cov, size_t slot,
                                                     int b, int rx0, int ry0) {
     const int lane = lane_id();
@@ -1747,8 +1822,285 @@ __device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWa
         const unsigned i = 64u * k + lane;
         if (i < (unsigned)VB_RN) ids[i] = idw[k];
     }
-    vb_resolve_job(Q, ids, reinterpret_cast<float*>(key), reinterpret_cast<unsigned short*>(&S.R), C, slot, b, rx0, ry0);
+    vb_resolve_job<COH>(Q, ids, reinterpret_cast<float*>(key), reinterpret_cast<unsigned short*>(&S.R), C, slot, b, rx0, ry0);
     VB_WAVE_SYNC();
+}
+
+// a lane's four pixels of a mask tile row := 0 (the composite kernel's layout: lane -> row lane / 8, columns 4 (lane % 8)..+3)
+__device__ __forceinline__ void vb_zero_tile_row(float* __restrict__ mask, size_t im, bool row_in, int ix, int W, int vec_ok) {
+    if (!row_in) return;
+    if (vec_ok) {
+        if (ix < W) *reinterpret_cast<float4*>(mask + im) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (ix + j < W) mask[im + j] = 0.f;
+    }
+}
+
+struct VbCompArgs {  // what the composite stage needs besides its LDS tables
+    BinGeom g;
+    int B;
+    const float4* posc;
+    int V;
+    const float* verts;
+    const int* jn;
+    const float* jval;
+    const VbItem* jitems;
+    const int* jspill;
+    int jcap;
+    const float* ref;
+    float* mask;
+    long long* facc;
+    int nls, want_grad, vec_ok;
+    const VbItem* spill;
+    int spill_cap;
+    int* meta;
+    int dbg;
+    const long long* tsum;
+};
+
+// The composite stage's work items of ONE wave (slot `wslot` of the `nslots` wave slots its XCD has; `nwg` workgroups in
+// all): see vb_composite_kernel.  s_jbase / s_utile: the (view, link) tables in LDS; gpix: 256 floats of LDS of this wave.
+// COH: the job slots are read at agent scope (the merged kernel: they were written earlier in the SAME launch, possibly
+// through another XCD's L2).
+template <bool COH, bool FILL>
+__device__ __forceinline__ void vb_composite_items(const VbCompArgs& C, const int* s_jbase, const unsigned* s_utile, float* gpix,
+                                                   int xcd, int wslot, int nslots, int nwg) {
+    const BinGeom& g = C.g;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int W = g.W, H = g.H, L = g.L, B = C.B, U = B * L;
+    const bool sparse = C.tsum != nullptr;
+    const int jcap = C.jcap, dbg = C.dbg, nls = C.nls, want_grad = C.want_grad, vec_ok = C.vec_ok, V = C.V, spill_cap = C.spill_cap;
+    const float4* const posc = C.posc;
+    const float* const verts = C.verts;
+    const int* const jn = C.jn;
+    const float* const jval = C.jval;
+    const VbItem* const jitems = C.jitems;
+    const int* const jspill = C.jspill;
+    const VbItem* const spill = C.spill;
+    const float* const ref = C.ref;
+    float* const mask = C.mask;
+    long long* const facc = C.facc;
+    int* const meta = C.meta;
+    const long long* const tsum = C.tsum;
+    // work items: every tile of every view, or (bound reference) the JOBS -- a job stands for its tile if no link before
+    // its own has a job there, so that every tile with a job comes up exactly once and the others never
+    const int nitems = sparse ? min(s_jbase[U], jcap) : B * g.nt;
+    // XCD-aware order (locality only): every XCD takes a contiguous run of items
+    const int per_xcd = (nitems + 7) >> 3;
+    const int ibeg = xcd * per_xcd, iend = min(ibeg + per_xcd, nitems);
+    const int istep = nslots;
+    const int acc_stride = 12 * L + nls * VB_LOSS_STRIDE;
+    const int r = lane >> 3, c4 = (lane & 7) * 4;
+    const float invL = __builtin_amdgcn_rcpf((float)L);  // (u / L by vb_div_small)
+    for (int item = ibeg + wslot; item < iend; item += istep) {
+    int b, tx, ty;
+    if (sparse) {
+        int lo = 0;
+        if (U <= 64) {  // the last (view, link) whose first job is <= item: one LDS read per lane and a ballot
+            lo = __popcll(__ballot(lane < U && s_jbase[lane] <= item)) - 1;
+        } else {
+            int hi = U - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (s_jbase[mid] <= item)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+        }
+        b = vb_div_small(lo, invL);
+        const unsigned ut = s_utile[lo];
+        const int nx = (int)(ut >> 22), k = item - s_jbase[lo];
+        const int kr = vb_div_small(k, __builtin_amdgcn_rcpf((float)nx));  // (k < 2^16 tiles, nx <= 128: exact)
+        ty = (int)((ut >> 10) & 4095u) + kr;
+        tx = (int)(ut & 1023u) + k - kr * nx;
+        // owner of the tile = the job of the first link that has one there
+        bool prior = false;
+        if (lane < lo - b * L) {
+            const int u2 = b * L + lane;
+            const unsigned u2t = s_utile[u2];
+            const int n2 = s_jbase[u2 + 1] - s_jbase[u2];
+            const int ax0 = u2t & 1023u, ay0 = (u2t >> 10) & 4095u, anx = u2t >> 22;
+            prior = n2 > 0 && tx >= ax0 && tx < ax0 + anx && ty >= ay0 && (ty - ay0) * anx < n2;  // (n2 = anx x the rows)
+        }
+        if (__ballot(prior)) continue;
+    } else {
+        b = item / g.nt;
+        const int tile = item - b * g.nt;
+        tx = tile % g.ntx;
+        ty = tile / g.ntx;
+    }
+    const int tile = ty * g.ntx + tx;
+    long long* const vacc = facc + (size_t)b * acc_stride;
+    long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
+    const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
+    // links whose tile range (the tiles + halo their screen box touches: the jobs stage 2 ran) contains this tile (lane l
+    // tests link l, from the tables in LDS)
+    unsigned tmask;
+    int myn = -1, myslot = 0;
+    {
+        if (lane < L && !(dbg & 1)) {
+            const int u = b * L + lane;
+            const unsigned ut = s_utile[u];
+            const int j0 = s_jbase[u], n = s_jbase[u + 1] - j0;
+            const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
+            if (n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && (ty - ty0) * nx < n) {
+                myslot = j0 + (ty - ty0) * nx + (tx - tx0);
+                if (myslot < jcap) myn = vb_ld_i32<COH>(&jn[myslot]);
+            }
+        }
+        tmask = (unsigned)__ballot(myn >= 0);  // links that contribute a value here
+    }
+    if (sparse && tmask == 0) {  // nothing drawn here: the tile's cached sum(ref^2) is part of vtot already
+        if (FILL) {
+            const int zx = tx * EHR_TILE_W + c4, zy = ty * EHR_TILE_H + r;
+            vb_zero_tile_row(mask, ((size_t)b * H + (H - 1 - (zy < H ? zy : 0))) * W + zx, zy < H, zx, W, vec_ok);
+        }
+        continue;
+    }
+    const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
+    const bool row_in = iy < H;
+    const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
+    float rf[4] = {0.f, 0.f, 0.f, 0.f};
+    bool pin[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pin[j] = row_in && (ix + j) < W;
+    if (vec_ok) {
+        if (pin[0]) {
+            const float4 r4 = *reinterpret_cast<const float4*>(ref + im);
+            rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (pin[j]) rf[j] = ref[im + j];
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    unsigned todo = tmask;
+    while (todo) {  // sum in link order
+        const int l = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const size_t slot = (size_t)vb_readlane(myslot, l);
+        const float4 v4 = vb_ld_f4<COH>(jval + slot * 256 + r * EHR_TILE_W + c4);
+        acc[0] += v4.x;
+        acc[1] += v4.y;
+        acc[2] += v4.z;
+        acc[3] += v4.w;
+    }
+    // ---- composite, loss, mask write (image convention: row 0 = top)
+    float e2 = 0.f, gv[4];
+    float mv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        gv[j] = 0.f;
+        mv[j] = 0.f;
+        if (pin[j]) {
+            const float m = acc[j] > 1.f ? 1.f : acc[j];
+            const float e = m - rf[j];
+            e2 += e * e;
+            gv[j] = (acc[j] <= 1.f) ? 2.f * e : 0.f;
+            mv[j] = m;
+        }
+    }
+    if (mask) {
+        if (vec_ok) {
+            if (pin[0]) *reinterpret_cast<float4*>(mask + im) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (pin[j]) mask[im + j] = mv[j];
+        }
+    }
+    {
+        const float s = wave_sum(e2);
+        if (lane == 0) {
+            if (sparse)
+                fix_add_delta(lacc, s, tsum[(size_t)b * g.nt + tile], meta);
+            else
+                fix_add(lacc, s, meta);
+        }
+    }
+    const unsigned bmask = (unsigned)__ballot(myn > 0);  // links with blended pairs to back-propagate
+    if (!want_grad || bmask == 0 || (dbg & 4)) continue;
+
+    // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
+    const float4* const pv = posc + (size_t)b * V;
+    VB_WAVE_SYNC();  // the previous tile's reads of gpix are complete
+#pragma unroll
+    for (int j = 0; j < 4; j++) gpix[r * EHR_TILE_W + c4 + j] = gv[j];
+    VB_WAVE_SYNC();
+    unsigned links = bmask;
+    while (links) {
+        const int l = __ffs(links) - 1;
+        links &= links - 1;
+        const size_t slot = (size_t)vb_readlane(myslot, l);
+        int n = vb_readlane(myn, l);
+        int sbase = 0;
+        if (n > VB_JOB_ITEMS) {  // the rest of the list lives in the spill pool; never read outside it
+            sbase = vb_ld_i32<COH>(&jspill[slot]);
+            if (sbase < 0 || sbase >= spill_cap) n = VB_JOB_ITEMS;
+            else n = min(n, VB_JOB_ITEMS + (spill_cap - sbase));
+        }
+        float G[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) G[k] = 0.f;
+        for (int i = lane; i < n; i += 64) {
+            const VbItem itm = vb_ld_item<COH>((i < VB_JOB_ITEMS) ? &jitems[slot * VB_JOB_ITEMS + i] : &spill[sbase + (i - VB_JOB_ITEMS)]);
+            const int q = itm.packed & 1023, d = (itm.packed >> 10) & 1;
+            const int tri1 = (itm.packed >> 13) & 1;
+            const float dc = ((itm.packed >> 14) & 1) ? 1.f : -1.f;
+            const int nq = q + (d ? VB_RW : 1);
+            const int oq = (itm.alpha > 0.f) ? q : nq;
+            const int oy = vb_div_rw(oq), ox = oq - oy * VB_RW;
+            const float gi = gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
+            const float dd = gi * dc;
+            if (gi == 0.f || dd == 0.f) continue;
+            const int qy = vb_div_rw(q), qx = q - qy * VB_RW;
+            int px = rx0 + qx, py = ry0 + qy;
+            if (tri1) {
+                px += 1 - d;
+                py += d;
+            }
+            float g1[3], g2[3];
+            aa_pos_grad(pv[itm.v1], pv[itm.v2], px, py, d, itm.alpha, dd, W, H, g1, g2);
+            const float* a1 = verts + 3 * (size_t)itm.v1;
+            const float* a2 = verts + 3 * (size_t)itm.v2;
+            const float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) G[4 * rr + c] += g1[rr] * h1[c] + g2[rr] * h2[c];
+        }
+        // the twelve sums in 14 shuffles (bit-equal to twelve wave_sum calls); one lane per element adds its sum
+        const float mine = wave_sum12(G, lane);
+        if ((lane & 3) == 0 && (lane & 12) != 12) fix_add(&vacc[12 * l + wave_sum12_element(lane)], mine, meta);
+    }
+    }
+    // ---- bound reference AND a mask output: the tiles that hold a job were written by their owners above; every other
+    //      tile of the images is zero.  The waves share them out (most have no item, or one): a wave tests a tile against
+    //      the links' tile ranges -- the predicate that decides whether the tile HAS an owner -- and stores 1 KB of zeros if
+    //      it has none.  Stores only: nothing here is waited for before the ticket's vmcnt.
+    if (FILL) {
+        const int total = B * g.nt;
+        for (int t = (int)blockIdx.x * 4 + wave; t < total; t += nwg * 4) {
+            const int b = t / g.nt, tile = t - b * g.nt;
+            const int ty = tile / g.ntx, tx = tile - ty * g.ntx;
+            bool owned = false;
+            if (lane < L) {
+                const int u = b * L + lane;
+                const unsigned ut = s_utile[u];
+                const int n = s_jbase[u + 1] - s_jbase[u];
+                const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
+                owned = n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && (ty - ty0) * nx < n;
+            }
+            if (__ballot(owned)) continue;
+            const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;
+            const bool row_in = iy < H;
+            vb_zero_tile_row(mask, ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix, row_in, ix, W, vec_ok);
+        }
+    }
 }
 
 #ifndef VB_JOB_WAVES
@@ -1788,6 +2140,14 @@ struct VbJobParams {
     int4* slow_list;
     int heavy_t, med_t0;
     VbResolveArgs rq;
+    // MERGE (round 6): the composite + finish stages run at the end of this launch
+    VbCompArgs ca;
+    const long long* vtot;
+    const int* ref_flag;
+    float* loss;
+    float* grad_mvp;
+    int* lbox_all;
+    StepTail tail;
 };
 typedef const VbJobParams __attribute__((address_space(4)))* VbJobParamsPtr;
 __device__ __forceinline__ VbJobParamsPtr vb_job_params() {
@@ -1795,6 +2155,19 @@ __device__ __forceinline__ VbJobParamsPtr vb_job_params() {
     asm volatile("" : "+s"(p));  // (what the optimiser cannot see through it cannot hoist to the kernel's entry)
     return p;
 }
+// a whole parameter sub-struct out of the kernarg segment (word by word: the segment's address space has no copy constructor)
+template <class T>
+__device__ __forceinline__ T vb_load_pod(const T __attribute__((address_space(4)))* p) {
+    static_assert(sizeof(T) % 4 == 0, "vb_load_pod");
+    T out;
+    const int __attribute__((address_space(4)))* const src = (const int __attribute__((address_space(4)))*)p;
+    int* const dst = reinterpret_cast<int*>(&out);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = src[i];
+    return out;
+}
+template <class T>
+__device__ __forceinline__ T vb_load_pod(const T* p) { return *p; }
 template <class P>
 __device__ __forceinline__ VbResolveArgs vb_load_rq(P p) {
     VbResolveArgs q;
@@ -1806,7 +2179,15 @@ __device__ __forceinline__ VbResolveArgs vb_load_rq(P p) {
 }
 // COVER (the scoring op): jcov = the (view, tile) coverage words [B][nt][4] the jobs OR their tile's interior into, jn = one
 // sticky flag raised by a job that met a triangle whose depth class does not let coverage decide; no slots, no lists.
-template <bool COVER>
+// MERGE (round 6, solver step with a bound reference mask and no mask output, one chunk of views, general-triangle pass off):
+// the composite and finish stages run at the END OF THIS LAUNCH instead of in a launch of their own.  All workgroups of the
+// grid are resident together (four per CU by registers and LDS, the grid is four per CU), so a grid-wide arrival counter is
+// safe: a workgroup whose waves have run out of jobs waits until its slots' stores have been performed, arrives (a ticket per
+// XCD, then one over the XCDs), sleeps on its XCD's go flag, and then takes composite items like a workgroup of
+// vb_composite_kernel would -- tables already in LDS, no launch boundary (cache write-back + invalidate, dispatch, tables:
+// 13 of that launch's 18 us were not tile work).  Job slots travel at agent scope (vb_st_* / vb_ld_*<true>).  A wait that
+// does not end (a grid that is not resident after all) is REPORTED through the overflow flag after ~50 ms, never a hang.
+template <bool COVER, bool MERGE = false>
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
 vb_job_kernel(VbJobParams prm_) {
     __shared__ VbWaveLds lds_all[4];
@@ -1817,6 +2198,9 @@ vb_job_kernel(VbJobParams prm_) {
 #else
 #define PRM(f) (prm_.f)
 #define VB_RQ() vb_load_rq(&prm_)
+#endif
+#ifdef VB_MERGE_TL
+    const long long tl_start0 = wall_clock64();
 #endif
     const int W = PRM(g.W), H = PRM(g.H), L = PRM(g.L), gnt = PRM(g.nt), gntx = PRM(g.ntx);
     const int B = PRM(B), V = PRM(V), dbg = PRM(dbg);
@@ -2015,10 +2399,10 @@ vb_job_kernel(VbJobParams prm_) {
 #endif
         if (wave == 0) {
             if (any_drawn & 2) {  // put aside for vb_slow_kernel
-                if (lane == 0) vb_put_aside(PRM(slow_list), PRM(meta), PRM(jn), PRM(jdesc), job, u, tx, ty);
+                if (lane == 0) vb_put_aside<MERGE>(PRM(slow_list), PRM(meta), PRM(jn), PRM(jdesc), job, u, tx, ty);
             } else if (any_drawn) {
             } else if (lane == 0) {
-                PRM(jn)[job] = -1;
+                vb_st_i32<MERGE>(&PRM(jn)[job], -1);
                 PRM(jdesc)[job] = -1;
             }
             if (lane == 0) {
@@ -2038,7 +2422,7 @@ vb_job_kernel(VbJobParams prm_) {
 
 #if VB_INLINE_RESOLVE
     // (the loop's last barrier is behind us: waves 1-3 go on to their own jobs, nobody touches wave 0's LDS but wave 0)
-    if (!COVER && wave == 0 && hres_job >= 0) vb_resolve_from_lds(VB_RQ(), S, S.key, S.cov, (size_t)hres_job, hres_b, hres_rx0, hres_ry0);
+    if (!COVER && wave == 0 && hres_job >= 0) vb_resolve_from_lds<MERGE>(VB_RQ(), S, S.key, S.cov, (size_t)hres_job, hres_b, hres_rx0, hres_ry0);
 #endif
 #if VB_PRIO_HEAVY
     __builtin_amdgcn_s_setprio(0);
@@ -2171,7 +2555,7 @@ vb_job_kernel(VbJobParams prm_) {
             continue;
         }
         if (drawn < 0) {  // a triangle for the general path (near-plane clipping, huge extent): put the job aside
-            if (lane == 0) vb_put_aside(PRM(slow_list), PRM(meta), PRM(jn), PRM(jdesc), job, u, tx, ty);
+            if (lane == 0) vb_put_aside<MERGE>(PRM(slow_list), PRM(meta), PRM(jn), PRM(jdesc), job, u, tx, ty);
             continue;
         }
         if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
@@ -2188,7 +2572,7 @@ vb_job_kernel(VbJobParams prm_) {
         }
         if (drawn == 0) {  // the link's box touches this tile, its triangles do not
             if (lane == 0) {
-                PRM(jn)[slot] = -1;
+                vb_st_i32<MERGE>(&PRM(jn)[slot], -1);
                 PRM(jdesc)[slot] = -1;
             }
             continue;
@@ -2197,7 +2581,7 @@ vb_job_kernel(VbJobParams prm_) {
         const long long tl_j2 = __builtin_readcyclecounter();
 #endif
 #if VB_INLINE_RESOLVE
-        vb_resolve_from_lds(VB_RQ(), S, S.key, S.cov, slot, b, rx0, ry0);
+        vb_resolve_from_lds<MERGE>(VB_RQ(), S, S.key, S.cov, slot, b, rx0, ry0);
 #else
         vb_publish(A, S.key, S.cov, job, u, tx, ty);
 #endif
@@ -2229,9 +2613,73 @@ vb_job_kernel(VbJobParams prm_) {
         for (int k = 0; k < 3; k++) tx[8 + k] = S.tl_c[4 + k];
         tx[11] = (S.tl_c[7] & 0xffffffffll) | ((long long)S.tl_cands << 32) | ((long long)S.tl_groups << 48);
     }
-#else
-    
 #endif
+    if (MERGE && !COVER) {
+        // ---- the grid-wide hand-over.  Every wave first waits until its own slot stores have been performed (agent scope:
+        //      written through), the workgroup arrives, then sleeps on its XCD's go flag (= this step's generation).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const meta = PRM(meta);
+#ifdef VB_MERGE_TL  // profiling build: when this workgroup arrived, was let go, finished its items, [finished the finish stage]
+        long long* const mtl = PRM(timeline) + 8 * (size_t)blockIdx.x;
+        if (tid == 0) {
+            mtl[0] = tl_start0;
+            mtl[1] = wall_clock64();
+        }
+#endif
+        if (tid == 0) {
+            if (atomicAdd(vb_line(meta, 18 + xcd), 1) == G8 - 1 && atomicAdd(vb_line(meta, 26), 1) == 7)
+                for (int k = 0; k < 8; k++) __hip_atomic_store(vb_line(meta, 27 + k), gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(vb_line(meta, 27 + xcd), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 16)) {  // (~50-100 ms: the grid is not resident together after all -- reported, never a hang)
+                    atomicOr(&meta[EHR_META_OVERFLOW], 8);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+#ifdef VB_MERGE_TL
+        if (tid == 0) mtl[2] = wall_clock64();
+#endif
+        // ---- composite stage (vb_composite_kernel's items, this XCD's eighth of them dealt over its waves)
+        const VbCompArgs C = vb_load_pod(&PRM(ca));
+        {   // the links' screen boxes start "empty" in the next step (nobody reads them after the prologue above)
+            int* const lbox_all = PRM(lbox_all);
+            for (int i = (int)blockIdx.x * 256 + tid; i < 16 * B * L; i += (int)gridDim.x * 256) lbox_all[i] = (i & 2) ? INT_MIN : INT_MAX;
+        }
+        // (items beyond a wave's first one claimed from a per-XCD cursor instead of dealt: measured, 72.2 -> 75.3 us at 8 views and
+        //  278 -> 326 us at 64 -- every wave ends on a claim, 512 same-address atomics per XCD at ~12 ns each)
+        vb_composite_items<true, false>(C, upre, utile, reinterpret_cast<float*>(S.key), xcd, kx * 4 + wave, G8 * 4, (int)gridDim.x);
+        // ---- the workgroup whose atomics are performed last runs the finish stage (as in vb_composite_kernel)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#ifdef VB_MERGE_TL
+        if (tid == 0) {
+            mtl[3] = wall_clock64();
+            mtl[4] = 0;
+        }
+#endif
+        if (tid == 0) {
+            int last = 0;
+            if (atomicAdd(vb_line(meta, 8 + xcd), 1) == G8 - 1) last = atomicAdd(vb_line(meta, 16), 1) == 7;
+            s_heavy[0] = last;  // (the heavy phase's flag word: idle since that phase)
+        }
+        __syncthreads();
+        if (!s_heavy[0]) return;
+        const int* const ref_flag = PRM(ref_flag);
+        if (ref_flag && tid == 0 && ref_flag[0]) atomicOr(&meta[EHR_META_OVERFLOW], 1);  // the bound reference's own sums overflowed
+        __syncthreads();
+        const StepTail tail = vb_load_pod(&PRM(tail));
+        finish_body<true>(C.g, B, C.facc, PRM(vtot), PRM(loss), PRM(grad_mvp), meta, tail, C.nls, nullptr, VB_LOSS_STRIDE,
+                          reinterpret_cast<float*>(lds_all[0].key), reinterpret_cast<double(*)[17]>(lds_all[1].key),
+                          reinterpret_cast<float*>(lds_all[2].key), reinterpret_cast<float(*)[16]>(lds_all[3].key));
+#ifdef VB_MERGE_TL
+        __syncthreads();
+        if (tid == 0) mtl[4] = wall_clock64();
+#endif
+    }
 }
 #undef PRM
 #undef VB_RQ
@@ -2387,18 +2835,6 @@ vb_refsum_kernel(BinGeom g, int B, const float* __restrict__ ref, int vec_ok, lo
     }
 }
 
-// a lane's four pixels of a mask tile row := 0 (the composite kernel's layout: lane -> row lane / 8, columns 4 (lane % 8)..+3)
-__device__ __forceinline__ void vb_zero_tile_row(float* __restrict__ mask, size_t im, bool row_in, int ix, int W, int vec_ok) {
-    if (!row_in) return;
-    if (vec_ok) {
-        if (ix < W) *reinterpret_cast<float4*>(mask + im) = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (ix + j < W) mask[im + j] = 0.f;
-    }
-}
-
 // Stage 3: one WAVE per 32x8 tile (4 pixels per lane, float4 image accesses, no workgroup barriers): sums the links'
 // values in link order, clamps, accumulates the frame loss, writes the mask, and back-propagates the tile's blended
 // pairs to 12 numbers per link which go to the view's fixed-point accumulators.  Persistent waves over
@@ -2438,224 +2874,12 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
         for (int i = (int)blockIdx.x * 256 + tid; i < 16 * B_all * g.L; i += (int)gridDim.x * 256)
             lbox_all[i] = (i & 2) ? INT_MIN : INT_MAX;  // 16 ints (one line) per box: min x, min y, max x, max y, padding
     __syncthreads();
-    // work items: every tile of every view, or (bound reference) the JOBS -- a job stands for its tile if no link before
-    // its own has a job there, so that every tile with a job comes up exactly once and the others never
-    const int nitems = sparse ? min(s_jbase[U], jcap) : B * g.nt;
-    // XCD-aware order (locality only): every XCD takes a contiguous run of items
-    const int nwg = gridDim.x;
-    const int per_xcd = (nitems + 7) >> 3, xcd = blockIdx.x & 7;
-    const int ibeg = xcd * per_xcd, iend = min(ibeg + per_xcd, nitems);
-    const int istep = (nwg >> 3) * 4;
-    const int acc_stride = 12 * L + nls * VB_LOSS_STRIDE;
-    const int r = lane >> 3, c4 = (lane & 7) * 4;
-    const float invL = __builtin_amdgcn_rcpf((float)L);  // (u / L by vb_div_small)
-    for (int item = ibeg + (int)(blockIdx.x >> 3) * 4 + wave; item < iend; item += istep) {
-    int b, tx, ty;
-    if (sparse) {
-        int lo = 0;
-        if (U <= 64) {  // the last (view, link) whose first job is <= item: one LDS read per lane and a ballot
-            lo = __popcll(__ballot(lane < U && s_jbase[lane] <= item)) - 1;
-        } else {
-            int hi = U - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_jbase[mid] <= item)
-                    lo = mid;
-                else
-                    hi = mid - 1;
-            }
-        }
-        b = vb_div_small(lo, invL);
-        const unsigned ut = s_utile[lo];
-        const int nx = (int)(ut >> 22), k = item - s_jbase[lo];
-        const int kr = vb_div_small(k, __builtin_amdgcn_rcpf((float)nx));  // (k < 2^16 tiles, nx <= 128: exact)
-        ty = (int)((ut >> 10) & 4095u) + kr;
-        tx = (int)(ut & 1023u) + k - kr * nx;
-        // owner of the tile = the job of the first link that has one there
-        bool prior = false;
-        if (lane < lo - b * L) {
-            const int u2 = b * L + lane;
-            const unsigned u2t = s_utile[u2];
-            const int n2 = s_jbase[u2 + 1] - s_jbase[u2];
-            const int ax0 = u2t & 1023u, ay0 = (u2t >> 10) & 4095u, anx = u2t >> 22;
-            prior = n2 > 0 && tx >= ax0 && tx < ax0 + anx && ty >= ay0 && (ty - ay0) * anx < n2;  // (n2 = anx x the rows)
-        }
-        if (__ballot(prior)) continue;
-    } else {
-        b = item / g.nt;
-        const int tile = item - b * g.nt;
-        tx = tile % g.ntx;
-        ty = tile / g.ntx;
-    }
-    const int tile = ty * g.ntx + tx;
-    long long* const vacc = facc + (size_t)b * acc_stride;
-    long long* const lacc = vacc + 12 * L + (tile % nls) * VB_LOSS_STRIDE;
-    const int rx0 = tx * EHR_TILE_W - 1, ry0 = ty * EHR_TILE_H - 1;
-    // links whose tile range (the tiles + halo their screen box touches: the jobs stage 2 ran) contains this tile (lane l
-    // tests link l, from the tables in LDS)
-    unsigned tmask;
-    int myn = -1, myslot = 0;
-    {
-        if (lane < L && !(dbg & 1)) {
-            const int u = b * L + lane;
-            const unsigned ut = s_utile[u];
-            const int j0 = s_jbase[u], n = s_jbase[u + 1] - j0;
-            const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
-            if (n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && (ty - ty0) * nx < n) {
-                myslot = j0 + (ty - ty0) * nx + (tx - tx0);
-                if (myslot < jcap) myn = jn[myslot];
-            }
-        }
-        tmask = (unsigned)__ballot(myn >= 0);  // links that contribute a value here
-    }
-    if (sparse && tmask == 0) {  // nothing drawn here: the tile's cached sum(ref^2) is part of vtot already
-        if (FILL) {
-            const int zx = tx * EHR_TILE_W + c4, zy = ty * EHR_TILE_H + r;
-            vb_zero_tile_row(mask, ((size_t)b * H + (H - 1 - (zy < H ? zy : 0))) * W + zx, zy < H, zx, W, vec_ok);
-        }
-        continue;
-    }
-    const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;  // first of my 4 pixels (GL rows: y up)
-    const bool row_in = iy < H;
-    const size_t im = ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix;  // image convention: row 0 = top
-    float rf[4] = {0.f, 0.f, 0.f, 0.f};
-    bool pin[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) pin[j] = row_in && (ix + j) < W;
-    if (vec_ok) {
-        if (pin[0]) {
-            const float4 r4 = *reinterpret_cast<const float4*>(ref + im);
-            rf[0] = r4.x; rf[1] = r4.y; rf[2] = r4.z; rf[3] = r4.w;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (pin[j]) rf[j] = ref[im + j];
-    }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned todo = tmask;
-    while (todo) {  // sum in link order
-        const int l = __ffs(todo) - 1;
-        todo &= todo - 1;
-        const size_t slot = (size_t)vb_readlane(myslot, l);
-        const float4 v4 = *reinterpret_cast<const float4*>(jval + slot * 256 + r * EHR_TILE_W + c4);
-        acc[0] += v4.x;
-        acc[1] += v4.y;
-        acc[2] += v4.z;
-        acc[3] += v4.w;
-    }
-    // ---- composite, loss, mask write (image convention: row 0 = top)
-    float e2 = 0.f, gv[4];
-    float mv[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        gv[j] = 0.f;
-        mv[j] = 0.f;
-        if (pin[j]) {
-            const float m = acc[j] > 1.f ? 1.f : acc[j];
-            const float e = m - rf[j];
-            e2 += e * e;
-            gv[j] = (acc[j] <= 1.f) ? 2.f * e : 0.f;
-            mv[j] = m;
-        }
-    }
-    if (mask) {
-        if (vec_ok) {
-            if (pin[0]) *reinterpret_cast<float4*>(mask + im) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (pin[j]) mask[im + j] = mv[j];
-        }
-    }
-    {
-        const float s = wave_sum(e2);
-        if (lane == 0) {
-            if (sparse)
-                fix_add_delta(lacc, s, tsum[(size_t)b * g.nt + tile], meta);
-            else
-                fix_add(lacc, s, meta);
-        }
-    }
-    const unsigned bmask = (unsigned)__ballot(myn > 0);  // links with blended pairs to back-propagate
-    if (!want_grad || bmask == 0 || (dbg & 4)) continue;
-
-    // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
-    const float4* const pv = posc + (size_t)b * V;
-    VB_WAVE_SYNC();  // the previous tile's reads of gpix are complete
-#pragma unroll
-    for (int j = 0; j < 4; j++) gpix[r * EHR_TILE_W + c4 + j] = gv[j];
-    VB_WAVE_SYNC();
-    unsigned links = bmask;
-    while (links) {
-        const int l = __ffs(links) - 1;
-        links &= links - 1;
-        const size_t slot = (size_t)vb_readlane(myslot, l);
-        int n = vb_readlane(myn, l);
-        int sbase = 0;
-        if (n > VB_JOB_ITEMS) {  // the rest of the list lives in the spill pool; never read outside it
-            sbase = jspill[slot];
-            if (sbase < 0 || sbase >= spill_cap) n = VB_JOB_ITEMS;
-            else n = min(n, VB_JOB_ITEMS + (spill_cap - sbase));
-        }
-        float G[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++) G[k] = 0.f;
-        for (int i = lane; i < n; i += 64) {
-            const VbItem itm = (i < VB_JOB_ITEMS) ? jitems[slot * VB_JOB_ITEMS + i] : spill[sbase + (i - VB_JOB_ITEMS)];
-            const int q = itm.packed & 1023, d = (itm.packed >> 10) & 1;
-            const int tri1 = (itm.packed >> 13) & 1;
-            const float dc = ((itm.packed >> 14) & 1) ? 1.f : -1.f;
-            const int nq = q + (d ? VB_RW : 1);
-            const int oq = (itm.alpha > 0.f) ? q : nq;
-            const int oy = vb_div_rw(oq), ox = oq - oy * VB_RW;
-            const float gi = gpix[(oy - 1) * EHR_TILE_W + (ox - 1)];
-            const float dd = gi * dc;
-            if (gi == 0.f || dd == 0.f) continue;
-            const int qy = vb_div_rw(q), qx = q - qy * VB_RW;
-            int px = rx0 + qx, py = ry0 + qy;
-            if (tri1) {
-                px += 1 - d;
-                py += d;
-            }
-            float g1[3], g2[3];
-            aa_pos_grad(pv[itm.v1], pv[itm.v2], px, py, d, itm.alpha, dd, W, H, g1, g2);
-            const float* a1 = verts + 3 * (size_t)itm.v1;
-            const float* a2 = verts + 3 * (size_t)itm.v2;
-            const float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
-#pragma unroll
-            for (int rr = 0; rr < 3; rr++)
-#pragma unroll
-                for (int c = 0; c < 4; c++) G[4 * rr + c] += g1[rr] * h1[c] + g2[rr] * h2[c];
-        }
-        // the twelve sums in 14 shuffles (bit-equal to twelve wave_sum calls); one lane per element adds its sum
-        const float mine = wave_sum12(G, lane);
-        if ((lane & 3) == 0 && (lane & 12) != 12) fix_add(&vacc[12 * l + wave_sum12_element(lane)], mine, meta);
-    }
-    }
-    // ---- bound reference AND a mask output: the tiles that hold a job were written by their owners above; every other
-    //      tile of the images is zero.  The waves share them out (most have no item, or one): a wave tests a tile against
-    //      the links' tile ranges -- the predicate that decides whether the tile HAS an owner -- and stores 1 KB of zeros if
-    //      it has none.  Stores only: nothing here is waited for before the ticket's vmcnt.
-    if (FILL) {
-        const int total = B * g.nt;
-        for (int t = (int)blockIdx.x * 4 + wave; t < total; t += nwg * 4) {
-            const int b = t / g.nt, tile = t - b * g.nt;
-            const int ty = tile / g.ntx, tx = tile - ty * g.ntx;
-            bool owned = false;
-            if (lane < L) {
-                const int u = b * L + lane;
-                const unsigned ut = s_utile[u];
-                const int n = s_jbase[u + 1] - s_jbase[u];
-                const int tx0 = ut & 1023u, ty0 = (ut >> 10) & 4095u, nx = ut >> 22;
-                owned = n > 0 && tx >= tx0 && tx < tx0 + nx && ty >= ty0 && (ty - ty0) * nx < n;
-            }
-            if (__ballot(owned)) continue;
-            const int ix = tx * EHR_TILE_W + c4, iy = ty * EHR_TILE_H + r;
-            const bool row_in = iy < H;
-            vb_zero_tile_row(mask, ((size_t)b * H + (H - 1 - (row_in ? iy : 0))) * W + ix, row_in, ix, W, vec_ok);
-        }
-    }
+    VbCompArgs C;
+    C.g = g; C.B = B; C.posc = posc; C.V = V; C.verts = verts; C.jn = jn; C.jval = jval; C.jitems = jitems; C.jspill = jspill;
+    C.jcap = jcap; C.ref = ref; C.mask = mask; C.facc = facc; C.nls = nls; C.want_grad = want_grad; C.vec_ok = vec_ok;
+    C.spill = spill; C.spill_cap = spill_cap; C.meta = meta; C.dbg = dbg; C.tsum = tsum;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    vb_composite_items<false, FILL>(C, s_jbase, s_utile, gpix, xcd, (int)(blockIdx.x >> 3) * 4 + wave, (nwg >> 3) * 4, nwg);
     // ---- the workgroup whose atomics are performed last runs the finish stage.  Every wave first waits until its own
     //      atomics have been performed (vmcnt covers them), then one lane takes a ticket on the XCD's counter and the
     //      last of an XCD one on the top counter: two levels, because a few thousand arrivals on ONE address serialise
@@ -2678,8 +2902,9 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
     __shared__ double S[4][17];
     __shared__ float red_lds[8];
 #ifndef VB_NO_FINISH
+    __shared__ float Js[6][16];
     finish_body<TAIL>(g, B_all, facc_all, sparse ? vtot_all : nullptr, loss, grad_mvp, meta, tail, nls, nullptr, VB_LOSS_STRIDE,
-                      gpix_all[0], S, red_lds);
+                      gpix_all[0], S, red_lds, Js);
 #endif
 }
 
@@ -3018,6 +3243,27 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
         for (int k = 0; k < 8; k++)
             EHR_HIP(hipMemcpy(&cur[k], vb_line((int*)((char*)ctx->vb_acc.ptr + off), k), sizeof(int), hipMemcpyDeviceToHost));
         fprintf(stderr, "[ehr vbuf] job cursors %d %d %d %d %d %d %d %d\n", cur[0], cur[1], cur[2], cur[3], cur[4], cur[5], cur[6], cur[7]);
+#ifdef VB_MERGE_TL
+        {   // merged kernel: per workgroup [start, arrived, let go, items done, finish done] on the 100 MHz clock
+            const int nwg = ((ctx->num_cus * 4) + 7) & ~7;
+            std::vector<long long> tl((size_t)8 * nwg);
+            EHR_HIP(hipMemcpy(tl.data(), ctx->vb_spill.ptr, tl.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            long long t0 = tl[0], a_last = 0, go_first = 1ll << 62, go_last = 0, it_last = 0, fin = 0;
+            double a_mean = 0, it_mean = 0;
+            for (int i = 0; i < nwg; i++) t0 = std::min(t0, tl[8 * i]);
+            for (int i = 0; i < nwg; i++) {
+                a_last = std::max(a_last, tl[8 * i + 1] - t0);
+                a_mean += (double)(tl[8 * i + 1] - t0) / nwg;
+                go_first = std::min(go_first, tl[8 * i + 2] - t0);
+                go_last = std::max(go_last, tl[8 * i + 2] - t0);
+                it_last = std::max(it_last, tl[8 * i + 3] - t0);
+                it_mean += (double)(tl[8 * i + 3] - tl[8 * i + 2]) / nwg;
+                if (tl[8 * i + 4]) fin = tl[8 * i + 4] - t0;
+            }
+            fprintf(stderr, "[ehr merge] workgroups arrive: mean %.1f last %.1f us; let go: first %.1f last %.1f us; items done: last %.1f us (mean %.1f us of work); finish done %.1f us\n",
+                    a_mean * 0.01, a_last * 0.01, go_first * 0.01, go_last * 0.01, it_last * 0.01, it_mean * 0.01, fin * 0.01);
+        }
+#endif
 #ifdef VB_TIMELINE
         {
             // Timeline of the job kernel's waves (100 MHz clock), written into the (otherwise idle) spill pool: when
@@ -3269,6 +3515,32 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         jp.heavy_t = heavy_t;
         jp.med_t0 = med_t;
         jp.rq = rq;
+        // Merged form (round 6, EHR_VB_MERGE=1; OFF by default): the composite + finish stages at the end of the job kernel's
+        // launch, for the solver step's default chain -- bound reference, no mask output, one chunk, general-triangle pass off.
+        // Measured (profiles/r06_merged_composite_ab.txt): the same step time as the launch of its own at 8 views (72.2 us both),
+        // 3 % slower at 64 views -- what follows the last job is a tile's chain of dependent round trips, two levels of arrival
+        // tickets and the finish stage's own chain, none of which a launch boundary adds to; and the merged grid has fewer waves
+        // than there are items.  Kept as the A/B record and as the carrier of the grid-wide hand-over (agent-scope job slots).
+        static const int merge_env = getenv("EHR_VB_MERGE") ? atoi(getenv("EHR_VB_MERGE")) : 0;
+        const bool merged = merge_env && tail && sparse && !mask_k && Bk == B && !with_slow && (job_wgs & 7) == 0;
+        if (merged) {
+            VbCompArgs& C = jp.ca;
+            C.g = g; C.B = Bk; C.posc = posc; C.V = V; C.verts = verts; C.jn = jn; C.jval = jval; C.jitems = jitems;
+            C.jspill = jspill; C.jcap = ctx->vb_jcap; C.ref = ref_k; C.mask = nullptr; C.facc = facc; C.nls = VB_LOSS_SLOTS;
+            C.want_grad = grad_mvp ? 1 : 0; C.vec_ok = vec_ok; C.spill = spill; C.spill_cap = ctx->vb_spill_cap; C.meta = meta;
+            C.dbg = dbg; C.tsum = tsum_all;
+            jp.vtot = vtot_all;
+            jp.ref_flag = ref_flag;
+            jp.loss = loss;
+            jp.grad_mvp = grad_mvp;
+            jp.lbox_all = lbox_all;
+            jp.tail = *tail;
+            vb_job_kernel<false, true><<<job_wgs, 256, 0, stream>>>(jp);
+            EHR_LAUNCH_CHECK();
+            if (time_it)
+                for (int k = 2; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
+            continue;
+        }
         vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(jp);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
