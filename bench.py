@@ -188,18 +188,46 @@ def timed_blocks(step, steps, barrier, min_ms, world=1, dev=None, max_blocks=100
     return elapsed / blocks, blocks
 
 
-def stage_times(p, steps):
-    """hipEvents around each kernel of the chain (eager launches), `steps` more steps of the same optimisation."""
+def stage_times(p, steps, step_fn=None):
+    """hipEvents around each kernel of the chain (eager launches), `steps` more steps of the same optimisation.
+    The default chain launches no resolve kernel (the job kernel resolves its own jobs): the event pair that would bracket
+    it is EMPTY, and what it measures is the cost of a pair of events on this stack -- reported as ``event_pair_overhead``
+    instead of as a stage; every real stage's figure includes about that much."""
     from easyhec_amd import fused
     tr = p["trainer"]
     fused.set_timing(p["glctx"], True)
     if tr.fast is not None:
         tr.fast.release_graph()  # hipEvents between kernels need eager launches
     for _ in range(steps):
-        tr.step()
+        (step_fn or tr.step)()
     stage_ms, ncalls = fused.read_timing(p["glctx"])
     fused.set_timing(p["glctx"], False)
-    return {k: v / max(ncalls, 1) for k, v in stage_ms.items() if not k.startswith("unused")}
+    st = {k: v / max(ncalls, 1) for k, v in stage_ms.items() if not k.startswith("unused")}
+    if "resolve" in st and st["resolve"] < 0.5 * min(st.get("vertex", 1.0), st.get("composite", 1.0)):
+        st["event_pair_overhead"] = st.pop("resolve")  # (an empty pair; a chain with the general-triangle pass on keeps "resolve")
+    return st
+
+
+def traffic_of(workload):
+    """PMC-measured HBM bytes per step of `workload`'s launch chain from profiles/traffic[_<workload>].json (tools/gpu_traffic.sh;
+    separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction), or None; stale = collected on other kernel sources."""
+    name = "traffic.json" if workload == WORKLOAD else f"traffic_{workload}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        tj = json.load(open(path))
+        return {"whole_op": tj.get("hbm_bytes_whole_op"), "dominant_kernel": tj.get("hbm_bytes_dominant_kernel"),
+                "source": {"file": "profiles/" + name, "commit": tj.get("commit"), "launch_form": tj.get("launch_form"),
+                           "csrc_sha16": tj.get("csrc_sha16")},
+                "stale": tj.get("csrc_sha16") != csrc_sha16()}
+    except Exception:
+        return None
+
+
+FRAC_NOTE = ("equivalent rate: ALGORITHMIC bytes (SURVEY 8d: 2 x geometry + 16 B per pixel + 128 B per link, per frame) / the "
+             "dominant kernel's time / 8 TB/s.  The bound-reference, mask = NULL launch form does not move the 16 B per pixel the "
+             "count budgets, so this can exceed 1; frac_hbm_actual beside it is the bandwidth the kernel really uses (PMC bytes)")
 
 
 def side_workload(name, dev, steps, warmup, min_ms=30.0):
@@ -227,7 +255,17 @@ def side_workload(name, dev, steps, warmup, min_ms=30.0):
            "frac": round(bytes_frame * p["B"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if kernel_ms > 0 else None,
            "frac_step": round(fps * bytes_frame / 1e9 / HBM_PEAK_GBS, 4), "kernel_ms": round(kernel_ms, 5),
            "stage_ms": {k: round(v, 5) for k, v in st.items()},
-           "timed_blocks": blocks, "final_mask_loss": round(float(tr.last_loss), 3)}
+           "timed_blocks": blocks, "final_mask_loss": round(float(tr.last_loss), 3), "frac_is": FRAC_NOTE}
+    tq = traffic_of(name)
+    if tq and tq["dominant_kernel"] and kernel_ms > 0:
+        out["frac_hbm_actual"] = round(tq["dominant_kernel"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        out["hbm_actual_step_gbs"] = round(tq["whole_op"] / (el / steps) / 1e9, 2)
+        out["traffic"] = tq["whole_op"]
+        out["traffic_dominant_kernel"] = tq["dominant_kernel"]
+        out["traffic_source"] = tq["source"]
+        out["counters_stale"] = bool(tq["stale"])
+    else:
+        out["frac_hbm_actual"] = None  # (no PMC pass of this workload under profiles/)
     del tr, p
     torch.cuda.empty_cache()
     return out
@@ -393,13 +431,14 @@ def main():
 
     # the same step WITH the rendered masks written (rb_solver.py:73-77 materialises `rendered_masks` every step): the
     # chain then streams every tile of every view (the bound reference's cached sums do not apply) and writes mask[B,H,W]
-    with_mask_ms = None
+    with_mask_ms, with_mask_stage_ms = None, None
     if tr.fast is not None and world == 1 and not args.no_with_mask:
         mstep = lambda: tr.fast.step(want_mask=True)  # noqa: E731
         for _ in range(max(2, args.warmup // 4)):
             mstep()
         el_m, _ = timed_blocks(mstep, args.steps, barrier, min(args.min_ms, 30.0))
         with_mask_ms = el_m / args.steps * 1e3
+        with_mask_stage_ms = stage_times(p, args.steps, mstep)
     # roofline leg: hipEvents around each kernel of the fused op, same K steps again (continuing the optimisation)
     stage_ms = stage_times(p, args.steps)
     side = None
@@ -509,9 +548,21 @@ def main():
                          "stage_ms": {k: round(v, 5) for k, v in stage_ms.items()}},
         }
         out["roofline"].update(counters)
+        out["roofline"]["frac_is"] = FRAC_NOTE
         if with_mask_ms is not None:
             out["with_mask_ms_per_step"] = round(with_mask_ms, 4)
             out["with_mask_value"] = round(p["n_views"] / (with_mask_ms * 1e-3), 1)
+            # the same figures for the launch form that WRITES the rendered masks every step (rb_solver.py:73-77's
+            # `rendered_masks`): the step the reference's own forward corresponds to
+            km = with_mask_stage_ms[fused.DOMINANT_STAGE]
+            fps_m = p["n_views"] / (with_mask_ms * 1e-3)
+            out["roofline_with_mask"] = {
+                "launch_form": "ehr_solver_step with a mask output: mask[B,H,W] written every step (4 B per pixel: the job tiles by "
+                               "their owners, zeros elsewhere), reference read at the job tiles, its sums over the other tiles cached",
+                "ms_per_step": round(with_mask_ms, 4), "value": round(fps_m, 1), "kernel": fused.DOMINANT_KERNEL,
+                "kernel_ms": round(km, 5), "frac": round(bytes_launch / (km * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if km > 0 else None,
+                "frac_step": round(fps_m * bytes_frame / 1e9 / HBM_PEAK_GBS, 5),
+                "stage_ms": {k: round(v, 5) for k, v in with_mask_stage_ms.items()}, "frac_is": FRAC_NOTE}
         if side is not None:
             out["side"] = side
         if drop_in is not None:

@@ -681,7 +681,7 @@ int ehr_rasterize_fwd(ehr_ctx* ctx, const float* pos, const int32_t* tri, const 
             u64* key = (u64*)ctx->rkeys.ptr;
             if (tmax > 0) {
                 const int nbx = (tmax + 63) / 64;
-                static const int rd_blocks = getenv("EHR_RD_BLOCKS") ? atoi(getenv("EHR_RD_BLOCKS")) : 8192;  // (tuning hook; bands are at least 8 rows)
+                static const int rd_blocks = getenv("EHR_RD_BLOCKS") ? atoi(getenv("EHR_RD_BLOCKS")) : 16384;  // (tuning hook; bands are at least 8 rows)
                 int Z = std::max(1, std::min(rd_blocks / std::max(1, nbx * B), (H + 7) / 8));
                 const int band_rows = (H + Z - 1) / Z;
                 Z = (H + band_rows - 1) / band_rows;

@@ -38,19 +38,22 @@ def mean_last(path, counter, last=100):
 def main():
     fetch, write = mean_last(sys.argv[1], "FETCH_SIZE"), mean_last(sys.argv[2], "WRITE_SIZE")
     commit = sys.argv[3] if len(sys.argv) > 3 else "unknown"
+    workload = sys.argv[4] if len(sys.argv) > 4 else "xarm7_1280x720_8view"
     kern = {k: {"FETCH_SIZE_KB": round(fetch.get(k, 0.0), 1), "WRITE_SIZE_KB": round(write.get(k, 0.0), 1)} for k in CHAIN}
     hbm = {k: int(round((2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024)) for k, v in kern.items()}
-    B, H, W = 8, 720, 1280
     sys.path.insert(0, ROOT)
     from bench import algorithmic_bytes_per_frame, csrc_sha16
     from easyhec_amd.robot import load_robot
-    rb = load_robot("xarm7")
+    from easyhec_amd.synthetic import WORKLOADS
+    wl = WORKLOADS[workload]
+    B, H, W = wl["views"], wl["H"], wl["W"]
+    rb = load_robot(wl.get("robot", "xarm7"))
     alg = algorithmic_bytes_per_frame(rb, H, W) * B
     G = 12 * rb.num_verts + 12 * rb.num_tris
-    out = {"round": 5, "commit": commit, "csrc_sha16": csrc_sha16(),
+    out = {"round": 6, "commit": commit, "csrc_sha16": csrc_sha16(), "workload": workload,
            "launch_form": "ehr_solver_step, reference masks bound (ehr_fused_bind_ref), mask = NULL: what bench.py times",
            "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/step_bench.py ; the same with --pmc WRITE_SIZE "
-                      "(separate passes, 8 views 1280x720 xArm7, mean of the last 100 launches of every kernel)",
+                      f"(separate passes, workload {workload}, mean of the last 100 launches of every kernel)",
            "unit": "bytes per step (all kernels of one ehr_solver_step)",
            "correction": "hbm = 2*FETCH_SIZE + WRITE_SIZE (counters in KB -> bytes x1024; gfx950 half-count of wide reads)",
            "kernels_KB": kern,
@@ -67,7 +70,8 @@ def main():
                "note": "SURVEY 8d's algorithmic figure budgets 16 B per pixel + 2 x geometry (%d B); with the reference bound "
                        "and no mask output the step needs none of the per-pixel traffic outside the links' tiles" % (2 * G)},
            }
-    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    name = "traffic.json" if workload == "xarm7_1280x720_8view" else f"traffic_{workload}.json"
+    json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
