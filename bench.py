@@ -407,26 +407,33 @@ def main():
         dist.all_gather(allr, mine)
         per_rank_ms = [round(float(x.item()) / args.steps * 1e3, 4) for x in allr]
         elapsed = max(float(x.item()) for x in allr)  # the job is as slow as its slowest rank
-        # the step's ONE collective on its own: 8 floats, latency-bound
+        # the step's ONE exchange on its own: 8 floats, latency-bound -- the one the step makes first, then (where
+        # they are available) the others beside it: the library's peer-memory exchange (one kernel, Adam not included here),
+        # ncclAllReduce on the library's communicator, torch.distributed's all-reduce
+        import ctypes
+        from easyhec_amd import _lib
         buf = torch.zeros(8, device=dev)
-        if tr.fast is not None and tr.fast.rccl:  # the call the step makes: ncclAllReduce on the library's communicator
-            import ctypes
-            from easyhec_amd import _lib
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-            def one():
-                _lib.check(_lib.lib().ehr_comm_allreduce(p["glctx"].handle, _lib.ptr(buf), 8, stream), "ehr_comm_allreduce")
-        else:
-            def one():
-                dist.all_reduce(buf)
-        for _ in range(20):
-            one()
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        for _ in range(200):
-            one()
-        torch.cuda.synchronize()
-        allreduce_us = (time.perf_counter() - ta) / 200 * 1e6
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        zf = ctypes.c_float(0.0)
+        kinds = {}
+        if tr.fast is not None and tr.fast.p2p:
+            kinds["peer_memory"] = lambda: _lib.check(_lib.lib().ehr_comm_p2p_step(
+                p["glctx"].handle, _lib.ptr(buf), None, None, None, None, zf, zf, zf, zf, zf, None, None, stream), "ehr_comm_p2p_step")
+        if tr.fast is not None and tr.fast.rccl:
+            kinds["rccl"] = lambda: _lib.check(_lib.lib().ehr_comm_allreduce(p["glctx"].handle, _lib.ptr(buf), 8, stream), "ehr_comm_allreduce")
+        kinds["torch_distributed"] = lambda: dist.all_reduce(buf)
+        exchange_us = {}
+        for name, one in kinds.items():  # (every rank runs the same sequence: the exchanges are collective)
+            for _ in range(20):
+                one()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(200):
+                one()
+            torch.cuda.synchronize()
+            exchange_us[name] = round((time.perf_counter() - ta) / 200 * 1e6, 2)
+        exchange_used = next(iter(kinds))
+        allreduce_us = exchange_us[exchange_used]
     final_loss = float(tr.last_loss)
 
     # the same step WITH the rendered masks written (rb_solver.py:73-77 materialises `rendered_masks` every step): the
@@ -520,8 +527,10 @@ def main():
                        # form that does): `with_mask_ms_per_step` below times the same chain writing rendered_masks every step
                        "mask_output": False if tr.fast is not None else True,
                        "step": "torch autograd" if args.eager else ("HIP launch chain" + (", hipGraph replay" if used_graph else "")),
-                       "parallelism": (f"dp{world} over views, one 8-float all-reduce/step ("
-                                       + ("ncclAllReduce on the chain's stream, library-owned RCCL communicator"
+                       "parallelism": (f"dp{world} over views, one 8-float exchange/step ("
+                                       + ("peer-memory mailboxes over xGMI, sums in rank order + Adam in one kernel on the chain's stream"
+                                          if tr.fast is not None and tr.fast.p2p else
+                                          "ncclAllReduce on the chain's stream, library-owned RCCL communicator"
                                           if tr.fast is not None and tr.fast.rccl else "torch.distributed") + ")")
                        if world > 1 else "single GPU",
                        "final_mask_loss": round(final_loss, 3),
@@ -570,6 +579,7 @@ def main():
         if per_rank_ms is not None:
             out["per_rank_ms_per_step"] = per_rank_ms
             out["allreduce_8float_us"] = round(allreduce_us, 2)
+            out["exchange"] = {"used_by_the_step": exchange_used, "us_per_exchange_of_8_floats": exchange_us}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p)
         json_out.write(json.dumps(out) + "\n")

@@ -59,6 +59,10 @@ SIGNATURES = {
     "ehr_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "ehr_comm_allreduce": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "ehr_comm_destroy": (c_int, [c_void_p]),
+    "ehr_comm_p2p_export": (c_int, [c_void_p, c_void_p]),
+    "ehr_comm_p2p_open": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "ehr_comm_p2p_step": (c_int, [c_void_p] * 6 + [c_float] * 5 + [c_void_p, c_void_p, c_void_p]),
+    "ehr_comm_p2p_close": (c_int, [c_void_p]),
     "ehr_graph_begin": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "ehr_graph_end": (c_int, [c_void_p]),
     "ehr_graph_launch": (c_int, [c_void_p, c_void_p]),

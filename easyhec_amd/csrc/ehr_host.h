@@ -132,6 +132,10 @@ struct ehr_ctx {
     // RCCL communicator of the data-parallel exchange (ehr_comm_*; an ncclComm_t), created by the library itself
     void* comm = nullptr;
     int comm_ranks = 0;
+    // ... and the one-shot exchange over peer memory (ehr_comm_p2p_*): this rank's mailbox and the peers' (opened IPC handles)
+    void* p2p_mail = nullptr;
+    void* p2p_peer[EHR_P2P_MAX_RANKS] = {};
+    int p2p_ranks = 0, p2p_rank = 0;
     // natively captured launch chain (ehr_graph_*): capture stream and the instantiated graph
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;

@@ -489,7 +489,7 @@ using namespace ehr;
 
 extern "C" {
 
-int ehr_version(void) { return 6; }
+int ehr_version(void) { return 7; }
 
 const char* ehr_last_error(void) { return g_last_error.c_str(); }
 
@@ -533,6 +533,7 @@ int ehr_ctx_create(int device, ehr_ctx** out) {
 int ehr_ctx_destroy(ehr_ctx* c) {
     if (!c) return EHR_OK;
     (void)ehr_comm_destroy(c);
+    (void)ehr_comm_p2p_close(c);
     int cur = 0;
     (void)hipGetDevice(&cur);
     (void)hipSetDevice(c->device);

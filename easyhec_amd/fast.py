@@ -31,7 +31,7 @@ def ranks_agree(ok, pg, dev):
 
 class FusedPoseStep:
     def __init__(self, model, batch, lr=0.003, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0005, near=0.001, far=10.0,
-                 process_group=None, rccl=None, slack=None):
+                 process_group=None, rccl=None, slack=None, p2p=None):
         self.model = model
         self.renderer = model._ensure_renderer()
         self.scene = model._ensure_scene()
@@ -59,6 +59,38 @@ class FusedPoseStep:
         import os as _os
         self.rccl = bool(rccl) if rccl is not None else (
             self.distributed and (dist.get_backend(self.pg) == "nccl" or _os.environ.get("EHR_TRY_RCCL") == "1"))
+        # "p2p" (EHR_COMM=p2p, or p2p=True): the one-shot exchange over peer memory (ehr_comm_p2p_*: every rank stores its 8
+        # floats into every peer's mailbox, sums in rank order and runs Adam in the SAME kernel -- one launch instead of an
+        # all-reduce plus ehr_pose_adam).  Needs the ranks on GPUs of one node (or, for tests, on one GPU); set up over the
+        # process group, checked against it, and dropped by ALL ranks together if any rank cannot set it up.
+        self.p2p = False
+        # Default under the nccl backend (one process per GPU of a node): tried first, the RCCL all-reduce is the fall-back.
+        # EHR_COMM = p2p / rccl / torch forces the choice (p2p: under any backend, e.g. two test ranks on one device).
+        comm_env = _os.environ.get("EHR_COMM", "")
+        want_p2p = p2p if p2p is not None else (comm_env == "p2p" or (comm_env == "" and rccl is None and self.distributed
+                                                                       and dist.get_backend(self.pg) == "nccl"))
+        if comm_env in ("torch", "rccl") and p2p is None:
+            want_p2p = False
+        if comm_env == "torch" and rccl is None:
+            self.rccl = False
+        if want_p2p and self.distributed:
+            ok, why = True, ""
+            try:
+                self._init_p2p()
+            except RuntimeError as e:
+                ok, why = False, str(e)
+            if not ranks_agree(ok, self.pg, self.dev):
+                if ok:
+                    why = "another rank could not set it up"
+                    with torch.cuda.device(self.dev):
+                        _lib.lib().ehr_comm_p2p_close(self.glctx.handle)
+                if p2p:
+                    raise RuntimeError(f"peer-memory exchange unavailable: {why}")
+                import sys
+                print(f"[easyhec_amd] peer-memory exchange unavailable ({why}); using the all-reduce", file=sys.stderr)
+            else:
+                self.p2p = True
+                self.rccl = False
         if self.rccl:
             ok, why = True, ""
             try:
@@ -160,6 +192,45 @@ class FusedPoseStep:
             if not bool((probe == want).all()):
                 raise RuntimeError(f"ehr_comm_allreduce self-check: got {probe.tolist()}, expected {want}")
 
+    def _init_p2p(self):
+        """Mailboxes of the one-shot exchange (``ehr_comm_p2p_*``): every rank exports its mailbox's 64-byte IPC handle, the
+        handles travel over the process group that is already up, every rank opens its peers', and one exchange of a known
+        vector must give what it should before the solve depends on it.  Every rank makes the same collective calls whatever
+        fails locally (a rank that cannot export ships an all-zero handle; the open phase ends on an agreement)."""
+        lib = _lib.lib()
+        world, rank = dist.get_world_size(self.pg), dist.get_rank(self.pg)
+        hbuf, err = (ctypes.c_ubyte * 64)(), None
+        try:
+            with torch.cuda.device(self.dev):
+                _lib.check(lib.ehr_comm_p2p_export(self.glctx.handle, hbuf), "ehr_comm_p2p_export")
+        except RuntimeError as e:
+            hbuf, err = (ctypes.c_ubyte * 64)(), e
+        on_dev = dist.get_backend(self.pg) == "nccl"
+        mine = torch.tensor(list(hbuf), dtype=torch.uint8, device=self.dev if on_dev else "cpu")
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=self.pg)          # (also the barrier "every rank has exported")
+        flat = torch.stack(every).cpu().contiguous()
+        if err is None and not bool((flat != 0).any(dim=1).all()):
+            err = RuntimeError("a rank exported no mailbox")
+        if err is None:
+            try:
+                allh = (ctypes.c_ubyte * (64 * world))(*flat.view(-1).tolist())
+                with torch.cuda.device(self.dev):
+                    _lib.check(lib.ehr_comm_p2p_open(self.glctx.handle, allh, world, rank), "ehr_comm_p2p_open")
+            except RuntimeError as e:
+                err = e
+        if not ranks_agree(err is None, self.pg, self.dev):   # every rank has opened (or nobody goes on): stores may begin
+            raise err if err is not None else RuntimeError("another rank could not open the mailboxes")
+        with torch.cuda.device(self.dev):
+            probe = torch.full((8,), float(rank + 1), device=self.dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.check(lib.ehr_comm_p2p_step(self.glctx.handle, _lib.ptr(probe), None, None, None, None, _f(0), _f(0), _f(0),
+                                             _f(0), _f(0), None, None, stream), "ehr_comm_p2p_step")
+            torch.cuda.synchronize()
+        want = world * (world + 1) / 2.0
+        if not bool((probe == want).all()):
+            raise RuntimeError(f"ehr_comm_p2p_step self-check: got {probe.tolist()}, expected {want}")
+
     # -- one step -------------------------------------------------------------------------------------------------
     def _enqueue(self, want_mask, stream=None):
         lib = _lib.lib()
@@ -179,7 +250,13 @@ class FusedPoseStep:
             _lib.ptr(self.tc_jac), _lib.ptr(self.mask if want_mask else None), _lib.ptr(self.loss_b),
             _lib.ptr(self.grad_mvp), _lib.ptr(self.red), _lib.ptr(self.loss), _lib.ptr(self.grad),
             int(self.distributed or self.rccl), stream), "ehr_solver_step")
-        if self.distributed or self.rccl:
+        if self.p2p:
+            # the exchange and Adam in ONE launch: stores into the peers' mailboxes, a wait on the own one, sums in rank order
+            _lib.check(lib.ehr_comm_p2p_step(self.glctx.handle, _lib.ptr(self.red), _lib.ptr(dof), _lib.ptr(self.exp_avg),
+                                             _lib.ptr(self.exp_avg_sq), _lib.ptr(self.step_t), _f(self.lr), _f(self.betas[0]),
+                                             _f(self.betas[1]), _f(self.eps), _f(self.wd), _lib.ptr(self.loss),
+                                             _lib.ptr(self.grad), stream), "ehr_comm_p2p_step")
+        elif self.distributed or self.rccl:
             # the ONE collective of a step (32 bytes), between the chain and Adam
             if self.rccl:
                 _lib.check(lib.ehr_comm_allreduce(self.glctx.handle, _lib.ptr(self.red), 8, stream), "ehr_comm_allreduce")
@@ -243,8 +320,8 @@ class FusedPoseStep:
         torch.distributed exchange (gloo) it cannot be."""
         if self._graph:
             return
-        if self.distributed and not self.rccl:
-            raise RuntimeError("capture(): not available with the torch.distributed exchange (use the RCCL one)")
+        if self.distributed and not (self.rccl or self.p2p):
+            raise RuntimeError("capture(): not available with the torch.distributed exchange (use the RCCL or the peer-memory one)")
         lib = _lib.lib()
         with torch.cuda.device(self.dev):
             torch.cuda.synchronize()

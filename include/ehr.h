@@ -37,7 +37,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 6 (6: tile flags -- ehr_tile_flags_bytes, a tile_flags argument on ehr_rasterize_fwd / _grad, ehr_interpolate_fwd / _grad, ehr_antialias_fwd; 2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*, ehr_rasterize_grad_db) */
+int ehr_version(void);                 /* ABI version, currently 7 (7: ehr_comm_p2p_*; 6: tile flags -- ehr_tile_flags_bytes, a tile_flags argument on ehr_rasterize_fwd / _grad, ehr_interpolate_fwd / _grad, ehr_antialias_fwd; 2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*, ehr_rasterize_grad_db) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
@@ -232,6 +232,29 @@ int ehr_comm_unique_id(void* id128_host);
 int ehr_comm_init(ehr_ctx* ctx, const void* id128_host, int nranks, int rank);
 int ehr_comm_allreduce(ehr_ctx* ctx, float* red, int count, void* stream);
 int ehr_comm_destroy(ehr_ctx* ctx);
+
+/* The same exchange WITHOUT a collective library (ABI 7; SURVEY 5 / 8e's one-shot exchange over xGMI peer memory): a step of
+ * ~70 us has no room for a 10-30 us ncclAllReduce followed by a launch of its own for Adam.  Every rank owns a mailbox in its
+ * device memory; the exchange is one single-workgroup kernel per rank and step that stores the rank's 8 floats and a sequence
+ * number into its slot of every peer's mailbox (system-scope stores), waits for its own mailbox to fill, adds the slots up in
+ * rank order (bit-identical sums on every rank) and goes on to the Adam update of ehr_pose_adam in the same launch.
+ *   ehr_comm_p2p_export : allocates (once) and clears this context's mailbox and returns its 64-byte hipIpcMemHandle; the
+ *                         caller ships every rank's handle to every rank (any transport, e.g. an all_gather);
+ *   ehr_comm_p2p_open   : handles [nranks][64] in rank order (the own entry is ignored); opens the peers' mailboxes
+ *                         (hipIpcOpenMemHandle: ranks on different GPUs of one node, or -- for tests -- on the same GPU);
+ *                         nranks <= EHR_P2P_MAX_RANKS.  Every rank must have exported before any rank opens, and opened
+ *                         before any rank exchanges (the caller's barrier).
+ *   ehr_comm_p2p_step   : red[8] (device) <- sum over the ranks, in place; with dof != NULL the Adam update of ehr_pose_adam
+ *                         follows in the same kernel (same arguments).  Every rank must make the same sequence of calls.
+ *                         Enqueued on `stream`, capturable.  A peer that never answers is REPORTED after ~1 s: the sums are NaN
+ *                         and the optimiser state stays as it was.
+ *   ehr_comm_p2p_close  : closes the peers' mailboxes and frees the own one (ehr_ctx_destroy does it too). */
+#define EHR_P2P_MAX_RANKS 64
+int ehr_comm_p2p_export(ehr_ctx* ctx, void* handle64_host);
+int ehr_comm_p2p_open(ehr_ctx* ctx, const void* handles_host, int nranks, int rank);
+int ehr_comm_p2p_step(ehr_ctx* ctx, float* red, float* dof, float* m, float* v, int32_t* step, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
+int ehr_comm_p2p_close(ehr_ctx* ctx);
 
 /* hipGraph capture of launch chains.  ehr_graph_begin opens a capture on a stream the context owns and returns it; every
  * library call made with THAT stream until ehr_graph_end (e.g. one ehr_solver_step, or ehr_solver_step with defer_adam
