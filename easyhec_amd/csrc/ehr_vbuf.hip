@@ -2435,6 +2435,7 @@ vb_job_kernel(VbJobParams prm_) {
 #ifdef VB_TIMELINE
     const long long tl_heavy = wall_clock64();
     int tl_jobs = 0, tl_maxsurv = 0, tl_sumsurv = 0;
+    long long tl_last[4] = {0, 0, 0, 0}, tl_dry = 0;  // the wave's LAST job: start, rounds done, depth tests done, resolved
 #endif
 #ifdef VB_TIMELINE
     const int tl_hcost = (wave == 0) ? lds_all[0].tl_flushes : 0;
@@ -2483,7 +2484,12 @@ vb_job_kernel(VbJobParams prm_) {
                 if (lane == 0) job = jbeg + nsn + atomicAdd(cursor, 1);
                 job = __builtin_amdgcn_readfirstlane(job);
             }
-            if (job >= jend) break;
+            if (job >= jend) {
+#ifdef VB_TIMELINE
+                tl_dry = wall_clock64();  // this wave found its XCD's list of jobs empty
+#endif
+                break;
+            }
             if (U <= 64) {  // the last (view, link) whose first job is <= job: one LDS read per lane and a ballot
                 u = __popcll(__ballot(lane < U && upre[lane] <= job)) - 1;
             } else {
@@ -2530,9 +2536,13 @@ vb_job_kernel(VbJobParams prm_) {
         VB_WAVE_SYNC();
 #ifdef VB_TIMELINE
         const long long tl_j1 = __builtin_readcyclecounter();
+        tl_last[0] = wall_clock64();
 #endif
         int nsurv = 0, dln = 0;
         const int drawn = vb_job_raster<false, COVER>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
+#ifdef VB_TIMELINE
+        tl_last[1] = tl_last[2] = tl_last[3] = wall_clock64();  // culling + rasterizer rounds done
+#endif
         if (COVER) {
             // flagged units (their depth range must be tested per pixel: edge-on slivers mostly) are the only deferred ones
             if (drawn >= 0 && dln > 0)
@@ -2560,6 +2570,7 @@ vb_job_kernel(VbJobParams prm_) {
         }
         if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
 #ifdef VB_TIMELINE
+        tl_last[2] = tl_last[3] = wall_clock64();  // depth tests done
         tl_jobs++;
         tl_maxsurv = max(tl_maxsurv, nsurv);
         tl_sumsurv += nsurv;
@@ -2586,6 +2597,7 @@ vb_job_kernel(VbJobParams prm_) {
         vb_publish(A, S.key, S.cov, job, u, tx, ty);
 #endif
 #ifdef VB_TIMELINE
+        tl_last[3] = wall_clock64();  // resolved
         if (lane == 0) {
             const long long now = __builtin_readcyclecounter();
             S.tl_c[4] += now - tl_j0;
@@ -2612,6 +2624,9 @@ vb_job_kernel(VbJobParams prm_) {
         tx[7] = tl_hcost;
         for (int k = 0; k < 3; k++) tx[8 + k] = S.tl_c[4 + k];
         tx[11] = (S.tl_c[7] & 0xffffffffll) | ((long long)S.tl_cands << 32) | ((long long)S.tl_groups << 48);
+        long long* const ty = PRM(timeline) + 16 * (size_t)gridDim.x * 4 + 5 * gw;
+        for (int k = 0; k < 4; k++) ty[k] = tl_last[k];
+        ty[4] = tl_dry;
     }
 #endif
     if (MERGE && !COVER) {
@@ -3269,7 +3284,7 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
             // Timeline of the job kernel's waves (100 MHz clock), written into the (otherwise idle) spill pool: when
             // they started, left the heavy phase and ended; what their single-wave jobs amounted to; where they ran.
             const int nw = 4 * (((ctx->num_cus * 4) + 7) & ~7);
-            std::vector<long long> tl((size_t)16 * nw);
+            std::vector<long long> tl((size_t)21 * nw);
             EHR_HIP(hipMemcpy(tl.data(), ctx->vb_spill.ptr, tl.size() * sizeof(long long), hipMemcpyDeviceToHost));
             long long t0 = tl[0], t1 = tl[1];
             for (int i = 0; i < nw; i++) {
@@ -3308,6 +3323,31 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                         (tl[4 * i] - t0) * 0.01, (tl[4 * i + 2] - t0) * 0.01, (tl[4 * i + 1] - t0) * 0.01, x & 0xff, (x >> 8) & 0xfff,
                         (x >> 20) & 0xfff, tx[0], tx[1], tx[2] & 0xffff, (tx[2] >> 16) & 0xffffff, tx[2] >> 40, tx[3] * 1e-3, tx[4] * 1e-3, tx[5] * 1e-3,
                         tx[6] * 1e-3, tx[10] * 1e-3, tx[8] * 1e-3, (tx[11] & 0xffffffffll) * 1e-3, (tx[11] >> 32) & 0xffff, (tx[11] >> 48) & 0xffff, (x >> 48) & 0xf, (hw >> 8) & 15, (hw >> 4) & 3);
+            }
+            {   // Where a late helper could still help: the last job of the waves the kernel ends on, against the moment the
+                // lists of jobs ran dry (task 1b: late sharing inside a workgroup)
+                std::vector<long long> dry;
+                for (int i = 0; i < nw; i++)
+                    if (tl[16 * (size_t)nw + 5 * i + 4]) dry.push_back(tl[16 * (size_t)nw + 5 * i + 4] - t0);
+                std::sort(dry.begin(), dry.end());
+                const double d10 = dry.empty() ? 0.0 : dry[dry.size() / 10] * 0.01, d50 = dry.empty() ? 0.0 : dry[dry.size() / 2] * 0.01;
+                fprintf(stderr, "[ehr timeline] waves find their list of jobs empty: first %.1f, 10 %% %.1f, median %.1f us (%zu waves)\n",
+                        dry.empty() ? 0.0 : dry[0] * 0.01, d10, d50, dry.size());
+                fprintf(stderr, "[ehr timeline] last job of the last waves: start, rounds done, depth tests done, resolved [us]; rounds still to run when 10 %% / half of the waves were idle\n");
+                double left10 = 0, left50 = 0, tail10 = 0, tail50 = 0;
+                const int NL = std::min(64, nw);
+                for (int k = 0; k < NL; k++) {
+                    const int i = order[k].second;
+                    const long long* ty = &tl[16 * (size_t)nw + 5 * i];
+                    if (!ty[0]) continue;  // (a wave without a single-wave job)
+                    const double a = (ty[0] - t0) * 0.01, b = (ty[1] - t0) * 0.01, c = (ty[2] - t0) * 0.01, d = (ty[3] - t0) * 0.01;
+                    if (k < 12) fprintf(stderr, "   %5d: %5.1f %5.1f %5.1f %5.1f ; %4.1f / %4.1f us\n", i, a, b, c, d, std::max(0.0, b - std::max(a, d10)), std::max(0.0, b - std::max(a, d50)));
+                    left10 += std::max(0.0, b - std::max(a, d10)) / NL;
+                    left50 += std::max(0.0, b - std::max(a, d50)) / NL;
+                    tail10 += std::max(0.0, d - std::max(b, d10)) / NL;
+                    tail50 += std::max(0.0, d - std::max(b, d50)) / NL;
+                }
+                fprintf(stderr, "[ehr timeline] mean over the %d last waves: rounds still to run %.1f / %.1f us, depth tests + resolve after that %.1f / %.1f us\n", NL, left10, left50, tail10, tail50);
             }
             long long mx = 0, sum = 0;
             int used = 0;

@@ -1,7 +1,8 @@
 """``FusedPoseStep`` -- one optimisation step of /root/reference/easyhec/trainer/rbsolver.py:29-43 as a fixed chain of
-HIP launches with no host round trip: [pose forward + vertices + raster records] -> jobs (coverage, depth where the
-silhouette analysis will look) -> resolve -> composite [+ in its last workgroup: loss, gradients, pose backward] ->
-[all-reduce of 8 floats when data-parallel] -> Adam.
+three HIP launches with no host round trip: [pose forward + vertices + raster records] -> jobs (coverage, depth where the
+silhouette analysis will look, and the resolve of every job by the wave that drew it) -> composite [+ in its last
+workgroup: loss, gradients, pose backward, Adam]; data-parallel: the composite launch stops before Adam and ONE more
+launch exchanges the 8 floats with the peers and applies Adam (peer-memory mailboxes; or an all-reduce followed by Adam).
 
 It operates IN PLACE on an :class:`easyhec_amd.rb_solver.RBSolver`'s ``dof`` parameter and ``history_ops`` buffer and
 keeps torch.optim.Adam-compatible state (exp_avg, exp_avg_sq, step), so it is interchangeable with the autograd path
@@ -239,8 +240,9 @@ class FusedPoseStep:
         m, sc = self.model, self.scene
         dof = m.dof.data
         hist = m.history_ops
-        # one C call = 4 launches: [pose fwd + vertices + raster records] -> jobs [-> general-triangle jobs, once a step
-        # has needed them] -> resolve -> composite [+ in its last workgroup: accumulators + pose bwd (+ Adam)]
+        # one C call = 3 launches: [pose fwd + vertices + raster records] -> jobs, resolved by the waves that drew them
+        # [-> general-triangle jobs + their resolve, once a step has needed them] -> composite [+ in its last workgroup:
+        # accumulators + pose bwd (+ Adam)]
         _lib.check(lib.ehr_solver_step(
             self.glctx.handle, _lib.ptr(sc.verts), _lib.ptr(sc.tris), _lib.ptr(sc.tri_link), _lib.ptr(sc.vert_link),
             _lib.ptr(sc.opp), _lib.ptr(self.K), _lib.ptr(self.link_poses), _lib.ptr(self.ref), self.B, self.L,
@@ -313,11 +315,11 @@ class FusedPoseStep:
         self._probe_ev.record()
 
     def capture(self):
-        """Record the step's launch chain (5 kernels on one stream) into a hipGraph owned by the rasterizer context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it
-        with one host call.  Iteration state lives on the device, so replays are ordinary optimisation steps.  The
+        """Record the step's launch chain (3 kernels on one stream; 4-5 data-parallel) into a hipGraph owned by the rasterizer
+        context (``ehr_graph_*`` in include/ehr.h); ``step()`` then replays it with one host call.  Iteration state lives on the device, so replays are ordinary optimisation steps.  The
         chain is GPU-bound, so this saves host time, not step time.  The data-parallel step is captured too when its
-        exchange is the library's own ncclAllReduce (``rccl``: [solver step, all-reduce, Adam] on one stream); with the
-        torch.distributed exchange (gloo) it cannot be."""
+        exchange is the library's own -- the peer-memory one (``p2p``: [solver step, exchange + Adam]) or ncclAllReduce
+        (``rccl``: [solver step, all-reduce, Adam]) -- on one stream; with the torch.distributed exchange (gloo) it cannot be."""
         if self._graph:
             return
         if self.distributed and not (self.rccl or self.p2p):

@@ -165,10 +165,13 @@ int ehr_fused_bind_ref(ehr_ctx* ctx, const float* ref, void* stream);
  * hipEvents around its kernels on the launch stream.  ehr_fused_timing_read synchronises, writes the ACCUMULATED
  * milliseconds per stage since the last read and the number of calls covered, then resets.  Stages of the default
  * (visibility-buffer) chain: ms[0] vertex kernel (pose forward, clip-space vertices, per-triangle raster records, cluster
- * and link boxes), ms[1] job kernel (one wave per (view, link, tile): box culling, LDS rasterizer -- the dominant
- * kernel), ms[2] resolve kernel (one wave per drawn job: silhouette analysis, antialiased values, blended pairs), ms[4]
- * composite kernel (link sum, clamp, loss, mask, backward; its last-arriving workgroup runs the finish stage:
- * accumulators -> loss / grad_mvp [-> pose backward -> Adam]); ms[3], ms[5], ms[6] are unused (~0).
+ * and link boxes), ms[1] job kernel (one wave per (view, link, tile): box culling, LDS rasterizer, depth tests where the
+ * silhouette analysis will look, and -- since round 5 -- the resolve stage of the job it has just drawn: silhouette analysis,
+ * antialiased values, blended pairs; the dominant kernel), ms[4] composite kernel (link sum, clamp, loss, mask, backward; its
+ * last-arriving workgroup runs the finish stage: accumulators -> loss / grad_mvp [-> pose backward -> Adam]).  ms[2] brackets
+ * the general-triangle pass and the resolve kernel of the jobs it redrew, which the solver step launches only once a step
+ * has needed them: in the default chain it is an EMPTY pair of events and measures what a pair costs on this stack (every
+ * other figure includes about as much); ms[3], ms[5], ms[6] are unused (~0).
  * Not for use under graph capture. */
 #define EHR_FUSED_STAGES 7
 int ehr_fused_timing(ehr_ctx* ctx, int enable);
@@ -193,9 +196,9 @@ int ehr_pose_backward(const float* grad_mvp, const float* loss, const float* K, 
 int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* red, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float* loss_out, float* grad_out, void* stream);
 
-/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 4 launches (vertex + raster records, jobs, resolve,
- * composite + finish; a fifth one, the general-triangle pass for jobs with a triangle that crosses the near plane or is
- * wider than 512 pixels, joins the chain once a step has needed it: that step is reported as NaN like an overflow -- loss,
+/* One whole optimisation step (trainer/rbsolver.py:29-43) as a chain of 3 launches (vertex + raster records; jobs, which
+ * resolve themselves; composite + finish.  Two more -- the general-triangle pass for jobs with a triangle that crosses the
+ * near plane or is wider than 512 pixels, and the resolve kernel of what it redrew -- join the chain once a step has needed them: that step is reported as NaN like an overflow -- loss,
  * gradient NaN, optimiser state untouched --, ehr_fused_status() then returns EHR_ERR_RETRY and switches the pass on for
  * the context's later calls; run the step again, and re-capture the chain if it was captured in a graph.  A robot in
  * front of the camera never has such a triangle; the stateless ehr_render_mask_loss always launches the pass):
@@ -205,8 +208,12 @@ int ehr_pose_adam(float* dof, float* m, float* v, int32_t* step, const float* re
  * `step` [1] is Adam's step count (bias correction); `history_row` [1] is the row of history [history_rows,6] that
  * receives this step's pose (rb_solver.py:50-51: the first free row) and is advanced by the call -- two counters,
  * because a solver built on a loaded model starts a fresh optimiser but keeps appending to the history.  history ==
- * NULL records nothing.
- * defer_adam != 0 stops after `red` so that the caller can all-reduce it across ranks and then call ehr_pose_adam.
+ * NULL records nothing.  A REPORTED step (overflow: NaN loss, pose and optimiser state untouched) has recorded the unchanged
+ * pose; the next call of this context notices that neither `step` nor `history_row` has moved since and writes into the
+ * SAME row again, so the history holds one row per effective step -- on every rank of a data-parallel job alike (the NaN
+ * travels with the exchanged sums), without the caller rewinding anything (ABI 7).
+ * defer_adam != 0 stops after `red` so that the caller can exchange it across ranks and then apply Adam: ehr_comm_p2p_step
+ * (exchange + Adam in one launch), or ehr_comm_allreduce / any all-reduce followed by ehr_pose_adam.
  * Requires ehr_fused_plan for (B,L,V,T,H,W); never synchronises or allocates. */
 int ehr_solver_step(ehr_ctx* ctx, const float* verts, const int32_t* tris, const int32_t* tri_link,
                     const int32_t* vert_link, const int32_t* opp, const float* K, const float* link_poses,

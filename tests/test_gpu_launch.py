@@ -48,6 +48,25 @@ def test_nccl_group_rccl_exchange_and_graph_at_world_size_one():
     assert r["dp_ms_per_step"] <= 1.5 * r["plain_ms_per_step"], r
 
 
+def test_bench_with_two_ranks_on_one_device_and_the_peer_memory_exchange():
+    """VERDICT round 5, task 6: ``bench.py --gpus 2`` with the one-shot peer-memory exchange (EHR_COMM=p2p: IPC mailboxes; two
+    ranks on ONE device, which RCCL refuses and IPC allows): the step uses it, the line names it and prints its latency next to
+    torch.distributed's."""
+    port = 31900 + (os.getpid() % 1000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EHR_BENCH_BACKEND="gloo", EHR_BENCH_DEVICE="0", EHR_COMM="p2p")
+    args = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "10", "--no-cpu-baseline"]
+    out = subprocess.run(args, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["exchange"]["used_by_the_step"] == "peer_memory" and "peer-memory" in r["config"]["parallelism"]
+    ex = r["exchange"]["us_per_exchange_of_8_floats"]
+    assert 0.0 < ex["peer_memory"] < 1.0e5 and 0.0 < ex["torch_distributed"] < 1.0e5
+    assert np.isfinite(r["config"]["final_mask_loss"]) and r["value"] > 0
+
+
 @pytest.mark.parametrize("try_rccl", [False, True])
 def test_bench_with_two_ranks_on_one_device_over_gloo(try_rccl):
     """bench.py's N > 1 code -- the rendezvous, the collective warm-up decision, the broadcast in
