@@ -943,6 +943,28 @@ int ehro_transform_pos(const float* M, const float* verts, int V, float* pos) {
  * ref/mask are in image convention (row 0 = top).  exact_interp != 0 evaluates colour through the
  * interpolate arithmetic (b0 + b1 + b2 in float, may be 1 +- 1ulp); 0 uses exactly 1.0.
  */
+/* grow-only buffers kept between calls: three shared ones and six per thread (see ehro_render_mask_loss) */
+static void* g_keep[3];
+static size_t g_keep_n[3];
+static void* keep_buf(int k, size_t n) {
+    if (n > g_keep_n[k]) {
+        free(g_keep[k]);
+        g_keep[k] = malloc(n);
+        g_keep_n[k] = g_keep[k] ? n : 0;
+    }
+    return g_keep[k];
+}
+static __thread void* t_keep[6];
+static __thread size_t t_keep_n[6];
+static void* keep_thread_buf(int k, size_t n) {
+    if (n > t_keep_n[k]) {
+        free(t_keep[k]);
+        t_keep[k] = malloc(n);
+        t_keep_n[k] = t_keep[k] ? n : 0;
+    }
+    return t_keep[k];
+}
+
 int ehro_render_mask_loss(const float* verts, const int32_t* tris, const int32_t* tri_off, const int32_t* vert_off,
                           const float* mvp, const float* ref, int B, int L, int V, int T, int H, int W,
                           int exact_interp, float* mask, float* loss, float* grad_mvp) {
@@ -970,23 +992,25 @@ int ehro_render_mask_loss(const float* verts, const int32_t* tris, const int32_t
     int Vmax = 1;
     for (int l = 0; l < L; l++)
         if (vert_off[l + 1] - vert_off[l] > Vmax) Vmax = vert_off[l + 1] - vert_off[l];
-    float* si_all = (float*)malloc((size_t)B * L * P * sizeof(float));   /* per-(view, link) AA masks, GL row order */
-    float* gimg_all = (float*)malloc((size_t)B * P * sizeof(float));      /* d loss_b / d composite, GL row order */
-    double* rowsum = (double*)malloc((size_t)B * H * sizeof(double));
+    /* Work images are kept between calls (grow-only; the bench's cpu_baseline leg calls this in a loop): allocating and
+     * first-touching a few hundred MB per call from 64 threads at once serialises in the kernel's page-fault path and cost the
+     * all-cores leg more than its arithmetic. */
+    float* si_all = (float*)keep_buf(0, (size_t)B * L * P * sizeof(float));   /* per-(view, link) AA masks, GL row order */
+    float* gimg_all = (float*)keep_buf(1, (size_t)B * P * sizeof(float));      /* d loss_b / d composite, GL row order */
+    double* rowsum = (double*)keep_buf(2, (size_t)B * H * sizeof(double));
     if (!si_all || !gimg_all || !rowsum) {
-        free(si_all); free(gimg_all); free(rowsum);
         for (int l = 0; l < L; l++) { free(opp[l]); free(ltri[l]); }
         free(opp); free(ltri);
         return -2;
     }
 #pragma omp parallel
     {
-        float* rast = (float*)malloc(P * 4 * sizeof(float));
-        float* color = (float*)malloc(P * sizeof(float));
-        float* gcol = (float*)malloc(P * sizeof(float));
-        float* pos = (float*)malloc((size_t)Vmax * 4 * sizeof(float));
-        float* gpos = (float*)malloc((size_t)Vmax * 4 * sizeof(float));
-        float* ones = (float*)malloc((size_t)Vmax * sizeof(float));
+        float* rast = (float*)keep_thread_buf(0, P * 4 * sizeof(float));
+        float* color = (float*)keep_thread_buf(1, P * sizeof(float));
+        float* gcol = (float*)keep_thread_buf(2, P * sizeof(float));
+        float* pos = (float*)keep_thread_buf(3, (size_t)Vmax * 4 * sizeof(float));
+        float* gpos = (float*)keep_thread_buf(4, (size_t)Vmax * 4 * sizeof(float));
+        float* ones = (float*)keep_thread_buf(5, (size_t)Vmax * sizeof(float));
         for (int i = 0; i < Vmax; i++) ones[i] = 1.f;
 #pragma omp for collapse(2) schedule(dynamic, 1)
         for (int b = 0; b < B; b++)
@@ -1057,9 +1081,7 @@ int ehro_render_mask_loss(const float* verts, const int32_t* tris, const int32_t
                     for (int i = 0; i < 16; i++) out[i] = (float)G[i];
                 }
         }
-        free(rast); free(color); free(gcol); free(pos); free(gpos); free(ones);
     }
-    free(si_all); free(gimg_all); free(rowsum);
     for (int l = 0; l < L; l++) {
         free(opp[l]);
         free(ltri[l]);
