@@ -111,7 +111,8 @@ struct ehr_ctx {
     ehr::Scratch vb_boxes;   // uint2 pixel boxes of the current step: tbox [B][NC][64] | cbox [B][NC]
     ehr::Scratch vb_units;   // i32 [B][L][4] pixel boxes of the links (re-armed by the finish kernel)
     ehr::Scratch vb_acc;     // i64 [B][12 L + VB_LOSS_SLOTS * VB_LOSS_STRIDE] fixed-point sums, then the meta words
-    ehr::Scratch vb_posc;    // float4 [B][V] clip-space vertices
+    ehr::Scratch vb_posc;    // float4 [B][V] clip-space vertices (eager plans only)
+    bool vb_lazy = false;    // the plan computes clip-space vertices where they are looked up (VbLazy in ehr_vbuf.hip): V > 1.5 T
     ehr::Scratch vb_jobs;    // per (view, link, tile) job slot: value tile | blended pairs | count | spill base
     ehr::Scratch vb_spill;   // blended pairs of jobs that exceed their slot
     int vb_spill_cap = 0;    // ... in items

@@ -357,8 +357,8 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
     chunk_role &= 3;
     const bool first = bx == 0 && b == 0 && chunk_role == 1;
     const bool rearm = bx == 0 && b == 0 && chunk_role == 2;
-    // A view's work items: [0, nvb) blocks of 256 vertices (-> posc), then groups of four clusters (one wave per cluster,
-    // one lane per triangle).  The workgroup takes items bx, bx + gx, ...: the pose head above every item (exponential,
+    // A view's work items: [0, nvb) blocks of 256 vertices (-> posc; nvb = 0 where the plan computes clip-space vertices on
+    // demand, see VbLazy), then groups of four clusters (one wave per cluster, one lane per triangle).  The workgroup takes items bx, bx + gx, ...: the pose head above every item (exponential,
     // matrices: ~3 us of dependent arithmetic) is paid once per workgroup, not once per 256 vertices -- with one item per
     // workgroup the Franka scene (375 k vertices x 16 views) needed 32 k workgroups and 125 us.
     const int nitems = nvb + (cl.NC + 3) / 4;
@@ -670,6 +670,55 @@ struct VbRegion {
     int x0, y0, x1, y1;  // pixels of the region inside the image (inclusive); region origin = (rx0, ry0) below
 };
 
+// Clip-space vertices ON DEMAND (round 6).  Until round 5 the vertex kernel wrote every vertex's clip-space position per view
+// (posc [B][V] float4) for the few thousand the depth tests, the silhouette analysis and the backward pass look up per step --
+// at Franka 16 x 1080p (unshared vertices: V = 3 T) 168 MB of a 286 MB, bandwidth-bound launch.  The consumers now
+// transform the object-space vertex themselves: the same fma chain (transform_vertex) on the same matrix (mvp[b][l], which
+// the vertex kernel publishes) gives the same bits.  VbLazy is what travels (two pointers); VbVerts holds the matrix in
+// scalar registers for the short stretch in which vertices are looked up.
+struct VbLazy {
+    const float* verts;  // [V][3] object-space vertices
+    const float* M;      // mvp[b][l], 16 floats: the job's (view, link) -- wave-uniform
+    const float4* pc;    // the view's clip-space vertices (posc + b V) where the plan keeps them (LAZY = false), else NULL
+};
+// LAZY = true: the matrix in scalar registers, a vertex = three loads + twelve fmas; false: a vertex = one 16-byte load.
+// A template, not a run-time switch: the sixteen scalars of the lazy form cost the job kernel -- which has six registers to
+// spare -- 19 more spilled VGPRs (8 views: 41.3 -> 44.8 us) whether they are used or not, so the plan picks the instantiation:
+// lazy where vertices outnumber what is looked up by far (unshared vertices, V > 1.5 T: Franka 16 x 1080p, vertex stage
+// 64.8 -> 46.8 us, step 175.5 -> 163.1 us), eager otherwise.
+template <bool LAZY>
+struct VbVertsT;
+template <>
+struct VbVertsT<true> {
+    const float* verts;
+    float M[16];
+    __device__ __forceinline__ float4 operator[](int v) const {
+        const float* a = verts + 3 * (size_t)v;
+        return transform_vertex(M, a[0], a[1], a[2]);
+    }
+};
+template <>
+struct VbVertsT<false> {
+    const float4* pc;
+    __device__ __forceinline__ float4 operator[](int v) const { return pc[v]; }
+};
+template <bool LAZY>
+__device__ __forceinline__ VbVertsT<LAZY> vb_verts(const VbLazy& z);
+template <>
+__device__ __forceinline__ VbVertsT<true> vb_verts<true>(const VbLazy& z) {
+    VbVertsT<true> r;
+    r.verts = z.verts;
+#pragma unroll
+    for (int k = 0; k < 16; k++) r.M[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z.M[k])));
+    return r;
+}
+template <>
+__device__ __forceinline__ VbVertsT<false> vb_verts<false>(const VbLazy& z) {
+    VbVertsT<false> r;
+    r.pc = z.pc;
+    return r;
+}
+
 // What stage 2 has to leave behind for a (view, link, region) is (a) which region pixels the link covers and (b) the
 // nearest triangle at those covered pixels that have an uncovered 4-neighbour: only pairs of one covered and one
 // uncovered pixel reach the silhouette analysis (with constant colour inside a link a blend between two covered pixels
@@ -790,8 +839,8 @@ __device__ __forceinline__ void vb_raster_wide(float4 pa, float4 pb, float4 pc, 
 // those pixels.  Units of unsafe triangles (flag) are always tested, at all their pixels, and set their coverage bits.
 // COVER (scoring op): the list holds flagged units only; a pixel that passes the depth-range test is covered, and one whose
 // depth is not positive raises *bad (the coverage-only chain cannot decide that pixel: the caller falls back).
-template <bool COVER = false>
-__device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n, const float4* __restrict__ pv,
+template <bool COVER = false, bool LAZY = false>
+__device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n, const VbLazy& pvz,
                                       const int4* __restrict__ cvidx_link, int W, int H, int rx0, int ry0) {
     const int lane = lane_id();
     VB_TL_BEGIN();
@@ -823,6 +872,7 @@ __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n
         nk += __popcll(km);
     }
     VB_WAVE_SYNC();
+    const VbVertsT<LAZY> pv = vb_verts<LAZY>(pvz);  // (lazy: the matrix in scalar registers for the tests below)
     for (int base = 0; base < nk; base += 64) {
         const int i = base + lane;
         if (i < nk) {
@@ -865,10 +915,10 @@ __device__ __forceinline__ void vb_flush(VbWaveLds& S, u64* key, u64* cov, int n
 // COVER: the coverage-only form of the scoring op's chain -- no deferred units, no depth anywhere: every triangle must be
 // of the class "coverage decides" (kind 0 under the positive-depth test), anything else aborts the job (-1); what is
 // already covered (not just interior) hides a box.
-template <bool WIDE, bool COVER = false>
+template <bool WIDE, bool COVER = false, bool LAZY = false>
 __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned srel, const VbRecs& rc, const VbRegion& rg,
                                                int rx0, int ry0, int W, int H, VbWaveLds& S, u64* key, u64* cov, int n,
-                                               const float4* __restrict__ pv, const int4* __restrict__ cvidx_link, bool& full,
+                                               const VbLazy& pv, const int4* __restrict__ cvidx_link, bool& full,
                                                int& cost, int qh) {
     VbRaster& R = S.R;
     const int lane = lane_id();
@@ -1044,7 +1094,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             // the deferred list takes at most 64 entries per step: walk as many steps as it has room for
             const int room = (VB_DL - n) >> 6;
             if (room == 0) {
-                vb_flush<COVER>(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
+                vb_flush<COVER, LAZY>(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
                 n = 0;
                 continue;
             }
@@ -1249,7 +1299,7 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
                 const int inc = vb_scan_add(cnt);
                 const int T = vb_readlane(inc, 63);
                 if (n + T > VB_DL) {  // no room for this step's entries: flush, then take the step again
-                    vb_flush<COVER>(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
+                    vb_flush<COVER, LAZY>(S, key, cov, n, pv, cvidx_link, W, H, rx0, ry0);
                     n = 0;
                     continue;
                 }
@@ -1292,7 +1342,8 @@ __device__ __forceinline__ int vb_raster_round(bool sv, size_t slot, unsigned sr
             const int s = __ffsll((unsigned long long)wm) - 1;
             wm &= wm - 1;
             const int4 vi = cvidx_link[vb_readlane((int)srel, s)];
-            vb_raster_wide(pv[vi.x], pv[vi.y], pv[vi.z], vi.w, W, H, rg, rx0, ry0, key, cov);
+            const VbVertsT<LAZY> pvv = vb_verts<LAZY>(pv);
+            vb_raster_wide(pvv[vi.x], pvv[vi.y], pvv[vi.z], vi.w, W, H, rg, rx0, ry0, key, cov);
         }
     }
     return n;
@@ -1326,7 +1377,9 @@ __device__ __forceinline__ bool vb_unit_tiles(const int* __restrict__ bx, int W,
 #endif
 struct VbJobArgs {
     VbRecs rc;
-    const float4* posc;   // [B][V] clip-space vertices
+    const float* verts;   // [V][3] object-space vertices
+    const float* mvp;     // [B][L][16] the chunk's (view, link) matrices: clip-space vertices are computed on demand (VbLazy) ...
+    const float4* posc;   // ... or read from here ([B][V]) where the plan keeps them (NULL: lazy)
     const int4* cvidx;    // [NC * 64] {v0, v1, v2, triangle} of every cluster slot
     const int* lcoff;     // LDS: first cluster of every link
     unsigned* jid;        // job slots: triangle ids of the region's pixels
@@ -1342,7 +1395,7 @@ struct VbJobArgs {
 // job.  The survivors' covered units are left in the wave's deferred list (dln entries on return): the caller flushes it
 // once the job's coverage is complete.  Returns 1 if anything survived the culling, 0 if not, and -1 (lean
 // instantiation only) if a survivor needs the general path: the caller then redoes the job with vb_job_slow.
-template <bool WIDE, bool COVER = false>
+template <bool WIDE, bool COVER = false, bool LAZY = false>
 __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, u64* key_, u64* cov_, int b, int l,
                                              const VbRegion& rg, int rx0, int ry0, int share, int nshare, int& nsurv,
                                              int& dln) {
@@ -1353,7 +1406,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
     // Survivors of the triangle-box test are queued (record slots) until 64 are waiting, so that every round of
     // the rasterizer is full; the triangle boxes of up to VB_CULL_GROUP candidate clusters are fetched per round trip.
     const size_t vbase = (size_t)b * A.NC * 64;
-    const float4* const pv = A.posc + (size_t)b * A.V;
+    const VbLazy pv = {A.verts, A.mvp + ((size_t)b * A.L + l) * 16, A.posc ? A.posc + (size_t)b * A.V : nullptr};
     const int4* const cvl = A.cvidx + (size_t)c0 * 64;  // the link's first cluster slot
     const unsigned srel0 = (unsigned)c0 * 64u;
     bool full = false;   // set by a round that finds the whole region interior
@@ -1466,7 +1519,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
                     while (qn >= 64) {
                         VB_WAVE_SYNC();
                         const unsigned sl = W_.sq[(qh + lane) & (VB_SQ - 1)];
-                        dln = vb_raster_round<WIDE, COVER>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
+                        dln = vb_raster_round<WIDE, COVER, LAZY>(true, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
                         if (dln < 0) return -1;
                         if (full) return 1;  // every pixel of the region is interior: nothing can change any more
                         qh = (qh + 64) & (VB_SQ - 1);
@@ -1488,7 +1541,7 @@ __device__ __forceinline__ int vb_job_raster(const VbJobArgs& A, VbWaveLds& W_, 
         VB_WAVE_SYNC();
         const bool sv = lane < qn;
         const unsigned sl = sv ? W_.sq[(qh + lane) & (VB_SQ - 1)] : srel0;
-        dln = vb_raster_round<WIDE, COVER>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
+        dln = vb_raster_round<WIDE, COVER, LAZY>(sv, vbase + sl, sl - srel0, A.rc, rg, rx0, ry0, A.W, A.H, W_, key_, cov_, dln, pv, cvl, full, nsurv, qh);
         if (dln < 0) return -1;
     }
     return drawn ? 1 : 0;
@@ -1526,6 +1579,7 @@ __device__ __forceinline__ void vb_publish(const VbJobArgs& A, const u64* key_, 
 // job falls back to when the lean code meets such a triangle.  Runs in a kernel of its own (vb_slow_kernel) over the list
 // of such jobs: compiled into the job kernel -- inline or as a call, in the rounds or at the job loop's end -- the general
 // path cost the lean code 50-70 spilled registers and 13 us at 8 views.
+template <bool LAZY>
 __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, int job, int u, int tx, int ty) {
     const int lane = lane_id();
     const int b = u / A.L, l = u - b * A.L;
@@ -1544,8 +1598,8 @@ __device__ __forceinline__ void vb_job_slow(const VbJobArgs& A, VbWaveLds& S, in
     if (lane < VB_RH) S.cov[lane] = 0ull;
     VB_WAVE_SYNC();
     int nsurv = 0, dln = 0;
-    const int drawn = vb_job_raster<true>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
-    if (dln > 0) vb_flush(S, S.key, S.cov, dln, A.posc + (size_t)b * A.V, A.cvidx + (size_t)A.lcoff[l] * 64, A.W, A.H, rx0, ry0);
+    const int drawn = vb_job_raster<true, false, LAZY>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
+    if (dln > 0) vb_flush<false, LAZY>(S, S.key, S.cov, dln, VbLazy{A.verts, A.mvp + ((size_t)b * A.L + l) * 16, A.posc ? A.posc + (size_t)b * A.V : nullptr}, A.cvidx + (size_t)A.lcoff[l] * 64, A.W, A.H, rx0, ry0);
     if (drawn > 0) {
         vb_publish(A, S.key, S.cov, job, u, tx, ty);
     } else if (lane == 0) {
@@ -1581,7 +1635,10 @@ __device__ __forceinline__ void vb_put_aside(int4* __restrict__ slow_list, int* 
 
 // Kernel-wide arguments of the resolve stage (what vb_resolve_job needs besides the job itself).
 struct VbResolveArgs {
-    const float4* posc;   // [B][V] clip-space vertices
+    const float* verts;   // [V][3] object-space vertices
+    const float* mvp;     // [B][L][16] (clip-space vertices on demand: VbLazy) ...
+    const float4* posc;   // ... or kept: [B][V] (NULL: lazy)
+    int L;
     const int4* tri4;     // [T] padded index table
     const int4* opp4;     // [T] opposite vertices (edge topology)
     int* jn;              // job slots: number of blended pairs (-1: the link contributes nothing to the tile)
@@ -1601,12 +1658,11 @@ struct VbResolveArgs {
 // (jitems) and their number (jn; -1 = the link contributes nothing here).  pairA [2 * VB_RN] and hits [2 * VB_RN] are the
 // wave's LDS work areas.  Called by the job kernel right after a job's depth tests (the ids never leave LDS) and by
 // vb_resolve_kernel for the jobs vb_slow_kernel drew.
-template <bool COH = false>
+template <bool COH = false, bool LAZY = false>
 __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const unsigned* ids, float* pairA,
                                                unsigned short* hits, const u64 (&C)[VB_WORDS], size_t slot, int b,
-                                               int rx0, int ry0) {
+                                               int l, int rx0, int ry0) {
     const int lane = lane_id();
-    const float4* const posc = Q.posc;
     const int4* const tri4 = Q.tri4;
     const int4* const opp4 = Q.opp4;
     int* const jn = Q.jn;
@@ -1619,7 +1675,7 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
 #define KT(i) (ids[i])
     const int r = lane >> 3, c4 = (lane & 7) * 4;
     const int myq = (r + 1) * VB_RW + (c4 + 1);
-    const float4* const pv = posc + (size_t)b * V;
+    const VbLazy pvz = {Q.verts, Q.mvp + ((size_t)b * Q.L + l) * 16, Q.posc ? Q.posc + (size_t)b * V : nullptr};
     int nitems = 0;       // wave-uniform
     int spill_base = -1;  // wave-uniform: first item of this job's spill block, once one was needed
     VB_WAVE_SYNC();
@@ -1684,6 +1740,7 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
         }
         VB_WAVE_SYNC();
         // ---- silhouette analysis of the hits (restates nvdiffrast's antialias mesh kernel), 64 per round
+        const VbVertsT<LAZY> pv = vb_verts<LAZY>(pvz);
         for (int hbase = 0; hbase < nh; hbase += 64) {
             const int h = hbase + lane;
             VbItem it;
@@ -1796,9 +1853,9 @@ __device__ __forceinline__ void vb_resolve_job(const VbResolveArgs& Q, const uns
 // Nothing of the job's region goes through global memory, and the resolve stage needs no launch of its own: it was a
 // 10 us kernel of one dependent chain per job behind a boundary; here the chain runs while other waves still rasterize.
 // (Resolve and rasterizer never overlap inside a wave: the live ranges of the two are disjoint, unlike round 2's fusion.)
-template <bool COH = false>
+template <bool COH = false, bool LAZY = false>
 __device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWaveLds& S, u64* key, const u64* cov, size_t slot,
-                                                    int b, int rx0, int ry0) {
+                                                    int b, int l, int rx0, int ry0) {
     const int lane = lane_id();
     static_assert(VB_RN <= VB_DL && 2 * VB_RN * sizeof(unsigned short) <= sizeof(VbRaster), "ids live in the deferred list's storage, the hit list in the rounds' staging area");
     VB_WAVE_SYNC();
@@ -1822,7 +1879,7 @@ __device__ __forceinline__ void vb_resolve_from_lds(const VbResolveArgs& Q, VbWa
         const unsigned i = 64u * k + lane;
         if (i < (unsigned)VB_RN) ids[i] = idw[k];
     }
-    vb_resolve_job<COH>(Q, ids, reinterpret_cast<float*>(key), reinterpret_cast<unsigned short*>(&S.R), C, slot, b, rx0, ry0);
+    vb_resolve_job<COH, LAZY>(Q, ids, reinterpret_cast<float*>(key), reinterpret_cast<unsigned short*>(&S.R), C, slot, b, l, rx0, ry0);
     VB_WAVE_SYNC();
 }
 
@@ -1841,7 +1898,7 @@ __device__ __forceinline__ void vb_zero_tile_row(float* __restrict__ mask, size_
 struct VbCompArgs {  // what the composite stage needs besides its LDS tables
     BinGeom g;
     int B;
-    const float4* posc;
+    const float* mvp;    // [B][L][16] (clip-space vertices on demand: VbLazy)
     int V;
     const float* verts;
     const int* jn;
@@ -1872,7 +1929,7 @@ __device__ __forceinline__ void vb_composite_items(const VbCompArgs& C, const in
     const int W = g.W, H = g.H, L = g.L, B = C.B, U = B * L;
     const bool sparse = C.tsum != nullptr;
     const int jcap = C.jcap, dbg = C.dbg, nls = C.nls, want_grad = C.want_grad, vec_ok = C.vec_ok, V = C.V, spill_cap = C.spill_cap;
-    const float4* const posc = C.posc;
+    const float* const mvpc = C.mvp;
     const float* const verts = C.verts;
     const int* const jn = C.jn;
     const float* const jval = C.jval;
@@ -2026,7 +2083,6 @@ __device__ __forceinline__ void vb_composite_items(const VbCompArgs& C, const in
     if (!want_grad || bmask == 0 || (dbg & 4)) continue;
 
     // ---- backward: blended pairs -> rows (x, y, w) of d loss / d MVP, per link
-    const float4* const pv = posc + (size_t)b * V;
     VB_WAVE_SYNC();  // the previous tile's reads of gpix are complete
 #pragma unroll
     for (int j = 0; j < 4; j++) gpix[r * EHR_TILE_W + c4 + j] = gv[j];
@@ -2043,6 +2099,7 @@ __device__ __forceinline__ void vb_composite_items(const VbCompArgs& C, const in
             if (sbase < 0 || sbase >= spill_cap) n = VB_JOB_ITEMS;
             else n = min(n, VB_JOB_ITEMS + (spill_cap - sbase));
         }
+        const VbVertsT<true> pv = vb_verts<true>(VbLazy{verts, mvpc + ((size_t)b * L + l) * 16, nullptr});  // (the link's matrix: clip space on demand)
         float G[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) G[k] = 0.f;
@@ -2064,10 +2121,12 @@ __device__ __forceinline__ void vb_composite_items(const VbCompArgs& C, const in
                 py += d;
             }
             float g1[3], g2[3];
-            aa_pos_grad(pv[itm.v1], pv[itm.v2], px, py, d, itm.alpha, dd, W, H, g1, g2);
             const float* a1 = verts + 3 * (size_t)itm.v1;
             const float* a2 = verts + 3 * (size_t)itm.v2;
             const float h1[4] = {a1[0], a1[1], a1[2], 1.f}, h2[4] = {a2[0], a2[1], a2[2], 1.f};
+            // (the object-space vertices are needed for the matrix gradient anyway: their clip-space positions come from them)
+            aa_pos_grad(transform_vertex(pv.M, h1[0], h1[1], h1[2]), transform_vertex(pv.M, h2[0], h2[1], h2[2]), px, py, d,
+                        itm.alpha, dd, W, H, g1, g2);
 #pragma unroll
             for (int rr = 0; rr < 3; rr++)
 #pragma unroll
@@ -2133,7 +2192,9 @@ struct VbJobParams {
     int dbg;
     VbHeavy hv;
     long long* timeline;
-    const float4* posc;
+    const float* verts;  // object-space vertices and the chunk's matrices: clip-space vertices are computed on demand (VbLazy) ...
+    const float* mvp;
+    const float4* posc;  // ... or kept per view ([B][V]) by the eager instantiations (NULL: lazy)
     int V;
     VbSlotIdx si;
     u64* jcov;
@@ -2171,7 +2232,7 @@ __device__ __forceinline__ T vb_load_pod(const T* p) { return *p; }
 template <class P>
 __device__ __forceinline__ VbResolveArgs vb_load_rq(P p) {
     VbResolveArgs q;
-    q.posc = p->rq.posc; q.tri4 = p->rq.tri4; q.opp4 = p->rq.opp4; q.jn = p->rq.jn; q.jval = p->rq.jval;
+    q.verts = p->rq.verts; q.mvp = p->rq.mvp; q.posc = p->rq.posc; q.L = p->rq.L; q.tri4 = p->rq.tri4; q.opp4 = p->rq.opp4; q.jn = p->rq.jn; q.jval = p->rq.jval;
     q.jitems = p->rq.jitems; q.jspill = p->rq.jspill; q.spill = p->rq.spill; q.meta = p->rq.meta; q.V = p->rq.V;
     q.T = p->rq.T; q.W = p->rq.W; q.H = p->rq.H; q.spill_cap = p->rq.spill_cap; q.want_grad = p->rq.want_grad;
     q.dbg = p->rq.dbg;
@@ -2187,7 +2248,7 @@ __device__ __forceinline__ VbResolveArgs vb_load_rq(P p) {
 // vb_composite_kernel would -- tables already in LDS, no launch boundary (cache write-back + invalidate, dispatch, tables:
 // 13 of that launch's 18 us were not tile work).  Job slots travel at agent scope (vb_st_* / vb_ld_*<true>).  A wait that
 // does not end (a grid that is not resident after all) is REPORTED through the overflow flag after ~50 ms, never a hang.
-template <bool COVER, bool MERGE = false>
+template <bool COVER, bool MERGE = false, bool LAZY = false>
 __global__ void __launch_bounds__(256, VB_JOB_WAVES)
 vb_job_kernel(VbJobParams prm_) {
     __shared__ VbWaveLds lds_all[4];
@@ -2205,7 +2266,9 @@ vb_job_kernel(VbJobParams prm_) {
     const int W = PRM(g.W), H = PRM(g.H), L = PRM(g.L), gnt = PRM(g.nt), gntx = PRM(g.ntx);
     const int B = PRM(B), V = PRM(V), dbg = PRM(dbg);
     int heavy_t = max(PRM(heavy_t), PRM(hv.gen)[6]);  // (the value in force: the vertex kernel adapts it, see VbHeavy)
-    const float4* const posc = PRM(posc);
+    const float* const pverts = PRM(verts);
+    const float* const pmvp = PRM(mvp);
+    const float4* const posc = LAZY ? nullptr : PRM(posc);
 #ifdef VB_TIMELINE  // profiling build only (-DVB_TIMELINE): a record per wave, printed by vbuf_meta_read under EHR_VB_PRINT
     const long long tl_start = wall_clock64();
 #endif
@@ -2303,6 +2366,8 @@ vb_job_kernel(VbJobParams prm_) {
     A.rc.cbox = PRM(rc.cbox);
     A.rc.trec = PRM(rc.trec);
     A.rc.n = PRM(rc.n);
+    A.verts = pverts;
+    A.mvp = pmvp;
     A.posc = posc;
     A.cvidx = PRM(si.cvidx);
     A.lcoff = lcoff;
@@ -2354,7 +2419,7 @@ vb_job_kernel(VbJobParams prm_) {
 #if VB_PRIO_HEAVY
     if ((int)blockIdx.x < nheavy) __builtin_amdgcn_s_setprio(VB_PRIO_HEAVY);
 #endif
-    int hres_job = -1, hres_b = 0, hres_rx0 = 0, hres_ry0 = 0;  // the heavy job wave 0 resolves once the workgroup has split up again
+    int hres_job = -1, hres_b = 0, hres_l = 0, hres_rx0 = 0, hres_ry0 = 0;  // the heavy job wave 0 resolves once the workgroup has split up again
     for (int hj = blockIdx.x; hj < nheavy; hj += gridDim.x) {  // workgroup-uniform (at most one turn: nheavy <= gridDim.x)
         const int id = (hj == (int)blockIdx.x) ? hid_first : PRM(hv.list)[hcur * VB_HEAVY_CAP + hj];
         const int u = min((int)((unsigned)id >> 22), U - 1), tx = id & 1023, ty = (id >> 10) & 4095;
@@ -2375,7 +2440,7 @@ vb_job_kernel(VbJobParams prm_) {
         if (tid < VB_RH) S0.cov[tid] = 0ull;
         __syncthreads();
         int nsurv = 0, dln = 0;
-        const int drawn = vb_job_raster<false>(A, S, S0.key, S0.cov, b, l, rg, rx0, ry0, wave, 4, nsurv, dln);
+        const int drawn = vb_job_raster<false, false, LAZY>(A, S, S0.key, S0.cov, b, l, rg, rx0, ry0, wave, 4, nsurv, dln);
         if (lane == 0) {
             if (drawn > 0) atomicOr(&s_heavy[0], 1);
             if (drawn < 0) atomicOr(&s_heavy[0], 2);  // a triangle for the general path: wave 0 redoes the job alone
@@ -2385,12 +2450,13 @@ vb_job_kernel(VbJobParams prm_) {
         const int any_drawn = s_heavy[0];
         int tot_surv = s_heavy[1];
         if (!(any_drawn & 2) && dln > 0)
-            vb_flush(S, S0.key, S0.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+            vb_flush<false, LAZY>(S, S0.key, S0.cov, dln, VbLazy{pverts, pmvp + ((size_t)b * L + l) * 16, LAZY ? nullptr : posc + (size_t)b * V}, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
         __syncthreads();
 #if VB_INLINE_RESOLVE
         if (!COVER && any_drawn == 1) {
             hres_job = job;
             hres_b = b;
+            hres_l = l;
             hres_rx0 = rx0;
             hres_ry0 = ry0;
         }
@@ -2422,7 +2488,7 @@ vb_job_kernel(VbJobParams prm_) {
 
 #if VB_INLINE_RESOLVE
     // (the loop's last barrier is behind us: waves 1-3 go on to their own jobs, nobody touches wave 0's LDS but wave 0)
-    if (!COVER && wave == 0 && hres_job >= 0) vb_resolve_from_lds<MERGE>(VB_RQ(), S, S.key, S.cov, (size_t)hres_job, hres_b, hres_rx0, hres_ry0);
+    if (!COVER && wave == 0 && hres_job >= 0) vb_resolve_from_lds<MERGE, LAZY>(VB_RQ(), S, S.key, S.cov, (size_t)hres_job, hres_b, hres_l, hres_rx0, hres_ry0);
 #endif
 #if VB_PRIO_HEAVY
     __builtin_amdgcn_s_setprio(0);
@@ -2541,14 +2607,14 @@ vb_job_kernel(VbJobParams prm_) {
         tl_last[0] = wall_clock64();
 #endif
         int nsurv = 0, dln = 0;
-        const int drawn = vb_job_raster<false, COVER>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
+        const int drawn = vb_job_raster<false, COVER, LAZY>(A, S, S.key, S.cov, b, l, rg, rx0, ry0, 0, 1, nsurv, dln);
 #ifdef VB_TIMELINE
         tl_last[1] = tl_last[2] = tl_last[3] = wall_clock64();  // culling + rasterizer rounds done
 #endif
         if (COVER) {
             // flagged units (their depth range must be tested per pixel: edge-on slivers mostly) are the only deferred ones
             if (drawn >= 0 && dln > 0)
-                vb_flush<true>(S, S.key, S.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+                vb_flush<true, LAZY>(S, S.key, S.cov, dln, VbLazy{pverts, pmvp + ((size_t)b * L + l) * 16, LAZY ? nullptr : posc + (size_t)b * V}, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
             VB_WAVE_SYNC();
             if (drawn < 0 || S.bad) {  // a triangle for the general path, or a drawn pixel with a depth <= 0: coverage cannot
                 if (lane == 0) PRM(jn)[0] = 1;  // decide here and the caller falls back for the whole call
@@ -2570,7 +2636,7 @@ vb_job_kernel(VbJobParams prm_) {
             if (lane == 0) vb_put_aside<MERGE>(PRM(slow_list), PRM(meta), PRM(jn), PRM(jdesc), job, u, tx, ty);
             continue;
         }
-        if (dln > 0) vb_flush(S, S.key, S.cov, dln, posc + (size_t)b * V, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
+        if (dln > 0) vb_flush<false, LAZY>(S, S.key, S.cov, dln, VbLazy{pverts, pmvp + ((size_t)b * L + l) * 16, LAZY ? nullptr : posc + (size_t)b * V}, PRM(si.cvidx) + (size_t)lcoff[l] * 64, W, H, rx0, ry0);
 #ifdef VB_TIMELINE
         tl_last[2] = tl_last[3] = wall_clock64();  // depth tests done
         tl_jobs++;
@@ -2594,7 +2660,7 @@ vb_job_kernel(VbJobParams prm_) {
         const long long tl_j2 = __builtin_readcyclecounter();
 #endif
 #if VB_INLINE_RESOLVE
-        vb_resolve_from_lds<MERGE>(VB_RQ(), S, S.key, S.cov, slot, b, rx0, ry0);
+        vb_resolve_from_lds<MERGE, LAZY>(VB_RQ(), S, S.key, S.cov, slot, b, l, rx0, ry0);
 #else
         vb_publish(A, S.key, S.cov, job, u, tx, ty);
 #endif
@@ -2703,7 +2769,8 @@ vb_job_kernel(VbJobParams prm_) {
 
 // Stage 2a (normally empty): the jobs the lean code put aside, one wave each, with the general triangle path.
 __global__ void __launch_bounds__(256)
-vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ posc, int V, VbSlotIdx si,
+vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float* __restrict__ verts, const float* __restrict__ mvp,
+               const float4* __restrict__ posc, int V, VbSlotIdx si,
                unsigned* __restrict__ jid, u64* __restrict__ jcov, int* __restrict__ jdesc, int* __restrict__ jn,
                const int4* __restrict__ slow_list, const int* __restrict__ meta) {
     const int n = *vb_line(const_cast<int*>(meta), 17);
@@ -2712,6 +2779,8 @@ vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ p
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VbJobArgs A;
     A.rc = rc;
+    A.verts = verts;
+    A.mvp = mvp;
     A.posc = posc;
     A.cvidx = si.cvidx;
     A.lcoff = cl.coff;
@@ -2727,7 +2796,10 @@ vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ p
     (void)lane;
     for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
         const int4 e = slow_list[i];
-        vb_job_slow(A, lds_all[wave], e.x, e.y, e.z, e.w);
+        if (posc)  // (not a hot kernel: both forms compiled in, chosen per launch)
+            vb_job_slow<false>(A, lds_all[wave], e.x, e.y, e.z, e.w);
+        else
+            vb_job_slow<true>(A, lds_all[wave], e.x, e.y, e.z, e.w);
     }
 }
 
@@ -2738,7 +2810,8 @@ vb_slow_kernel(BinGeom g, VbClusters cl, VbRecs rc, const float4* __restrict__ p
 // together with vb_slow_kernel.  slow_list == NULL: every job slot of the chunk (the round-4 form of the chain, kept as
 // the A/B reference: -DVB_INLINE_RESOLVE=0).
 __global__ void __launch_bounds__(256)
-vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int T, const int4* __restrict__ tri4,
+vb_resolve_kernel(BinGeom g, int B, const float* __restrict__ verts, const float* __restrict__ mvp,
+                  const float4* __restrict__ posc, int V, int T, const int4* __restrict__ tri4,
                   const int4* __restrict__ opp4, const unsigned* __restrict__ jid, const u64* __restrict__ jcov,
                   const int* __restrict__ jdesc,
                   int* __restrict__ jn, float* __restrict__ jval, VbItem* __restrict__ jitems,
@@ -2793,10 +2866,13 @@ vb_resolve_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, int 
                 S.ids[i] = (idw[k] != 0xffffffffu) ? idw[k] : (((C[k] >> lane) & 1ull) ? VB_ID_COVERED : 0xffffffffu);
         }
         VbResolveArgs Q;  // (wave-uniform; the compiler keeps what it needs in scalar registers)
-        Q.posc = posc; Q.tri4 = tri4; Q.opp4 = opp4; Q.jn = jn; Q.jval = jval; Q.jitems = jitems; Q.jspill = jspill;
+        Q.verts = verts; Q.mvp = mvp; Q.posc = posc; Q.L = L; Q.tri4 = tri4; Q.opp4 = opp4; Q.jn = jn; Q.jval = jval; Q.jitems = jitems; Q.jspill = jspill;
         Q.spill = spill; Q.meta = meta; Q.V = V; Q.T = T; Q.W = W; Q.H = H; Q.spill_cap = spill_cap; Q.want_grad = want_grad;
         Q.dbg = dbg;
-        vb_resolve_job(Q, S.ids, S.pairA, S.hits, C, slot, b, rx0, ry0);
+        if (posc)
+            vb_resolve_job<false, false>(Q, S.ids, S.pairA, S.hits, C, slot, b, u - b * L, rx0, ry0);
+        else
+            vb_resolve_job<false, true>(Q, S.ids, S.pairA, S.hits, C, slot, b, u - b * L, rx0, ry0);
     }
 }
 
@@ -2863,7 +2939,7 @@ vb_refsum_kernel(BinGeom g, int B, const float* __restrict__ ref, int vec_ok, lo
 // loss / grad_mvp [-> pose backward -> Adam], re-arms the link boxes.  vec_ok: W % 4 == 0 and 16-byte aligned images.
 template <bool TAIL, bool FILL>
 __global__ void __launch_bounds__(256, FILL ? 5 : 6)
-vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, const float* __restrict__ verts,
+vb_composite_kernel(BinGeom g, int B, const float* __restrict__ mvp, int V, const float* __restrict__ verts,
                     int* __restrict__ lbox, const int* __restrict__ jn, const float* __restrict__ jval,
                     const VbItem* __restrict__ jitems, const int* __restrict__ jspill, const int* __restrict__ jbase,
                     const unsigned* __restrict__ jutile, int jcap, const float* __restrict__ ref,
@@ -2892,7 +2968,7 @@ vb_composite_kernel(BinGeom g, int B, const float4* __restrict__ posc, int V, co
             lbox_all[i] = (i & 2) ? INT_MIN : INT_MAX;  // 16 ints (one line) per box: min x, min y, max x, max y, padding
     __syncthreads();
     VbCompArgs C;
-    C.g = g; C.B = B; C.posc = posc; C.V = V; C.verts = verts; C.jn = jn; C.jval = jval; C.jitems = jitems; C.jspill = jspill;
+    C.g = g; C.B = B; C.mvp = mvp; C.V = V; C.verts = verts; C.jn = jn; C.jval = jval; C.jitems = jitems; C.jspill = jspill;
     C.jcap = jcap; C.ref = ref; C.mask = mask; C.facc = facc; C.nls = nls; C.want_grad = want_grad; C.vec_ok = vec_ok;
     C.spill = spill; C.spill_cap = spill_cap; C.meta = meta; C.dbg = dbg; C.tsum = tsum;
     const int nwg = gridDim.x, xcd = blockIdx.x & 7;
@@ -3200,7 +3276,18 @@ int ehr::vbuf_plan(ehr_ctx* ctx, int B, int L, int V, int T, int H, int W, float
     if (jobs_per_view * Bc > 2.0e9) return fail(EHR_ERR_INVALID, "ehr_fused_plan: views x links x tiles of a chunk exceeds 2e9");
     ctx->vb_chunk = Bc;
     if ((rc = ctx->vb_acc.reserve(((size_t)B * (12 * (size_t)L + VB_LOSS_SLOTS * VB_LOSS_STRIDE)) * sizeof(long long) + EHR_META_INTS * sizeof(int) + (VB_LINES + 1) * 128))) return rc;
-    if ((rc = ctx->vb_posc.reserve((size_t)Bc * std::max(V, 1) * sizeof(float4)))) return rc;
+    {   // Clip-space vertices: kept per view (posc, 16 B per vertex and view, written by the vertex kernel) or computed where
+        // they are looked up (VbLazy).  Lazy pays where vertices outnumber the look-ups by far -- meshes with unshared
+        // vertices (V ~ 3 T): Franka 16 x 1080p spends 168 of the vertex launch's 286 MB on them -- and costs the job kernel
+        // registers it does not have (8 views xArm7: +3.5 us), hence a choice per plan.  EHR_VB_LAZY=0/1 overrides.
+        const char* e = getenv("EHR_VB_LAZY");
+        ctx->vb_lazy = e ? atoi(e) != 0 : (double)V > 1.5 * (double)std::max(T, 1);
+        if (ctx->vb_lazy != (ctx->vb_posc.ptr == nullptr) && ctx->gexec) {  // (a captured chain has the form baked in)
+            EHR_HIP(hipGraphExecDestroy(ctx->gexec));
+            ctx->gexec = nullptr;
+        }
+        if (!ctx->vb_lazy && (rc = ctx->vb_posc.reserve((size_t)Bc * std::max(V, 1) * sizeof(float4)))) return rc;
+    }
     // per step and (view, cluster slot): trec 32 B | tbox 8 B, then cbox 8 B per (view, cluster)
     if ((rc = ctx->vb_boxes.reserve((size_t)Bc * NC * (64 * 40 + 8)))) return rc;
     {  // pool of blended pairs for jobs that exceed their slot (EHR_VB_SPILL_ITEMS: test hook for the overflow path)
@@ -3412,7 +3499,6 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     long long* const facc_all = (long long*)ctx->vb_acc.ptr;
     const int acc_stride = 12 * L + VB_LOSS_SLOTS * VB_LOSS_STRIDE;
     int* meta = (int*)(facc_all + (size_t)B * acc_stride);
-    float4* posc = (float4*)ctx->vb_posc.ptr;
     int* const lbox_all = (int*)ctx->vb_units.ptr;
     VbItem* spill = (VbItem*)ctx->vb_spill.ptr;
     const int NC = ctx->vb_nc, NC1 = std::max(NC, 1);
@@ -3475,7 +3561,9 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
     int* jbase = jdesc + nslot;                                 // [Bc * L + 1] first job of every (view, link) of the chunk
     unsigned* jutile = (unsigned*)(jbase + (size_t)Bc * L + 1);  // [Bc * L] its tile range
     int4* slow_list = (int4*)(((uintptr_t)(jutile + (size_t)Bc * L) + 15) & ~(uintptr_t)15);  // [nslot] jobs for vb_slow_kernel
-    const int nvb = (std::max(V, 1) + 255) / 256;
+    const bool lazy = ctx->vb_lazy;
+    float4* const posc = lazy ? nullptr : (float4*)ctx->vb_posc.ptr;
+    const int nvb = lazy ? 0 : (std::max(V, 1) + 255) / 256;  // (no per-vertex work items where clip-space vertices are computed on demand)
     const int nitems = nvb + (NC + 3) / 4;
     for (int b0 = 0; b0 < B; b0 += Bc) {  // chunks of views (one, unless views x links / scratch say otherwise)
         const int Bk = std::min(Bc, B - b0);
@@ -3517,7 +3605,10 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         // stage 1a (below) is launched by the stateless render call always, by the solver step only once a step needed it
         const bool with_slow = !tail || ctx->vb_slow_needed;
         VbResolveArgs rq;  // the resolve stage runs inside the job kernel, on the wave that drew the job
+        rq.verts = verts;
+        rq.mvp = mvp_k;
         rq.posc = posc;
+        rq.L = L;
         rq.tri4 = (const int4*)ctx->vb_idx.ptr;
         rq.opp4 = (const int4*)ctx->vb_idx.ptr + T;
         rq.jn = jn;
@@ -3549,6 +3640,8 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         jp.dbg = dbg;
         jp.hv = hv;
         jp.timeline = (long long*)ctx->vb_spill.ptr;
+        jp.verts = verts;
+        jp.mvp = mvp_k;
         jp.posc = posc;
         jp.V = V;
         jp.si = si;
@@ -3564,10 +3657,10 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         // tickets and the finish stage's own chain, none of which a launch boundary adds to; and the merged grid has fewer waves
         // than there are items.  Kept as the A/B record and as the carrier of the grid-wide hand-over (agent-scope job slots).
         static const int merge_env = getenv("EHR_VB_MERGE") ? atoi(getenv("EHR_VB_MERGE")) : 0;
-        const bool merged = merge_env && tail && sparse && !mask_k && Bk == B && !with_slow && (job_wgs & 7) == 0;
+        const bool merged = merge_env && !lazy && tail && sparse && !mask_k && Bk == B && !with_slow && (job_wgs & 7) == 0;
         if (merged) {
             VbCompArgs& C = jp.ca;
-            C.g = g; C.B = Bk; C.posc = posc; C.V = V; C.verts = verts; C.jn = jn; C.jval = jval; C.jitems = jitems;
+            C.g = g; C.B = Bk; C.mvp = mvp_k; C.V = V; C.verts = verts; C.jn = jn; C.jval = jval; C.jitems = jitems;
             C.jspill = jspill; C.jcap = ctx->vb_jcap; C.ref = ref_k; C.mask = nullptr; C.facc = facc; C.nls = VB_LOSS_SLOTS;
             C.want_grad = grad_mvp ? 1 : 0; C.vec_ok = vec_ok; C.spill = spill; C.spill_cap = ctx->vb_spill_cap; C.meta = meta;
             C.dbg = dbg; C.tsum = tsum_all;
@@ -3583,12 +3676,15 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                 for (int k = 2; k <= 4; k++) EHR_HIP(hipEventRecord(ev[k], stream));
             continue;
         }
-        vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(jp);
+        if (lazy)
+            vb_job_kernel<false, false, true><<<job_wgs, 256, 0, stream>>>(jp);
+        else
+            vb_job_kernel<false><<<job_wgs, 256, 0, stream>>>(jp);
         EHR_LAUNCH_CHECK();
         // stage 1a: jobs with a triangle that crosses the near plane or spans > 512 pixels (normally none: the kernel returns at once)
         static const int slow_grid = getenv("EHR_VB_SLOW_GRID") ? atoi(getenv("EHR_VB_SLOW_GRID")) : 32;  // tuning knob
         if (with_slow) {
-            vb_slow_kernel<<<std::max(1, slow_grid), 256, 0, stream>>>(g, cl, recs, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
+            vb_slow_kernel<<<std::max(1, slow_grid), 256, 0, stream>>>(g, cl, recs, verts, mvp_k, posc, V, si, jid, jcov, jdesc, jn, slow_list, meta);
             EHR_LAUNCH_CHECK();
         }
         if (time_it) EHR_HIP(hipEventRecord(ev[2], stream));
@@ -3596,7 +3692,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         // only the jobs vb_slow_kernel redrew are left (none, normally: a launch of 32 workgroups that read a counter)
 #if VB_INLINE_RESOLVE
         if (with_slow) {
-            vb_resolve_kernel<<<std::max(8, slow_grid), 256, 0, stream>>>(g, Bk, posc, V, T, rq.tri4, rq.opp4, jid, jcov, jdesc, jn, jval,
+            vb_resolve_kernel<<<std::max(8, slow_grid), 256, 0, stream>>>(g, Bk, verts, mvp_k, posc, V, T, rq.tri4, rq.opp4, jid, jcov, jdesc, jn, jval,
                                                                           jitems, jspill, ctx->vb_jcap, rq.want_grad, spill,
                                                                           ctx->vb_spill_cap, meta, dbg, slow_list);
             EHR_LAUNCH_CHECK();
@@ -3604,7 +3700,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         (void)res_grid;
 #else
         const int res_wgs = ((ctx->num_cus * std::max(1, res_grid)) + 7) & ~7;
-        vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, Bk, posc, V, T, (const int4*)ctx->vb_idx.ptr,
+        vb_resolve_kernel<<<res_wgs, 256, 0, stream>>>(g, Bk, verts, mvp_k, posc, V, T, (const int4*)ctx->vb_idx.ptr,
                                                        (const int4*)ctx->vb_idx.ptr + T, jid, jcov, jdesc, jn, jval, jitems, jspill,
                                                        ctx->vb_jcap, grad_mvp ? 1 : 0, spill, ctx->vb_spill_cap, meta, dbg, nullptr);
         EHR_LAUNCH_CHECK();
@@ -3625,7 +3721,7 @@ int ehr::vbuf_chain(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
                                                           //  so that the form without a mask output keeps its registers)
 #define VB_COMPOSITE(TAILV, FILLV, tailarg)                                                                                  \
     vb_composite_kernel<TAILV, FILLV><<<nwg, 256, dyn, stream>>>(                                                            \
-        g, Bk, posc, V, verts, lbox, jn, jval, jitems, jspill, jbase, jutile, ctx->vb_jcap, ref_k, mask_k, facc,             \
+        g, Bk, mvp_k, V, verts, lbox, jn, jval, jitems, jspill, jbase, jutile, ctx->vb_jcap, ref_k, mask_k, facc,            \
         VB_LOSS_SLOTS, grad_mvp ? 1 : 0, vec_ok, spill, ctx->vb_spill_cap, meta, dbg, tsum, vtot, ref_flag, loss, grad_mvp,  \
         tailarg, last_chunk ? 1 : 0, B, facc_all, vtot_all, lbox_all)
         StepTail none = {};
@@ -3775,6 +3871,8 @@ int ehr::vbuf_score(ehr_ctx* ctx, const float* verts, const int32_t* tris, const
         jp.meta = meta;
         jp.dbg = 64 | 128;
         jp.hv = hv;
+        jp.verts = verts;
+        jp.mvp = mvp + (size_t)q0 * S * L * 16;
         jp.posc = posc;
         jp.V = V;
         jp.si = si;

@@ -251,3 +251,30 @@ def test_default_solver_context_stays_under_100_mb_at_8_views_720p(xarm7):
     fused.check_status(f.glctx)
     mb = f.glctx.scratch_bytes() / 1048576.0
     assert f.slack == 0.5 and mb <= 100.0, mb   # 50 MB of slots + records, clip-space vertices, hint tables, spill pool (16 MB)
+
+
+def test_clip_space_vertices_on_demand_equal_the_kept_ones(xarm7, monkeypatch):
+    """Round 6: a plan either keeps every vertex's clip-space position per view (posc, written by the vertex kernel) or lets
+    the depth tests, the silhouette analysis and the backward pass transform the few vertices they look up themselves
+    (VbLazy in csrc/ehr_vbuf.hip: the choice for meshes with unshared vertices, V > 1.5 T).  Same fma chain on the same matrix:
+    the launch chain's losses, gradients and pose trajectory must be bit-identical either way, and so must the stateless
+    render (mask included)."""
+    from easyhec_amd import fused
+    from easyhec_amd.fast import FusedPoseStep
+    cfg, make, batch = problem(xarm7, 3, 240, 320, 0.25)
+    res = {}
+    for lazy in ("0", "1"):
+        monkeypatch.setenv("EHR_VB_LAZY", lazy)     # (read by ehr_fused_plan: every FusedPoseStep below plans afresh)
+        m = make()
+        f = FusedPoseStep(m, batch)
+        losses = [float(f.step()) for _ in range(6)]
+        f.step(want_mask=True)
+        torch.cuda.synchronize()
+        fused.check_status(f.glctx)
+        res[lazy] = (losses, m.dof.detach().clone(), f.grad_mvp.clone(), f.mask.clone(), f.loss_b.clone())
+    monkeypatch.delenv("EHR_VB_LAZY")
+    a, b = res["0"], res["1"]
+    assert a[0] == b[0] and a[0][-1] < a[0][0]
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x, y)
+    assert float(a[3].sum()) > 100.0

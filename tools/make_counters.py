@@ -14,7 +14,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-KERNEL = "vb_job_kernel<false>"
+KERNEL = "vb_job_kernel<false, false, false>"  # (COVER, MERGE, LAZY)
 SIMDS, CLOCK_GHZ = 1024, 2.4
 
 
@@ -37,10 +37,10 @@ def main():
         if m:
             res[m.group(1)] = {"vgprs": int(m.group(2)), "spilled_vgprs": int(m.group(4)), "spilled_sgprs": int(m.group(5)),
                                "scratch_bytes_per_lane": int(m.group(6)), "lds_bytes": int(m.group(7)), "waves_per_simd": int(m.group(8))}
-    job = next((v for k, v in res.items() if k.startswith("vb_job_kernelILb0E")), {})
+    job = next((v for k, v in res.items() if k.startswith("vb_job_kernelILb0ELb0ELb0E")), {})
     cycles = dur * 1e-6 * CLOCK_GHZ * 1e9
     from bench import csrc_sha16
-    out = {"commit": commit, "csrc_sha16": csrc_sha16(), "kernel": "vb_job_kernel<false>", "workload": "xarm7_1280x720_8view",
+    out = {"commit": commit, "csrc_sha16": csrc_sha16(), "kernel": KERNEL, "workload": "xarm7_1280x720_8view",
            "kernel_us_rocprof": dur, "chain_kernels_us": chain, "chain_total_us": round(sum(chain.values()), 2),
            "SQ_INSTS_VALU": cnt.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU": cnt.get("SQ_INSTS_SALU"), "SQ_INSTS_LDS": cnt.get("SQ_INSTS_LDS"),
            "SQ_ACTIVE_INST_ANY": cnt.get("SQ_ACTIVE_INST_ANY"), "SQ_WAVE_CYCLES": cnt.get("SQ_WAVE_CYCLES"), "SQ_WAVES": cnt.get("SQ_WAVES"),
