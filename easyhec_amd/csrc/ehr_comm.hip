@@ -70,7 +70,7 @@ static int rccl_load() {
 // rank adds the same numbers in the same order: bit-identical sums, hence bit-identical Adam steps), and the kernel goes on to
 // the Adam update.  Slots alternate by the parity of the sequence number: a rank can only be two exchanges ahead of a peer
 // after that peer has read the older one.  A wait that does not end (a peer died) is reported -- NaN sums, Adam untouched --
-// after ~1 s, never a hang.  Kernel only: capturable in a hipGraph like the rest of the chain.
+// after ~half a minute, never a hang.  Kernel only: capturable in a hipGraph like the rest of the chain.
 constexpr int P2P_MAX = EHR_P2P_MAX_RANKS;
 constexpr int P2P_SLOT = 64;                       // bytes: 8 floats | sequence number | padding (a slot never shares a line)
 constexpr int P2P_HDR = 128;                       // [0] exchanges completed by the owner
@@ -103,7 +103,8 @@ p2p_exchange_adam_kernel(P2PPeers peers, char* __restrict__ mine, int nranks, in
         int spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1 << 21)) {
+            if (++spins > (1 << 24)) {  // (~half a minute: far beyond a peer that is only late -- a re-plan after a reported step
+                                        //  takes a second --; a rank that gave up would leave the replicated state for good)
                 s_bad = 1;
                 break;
             }

@@ -253,7 +253,7 @@ int ehr_comm_destroy(ehr_ctx* ctx);
  *                         before any rank exchanges (the caller's barrier).
  *   ehr_comm_p2p_step   : red[8] (device) <- sum over the ranks, in place; with dof != NULL the Adam update of ehr_pose_adam
  *                         follows in the same kernel (same arguments).  Every rank must make the same sequence of calls.
- *                         Enqueued on `stream`, capturable.  A peer that never answers is REPORTED after ~1 s: the sums are NaN
+ *                         Enqueued on `stream`, capturable.  A peer that never answers is REPORTED after ~half a minute: the sums are NaN
  *                         and the optimiser state stays as it was.
  *   ehr_comm_p2p_close  : closes the peers' mailboxes and frees the own one (ehr_ctx_destroy does it too). */
 #define EHR_P2P_MAX_RANKS 64
