@@ -159,7 +159,10 @@ class RBSolver(nn.Module):
         mvp_all = renderer.clip_matrices(K, Tc_c2b[None, None] @ link_poses)                     # [B, L, 4, 4]
         per_link = [renderer.clip_positions_batched(m, getattr(self, f"vertices_{k}"))           # L x [B, V_k, 4]
                     for k, m in enumerate(mvp_all.unbind(1))]
-        pos = torch.cat([per_link[k][b] for b in range(B) for k in range(self.nlinks)]).contiguous()   # [sum V, 4], image-major
+        # ([B, V_k, 4] blocks side by side along the vertex axis ARE the image-major concatenation -- one cat of L tensors and a
+        #  view, where round 5 concatenated B x L slices: 64 copies forward and a fill + an add per slice backward, a quarter of
+        #  this step's launches)
+        pos = torch.cat(per_link, dim=1).reshape(-1, 4)                                          # [sum V, 4], image-major
         rast, _ = dr.rasterize(renderer.glctx, pos, st["tri"], [self.H, self.W], ranges=st["ranges"], grad_db=False)
         color, _ = dr.interpolate(st["ones"], dr.carry_tile_flags(rast, rast.detach()), st["tri"])
         aa = dr.antialias(color, rast, pos, st["tri"], topology_hash=st["topology"])                 # [B L, H, W, 1]
