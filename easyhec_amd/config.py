@@ -31,6 +31,10 @@ class RBSolverCfg:
     # concatenated vertex / triangle array, a (start, count) range per image -- instead of once per image.  Same ops, same
     # arithmetic per image; what changes is that a call's latency chain is paid once for B x L images instead of B x L times
     batched_ops: bool = False
+    # use_fused=False, per-image schedule only: frames' render chains on this many HIP streams, each with its own rasterizer
+    # context (renderer.link_lanes), so that the independent chains overlap; 0 / 1 = everything on the step's stream;
+    # -1 = automatic: 2 when RBSolverTrainer(graph=True) replays the step from a graph (parallel branches), 1 otherwise
+    render_lanes: int = -1
 
 
 @dataclass

@@ -6,6 +6,8 @@ forward(dps) consumes the dataset tensors of /root/reference/easyhec/data/datase
 (``mask [B,H,W]``, ``link_poses [B,L,4,4]``, ``K [B,3,3]``, ``Tc_c2b [B,4,4]``) and renders every frame x link.
 With ``use_fused`` (default) the whole double loop + loss is one HIP kernel chain; with ``use_fused=False`` it is the
 reference's own per-(frame, link) sequence of rasterize / interpolate / antialias calls."""
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -67,6 +69,7 @@ class RBSolver(nn.Module):
         # (one sync) whenever it may be stale: after load_state_dict and after steps of the HIP launch chain, which
         # writes the rows itself (None = unknown).
         self._hist_n = 0
+        self.auto_render_lanes = 1  # cfg.render_lanes = -1: what RBSolverTrainer(graph=True) sets to 2 (see _forward_three_ops)
         self._hist_dev = None  # device-side cursor (a [1] int64 tensor) while the step is being replayed from a graph
         self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_hist_n", None))
 
@@ -112,17 +115,42 @@ class RBSolver(nn.Module):
         # Autograd nodes are launches too: unbind (backward = ONE stack) instead of indexing per (frame, link) (backward = a
         # zero fill + a copy + an add each), and _LinkComposite hands all links one contiguous gradient image.
         mvp_all = renderer.clip_matrices(K, Tc_c2b[None, None] @ link_poses)          # [B, L, 4, 4]
-        pos_all = [renderer.clip_positions_batched(m, getattr(self, f"vertices_{k}")).unbind(0)  # B x [V_k, 4] each
-                   for k, m in enumerate(mvp_all.unbind(1))]
+        pos_links = [renderer.clip_positions_batched(m, getattr(self, f"vertices_{k}"))     # [B, V_k, 4] per link
+                     for k, m in enumerate(mvp_all.unbind(1))]
+        pos_all = [p.unbind(0) for p in pos_links]
+        # One lane (HIP stream + rasterizer context) per frame (modulo cfg.render_lanes): the renders of different frames do
+        # not depend on each other, and each is a chain of small launches that leaves most of the GPU idle.  A frame's chain
+        # -- its L renders, the sum over links, its loss -- goes to its lane whole, so a frame costs one fork and one join; the
+        # backward of every op runs on the stream its forward ran on (autograd's rule) and overlaps the same way.
+        n_lanes = int(getattr(self.cfg, "render_lanes", -1))
+        n_lanes = min(self.auto_render_lanes if n_lanes < 0 else n_lanes, masks_ref.shape[0])
+        lanes = renderer.link_lanes(n_lanes) if n_lanes > 1 else None
+        here = torch.cuda.current_stream()
+        if lanes:
+            for k in range(self.nlinks):   # constants the renders share are made before the lanes part
+                renderer.warm(getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}"))
+            for lane, _ in lanes:
+                lane.wait_stream(here)
+                for p in pos_links:
+                    p.record_stream(lane)   # made on the step's stream, read on the lanes (forward and backward)
         for frame in range(masks_ref.shape[0]):
-            silhouettes = [
-                renderer.mask_from_clip(pos_all[k][frame][None], getattr(self, f"vertices_{k}"), getattr(self, f"faces_{k}"),
-                                        flip=False)
-                for k in range(self.nlinks)
-            ]
-            composite = _LinkComposite.apply(*silhouettes)
+            lane, glctx = lanes[frame % n_lanes] if lanes else (None, None)
+            with (torch.cuda.stream(lane) if lanes else contextlib.nullcontext()):
+                silhouettes = [
+                    renderer.mask_from_clip(pos_all[k][frame][None], getattr(self, f"vertices_{k}"),
+                                            getattr(self, f"faces_{k}"), flip=False, glctx=glctx)
+                    for k in range(self.nlinks)
+                ]
+                composite = _LinkComposite.apply(*silhouettes)
+                frame_loss = ((composite - masks_ref[frame].float()) ** 2).sum()
+            if lanes:
+                composite.record_stream(here)
+                frame_loss.record_stream(here)
             per_frame_mask.append(composite)
-            per_frame_loss.append(((composite - masks_ref[frame].float()) ** 2).sum())
+            per_frame_loss.append(frame_loss)
+        if lanes:
+            for lane, _ in lanes:
+                here.wait_stream(lane)
         return torch.stack(per_frame_mask), torch.stack(per_frame_loss).mean()
 
     def _batched_topology(self, B, dev):

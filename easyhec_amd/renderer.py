@@ -31,6 +31,27 @@ class NVDiffrastRenderer:
         # links), cached on the identity + version of the tensor they derive from: the projection of K, the homogeneous
         # vertex array and the all-ones vertex colour -- six small torch ops per call otherwise, a fifth of the step
         self._const = {}
+        self._lanes = []  # link_lanes(): (HIP stream, rasterizer context) pairs for renders that do not depend on each other
+
+    def link_lanes(self, n):
+        """``n`` (stream, rasterizer context) pairs.  The per-(frame, link) renders of one step do not depend on each other and
+        each is a chain of five small launches (a few microseconds each, far from filling 256 CUs); issued on one stream they
+        run end to end, on one stream per link the chains of a frame's links run side by side -- in a captured hipGraph they
+        become parallel branches.  A rasterizer context owns scratch that a render writes (the key image of the direct form),
+        so every lane has its own."""
+        while len(self._lanes) < n:
+            with torch.cuda.device(self.device):
+                self._lanes.append((torch.cuda.Stream(device=self.device), dr.RasterizeCudaContext(device=self.device)))
+        return self._lanes[:n]
+
+    def warm(self, verts, faces):
+        """Builds the cached per-mesh constants of mask_from_clip (edge topology, all-ones colour) on the current stream."""
+        if not self.plain:
+            self._topology(faces)
+            self._ones(verts)
+
+    def _ones(self, verts):
+        return self._cached("ones", verts, lambda: torch.ones((1, verts.shape[0], 1), dtype=torch.float, device=verts.device))
 
     def _topology(self, faces):
         ent = self._topo.get(id(faces))
@@ -88,18 +109,20 @@ class NVDiffrastRenderer:
             [verts, torch.ones([verts.shape[0], 1], dtype=verts.dtype, device=verts.device)], dim=1))
         return torch.matmul(posw[None], mtx.transpose(1, 2))
 
-    def mask_from_clip(self, pos_clip, verts, faces, anti_aliasing=True, flip=True):
-        """rasterize -> interpolate(ones) -> antialias on given clip-space positions [1, V, 4] (the body of render_mask)."""
-        return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing, flip=flip)
+    def mask_from_clip(self, pos_clip, verts, faces, anti_aliasing=True, flip=True, glctx=None):
+        """rasterize -> interpolate(ones) -> antialias on given clip-space positions [1, V, 4] (the body of render_mask);
+        ``glctx``: the rasterizer context of the lane the call is issued on (link_lanes), default the renderer's own."""
+        return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing, flip=flip, glctx=glctx)
 
     def batch_render_mask(self, verts, faces, K, anti_aliasing=True):
         """Vertices already in the camera frame (nvdiffrast_renderer.py:49-72)."""
         pos_clip = self._clip_positions(self._projection(K, verts.device) @ self.opencv2blender, verts)
         return self._mask_from_clip(pos_clip, verts, faces, anti_aliasing)
 
-    def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing, flip=True):
+    def _mask_from_clip(self, pos_clip, verts, faces, anti_aliasing, flip=True, glctx=None):
+        glctx = self.glctx if glctx is None else glctx
         if self.plain:
-            rast, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=[self.H, self.W])
+            rast, _ = dr.rasterize(glctx, pos_clip, faces, resolution=[self.H, self.W])
             if not anti_aliasing:
                 return torch.flip(rast[0, :, :, 2] > 0, dims=[0])
             rgb = torch.ones((1,) + tuple(verts.shape), dtype=torch.float, device=verts.device)
@@ -107,13 +130,12 @@ class NVDiffrastRenderer:
             return torch.flip(dr.antialias(shaded, rast, pos_clip, faces)[0, :, :, 0], dims=[0])
         # (grad_db=False: the reference takes the default and throws rast_db away -- `rast_out, _ = ...`,
         #  nvdiffrast_renderer.py:39 -- so the 16 B per pixel are not written here)
-        rast_out, _ = dr.rasterize(self.glctx, pos_clip, faces, resolution=self.resolution, grad_db=False)
+        rast_out, _ = dr.rasterize(glctx, pos_clip, faces, resolution=self.resolution, grad_db=False)
         if anti_aliasing:
             # ONE colour channel: the reference interpolates torch.ones(verts.shape) (three equal channels,
             # nvdiffrast_renderer.py:41) and keeps channel 0; the other two are never read, their gradient is zero, and
             # with one channel the mask below is a view of the op's output instead of a strided select
-            vtx_color = self._cached("ones", verts, lambda: torch.ones((1, verts.shape[0], 1), dtype=torch.float,
-                                                                       device=verts.device))
+            vtx_color = self._ones(verts)
             # (the colour is the same at every vertex, so it does not depend on the barycentrics: the gradient that would
             #  flow back through rast_out into pos_clip is exactly zero -- every term is dy * (1 - 1) -- and detaching saves
             #  two full-image backward kernels per (frame, link); the silhouette gradient comes from dr.antialias)

@@ -91,6 +91,11 @@ class RBSolverTrainer:
             raise ValueError("graph=True records the reference's default solver only (no gradient clipping)")
         m = self.model
         dev = m.dof.device
+        # render_lanes = -1 (automatic): the per-image three-op schedule goes to two streams when it is replayed from a graph
+        # (two parallel branches: 4.0 -> 3.1 ms per step at 8 views; three or more are slower than two under ROCm 7.2's graph
+        # executor, and issued from Python the extra stream bookkeeping costs more than the overlap returns).  Set before the
+        # warm-up steps: the lanes' rasterizer contexts must exist before the capture begins.
+        m.auto_render_lanes = 2
         if "gt_dof6" not in self.batch and "Tc_c2b" in self.batch:
             gt = self.batch["Tc_c2b"][0]
             if not torch.allclose(gt.cpu(), torch.eye(4)):

@@ -334,3 +334,42 @@ def test_batched_three_ops_equal_the_per_image_schedule(xarm7, graph):
     assert np.allclose(la, lb, rtol=1e-4), (la, lb)
     assert la[-1] < la[0]
     assert (ma.dof.detach() - mb.dof.detach()).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_render_lanes_equal_the_one_stream_schedule(xarm7, graph):
+    """``render_lanes=2`` issues the frames' render chains alternately on two lanes -- each its own HIP stream and rasterizer
+    context -- so that independent chains overlap, forward and backward; ``render_lanes=1`` issues the same calls on the
+    step's stream.  Same calls on the same inputs: the masks are the same bits, the loss curve and the pose trajectory equal to
+    float noise (dr.antialias' gradient is a sum of float atomics) -- eager and replayed from a graph (parallel branches,
+    which is also what the default, render_lanes=-1, gives a graph)."""
+    from easyhec_amd.trainer import RBSolverTrainer
+    from test_gpu_fast import problem
+    cfg_a, make_a, batch = problem(xarm7, 3, 120, 160, 0.125)
+    cfg_a.model.rbsolver.use_fused = False
+    cfg_a.model.rbsolver.render_lanes = 1
+    cfg_b, make_b, _ = problem(xarm7, 3, 120, 160, 0.125)
+    cfg_b.model.rbsolver.use_fused = False
+    assert cfg_b.model.rbsolver.render_lanes == -1
+    if not graph:
+        cfg_b.model.rbsolver.render_lanes = 2
+    ma, mb = make_a(), make_b()
+    with torch.no_grad():
+        ra = ma(dict(batch, global_step=0))[0]["rendered_masks"]
+        rb = mb(dict(batch, global_step=0))[0]["rendered_masks"]
+    torch.cuda.synchronize()
+    assert torch.equal(ra, rb) and float(ra.sum()) > 100.0
+    for m in (ma, mb):
+        m.history_ops.zero_()
+        m._hist_n = None
+    ta = RBSolverTrainer(cfg_a, ma, batch)
+    tb = RBSolverTrainer(cfg_b, mb, batch, graph=graph)
+    la, lb = [], []
+    for _ in range(8):
+        la.append(float(ta.step()[1]))
+        lb.append(float(tb.step()[1]))
+    torch.cuda.synchronize()
+    assert len(mb.renderer._lanes) == 2 and not ma.renderer._lanes
+    assert np.allclose(la, lb, rtol=1e-5), (la, lb)
+    assert la[-1] < la[0]
+    assert (ma.dof.detach() - mb.dof.detach()).abs().max() <= 1e-5

@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--graph", action="store_true", help="record the autograd step in a torch.cuda.CUDAGraph and replay it "
                     "(RBSolverTrainer(graph=True)): the ~1 500 launches of the three-op step at GPU speed")
-    ap.add_argument("--only", default="", help="one of three_ops / import_swap_only / fused_autograd (profiling runs)")
+    ap.add_argument("--lanes", type=int, default=-1, help="render_lanes of the three_ops line (streams the frames' chains go to)")
+    ap.add_argument("--only", default="", help="one of three_ops / three_ops_one_stream / three_ops_batched / import_swap_only / fused_autograd (profiling runs)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     wl = WORKLOADS["xarm7_1280x720_8view"]
@@ -34,8 +35,9 @@ def main():
     _, lp = make_views(rb, a.views)
     Tc = camera_Tc_c2b(radius=wl["radius"], lift=wl["lift"])
     out = {}
-    for fusedflag, refsched in ((False, False), (False, "batched"), (False, True), (True, False)):
-        name = "fused_autograd" if fusedflag else ("import_swap_only" if refsched is True else ("three_ops_batched" if refsched else "three_ops"))
+    for fusedflag, refsched in ((False, False), (False, "one_stream"), (False, "batched"), (False, True), (True, False)):
+        name = "fused_autograd" if fusedflag else {True: "import_swap_only", "batched": "three_ops_batched",
+                                                   "one_stream": "three_ops_one_stream", False: "three_ops"}[refsched]
         if a.only and a.only != name:
             continue
         cfg = Cfg()
@@ -44,6 +46,7 @@ def main():
         cfg.model.rbsolver.use_fused = fusedflag
         cfg.model.rbsolver.reference_schedule = refsched is True  # True: the reference's own statements, only the import swapped
         cfg.model.rbsolver.batched_ops = refsched == "batched"   # one call per op and step over all (view, link) images
+        cfg.model.rbsolver.render_lanes = 1 if refsched == "one_stream" else a.lanes
         model = RBSolver(cfg, meshes=rb.meshes).to(dev)
         batch = {"mask": torch.zeros((a.views, H, W), device=dev), "link_poses": torch.tensor(lp, device=dev),
                  "K": torch.tensor(K, dtype=torch.float32, device=dev)[None].repeat(a.views, 1, 1)}
