@@ -37,6 +37,8 @@ SIGNATURES = {
     "ehr_antialias_work_bytes": (c_size_t, [c_int, c_int, c_int]),
     "ehr_antialias_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                   c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ehr_antialias_fwd_zg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ehr_antialias_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ehr_fused_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,

@@ -341,7 +341,8 @@ __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ c
                                                      const float4* __restrict__ pos, const int32_t* __restrict__ tri,
                                                      const int32_t* __restrict__ opp, int range_mode, int B, int V, int T,
                                                      int H, int W, int C, int ntx, int nty, float* __restrict__ out,
-                                                     int4* __restrict__ work, const unsigned char* __restrict__ flags) {
+                                                     int4* __restrict__ work, const unsigned char* __restrict__ flags,
+                                                     float4* __restrict__ zero, int zero_n) {
     __shared__ int s_npair, s_count;
     __shared__ unsigned s_pair[AA_MAXP];   // px - tx0 + 1 (6 bits) | (py - ty0 + 1) << 6 (4 bits) | d << 10
     __shared__ float s_alpha[AA_MAXP];     // 0 = nothing lands anywhere
@@ -351,6 +352,12 @@ __global__ void __launch_bounds__(256) aa_fwd_kernel(const float* __restrict__ c
     const int ttx = (int)blockIdx.x, tty = (int)blockIdx.y, b = (int)blockIdx.z;
     const int tile = tty * ntx + ttx;
     const int segi = b * ntx * nty + tile;  // the tile's segment of `work`
+    if (zero) {
+        // the buffer the backward pass will accumulate pos's gradient into, cleared here: the fill a caller would launch
+        // before ehr_antialias_grad (one per (view, link) image in EasyHeC's schedule) rides on a launch that exists anyway
+        const int nwg = ntx * nty * B;
+        for (int i = segi * 256 + tid; i < zero_n; i += nwg * 256) zero[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int tx0 = ttx * AA_TW, ty0 = tty * AA_TH;
     const int lx = tid % AA_TW, ly = tid / AA_TW;
     const int px = tx0 + lx, py = ty0 + ly;
@@ -594,16 +601,27 @@ size_t ehr_antialias_work_bytes(int B, int H, int W) { return std::max<size_t>(a
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                       int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work,
                       const unsigned char* tile_flags, void* stream_) {
+    return ehr_antialias_fwd_zg(color, rast, pos, tri, opp, range_mode, B, V, T, H, W, C, out, work, tile_flags, nullptr, stream_);
+}
+
+int ehr_antialias_fwd_zg(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                         int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work,
+                         const unsigned char* tile_flags, float* grad_pos_zero, void* stream_) {
     if (!color || !rast || !pos || !tri || !opp || !out || !work)
         return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: NULL tensor");
     if (out == color) return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: out must not alias color (every pixel reads its neighbours' colours)");
     if (B >= 32768) return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: batch too large");
     hipStream_t stream = (hipStream_t)stream_;
     size_t n = (size_t)B * H * W;
-    if (n == 0) return EHR_OK;
+    const size_t nzero = (size_t)(range_mode ? 1 : B) * V;  // float4s of grad_pos_zero (pos's shape)
+    if (nzero > 0x7fffffffu) return fail(EHR_ERR_INVALID, "ehr_antialias_fwd: vertex array too large");
+    if (n == 0) {
+        if (grad_pos_zero && nzero) EHR_HIP(hipMemsetAsync(grad_pos_zero, 0, nzero * 16, stream));
+        return EHR_OK;
+    }
     aa_fwd_kernel<<<dim3((W + AA_TW - 1) / AA_TW, (H + AA_TH - 1) / AA_TH, B), 256, 0, stream>>>(
         color, (const float4*)rast, (const float4*)pos, tri, opp, range_mode, B, V, T, H, W, C, (W + AA_TW - 1) / AA_TW,
-        (H + AA_TH - 1) / AA_TH, out, (int4*)work, tile_flags);
+        (H + AA_TH - 1) / AA_TH, out, (int4*)work, tile_flags, (float4*)grad_pos_zero, (int)nzero);
     EHR_LAUNCH_CHECK();
     return EHR_OK;
 }

@@ -489,7 +489,7 @@ using namespace ehr;
 
 extern "C" {
 
-int ehr_version(void) { return 7; }
+int ehr_version(void) { return 8; }
 
 const char* ehr_last_error(void) { return g_last_error.c_str(); }
 

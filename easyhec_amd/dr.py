@@ -329,11 +329,15 @@ class _AntialiasFunc(torch.autograd.Function):
         lib = _lib.lib()
         out = torch.empty_like(color)
         work = torch.empty((lib.ehr_antialias_work_bytes(B, H, W),), dtype=torch.uint8, device=color.device)
+        # the buffer backward() accumulates pos's gradient into is cleared by the forward kernel on its way (a fill per call
+        # otherwise: 64 launches per step of the reference's schedule); backward() takes it once
+        g_pos = torch.empty_like(pos) if ctx.needs_input_grad[2] else None
         with torch.cuda.device(color.device):
-            _lib.check(lib.ehr_antialias_fwd(_lib.ptr(color), _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri),
-                                             _lib.ptr(opp), range_mode, B, V, T, H, W, C, _lib.ptr(out),
-                                             _lib.ptr(work), _lib.ptr(flags), _stream()), "antialias")
+            _lib.check(lib.ehr_antialias_fwd_zg(_lib.ptr(color), _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri),
+                                                _lib.ptr(opp), range_mode, B, V, T, H, W, C, _lib.ptr(out),
+                                                _lib.ptr(work), _lib.ptr(flags), _lib.ptr(g_pos), _stream()), "antialias")
         ctx.save_for_backward(color, rast, pos, tri, work)
+        ctx.g_pos = g_pos
         ctx.boost = float(boost)
         return out
 
@@ -347,7 +351,9 @@ class _AntialiasFunc(torch.autograd.Function):
         # (EasyHeC's colour is interpolated from constant attributes: nothing asks for its gradient, and the full-image copy
         #  of dy it starts from is a kernel per (view, link))
         g_color = torch.empty_like(color) if ctx.needs_input_grad[0] else None
-        g_pos = torch.zeros_like(pos)
+        g_pos, ctx.g_pos = ctx.g_pos, None   # cleared by the forward pass; a second backward() of a retained graph fills its own
+        if g_pos is None:
+            g_pos = torch.zeros_like(pos)
         with torch.cuda.device(color.device):
             _lib.check(_lib.lib().ehr_antialias_grad(_lib.ptr(color), _lib.ptr(rast), _lib.ptr(pos), _lib.ptr(tri),
                                                      _lib.ptr(dy), _lib.ptr(work), range_mode, B, V, T, H, W, C,

@@ -37,7 +37,7 @@ extern "C" {
 typedef struct ehr_ctx ehr_ctx;
 
 /* library / device --------------------------------------------------------------------------------------------- */
-int ehr_version(void);                 /* ABI version, currently 7 (7: ehr_comm_p2p_*; 6: tile flags -- ehr_tile_flags_bytes, a tile_flags argument on ehr_rasterize_fwd / _grad, ehr_interpolate_fwd / _grad, ehr_antialias_fwd; 2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*, ehr_rasterize_grad_db) */
+int ehr_version(void);                 /* ABI version, currently 8 (8: ehr_antialias_fwd_zg; 7: ehr_comm_p2p_*; 6: tile flags -- ehr_tile_flags_bytes, a tile_flags argument on ehr_rasterize_fwd / _grad, ehr_interpolate_fwd / _grad, ehr_antialias_fwd; 2: ehr_fused_plan takes the scene arrays; 3: ehr_fused_bind_ref, ehr_comm_*, history_row; 4: ehr_ctx_scratch_bytes; 5: EHR_ERR_RETRY from ehr_fused_status, ehr_antialias_fwd needs no zeroed work buffer and out != color, ehr_interpolate_da_*, ehr_rasterize_grad_db) */
 const char* ehr_last_error(void);      /* message of the last failing call on this thread ("" if none) */
 int ehr_device_count(void);            /* number of visible HIP devices (0 if none) */
 const char* ehr_device_arch(int dev);  /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
@@ -112,6 +112,12 @@ size_t ehr_antialias_work_bytes(int B, int H, int W);
 int ehr_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                       int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work,
                       const unsigned char* tile_flags, void* stream);
+/* The same forward pass, which also clears grad_pos_zero (pos's shape; may be NULL) on its way: the buffer a later
+ * ehr_antialias_grad accumulates into then needs no fill of its own -- one launch less per (view, link) image of the
+ * reference's schedule (ABI 8).  A caller that runs the backward pass twice zero-fills the buffer itself the second time. */
+int ehr_antialias_fwd_zg(const float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                         int range_mode, int B, int V, int T, int H, int W, int C, float* out, void* work,
+                         const unsigned char* tile_flags, float* grad_pos_zero, void* stream);
 /* grad_color [B,H,W,C] is overwritten (may be NULL: not wanted); grad_pos (pos's shape) is ACCUMULATED into (caller zero-fills). */
 int ehr_antialias_grad(const float* color, const float* rast, const float* pos, const int32_t* tri, const float* dy,
                        const void* work, int range_mode, int B, int V, int T, int H, int W, int C, float* grad_color,

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
 def test_library_reports_version_and_no_device_gracefully():
     from easyhec_amd import _lib
     lib = _lib.lib()
-    assert lib.ehr_version() == 7
+    assert lib.ehr_version() == 8
     n = lib.ehr_device_count()
     assert n >= 0
     if n == 0:

@@ -441,3 +441,55 @@ def test_a_context_whose_calls_were_captured_refuses_to_move_its_scratch():
     g.replay()                                                    # ... and the graph still replays into live memory
     torch.cuda.synchronize()
     assert torch.equal(r, first)
+
+
+@pytest.mark.parametrize("range_mode", [False, True])
+def test_antialias_gradient_buffer_cleared_by_the_forward_pass(env, oracle, range_mode):
+    """dr.antialias' forward kernel clears the buffer its backward pass accumulates pos's gradient into
+    (``ehr_antialias_fwd_zg``: no fill launch per call).  The gradient equals the oracle's; a second backward() through a
+    retained graph (whose buffer the first one handed to autograd) gives the same gradient again; under no_grad no buffer is
+    made; and a buffer that held garbage before the forward pass is clean after it (pointer-level call)."""
+    import ctypes
+    from easyhec_amd import _lib
+    dr, ctx, dev = env
+    H, W = 96, 136
+    rng = np.random.default_rng(77)
+    pos, tri = helpers.random_mesh(rng, 300, shared=True, size=0.3)
+    nimg = 3
+    if range_mode:
+        V, T = pos.shape[0], tri.shape[0]
+        posb = np.concatenate([pos + np.float32(0.01 * i) * np.array([1, 1, 0, 0], np.float32) for i in range(nimg)])
+        trib = np.concatenate([tri + i * V for i in range(nimg)]).astype(np.int32)
+        ranges = torch.tensor([[i * T, T] for i in range(nimg)], dtype=torch.int32)
+        tp, tt = t(posb, dev, True), t(trib, dev)
+        r, _ = dr.rasterize(ctx, tp, tt, [H, W], ranges=ranges)
+    else:
+        posb = np.stack([pos + np.float32(0.01 * i) * np.array([1, 1, 0, 0], np.float32) for i in range(nimg)])
+        tp, tt = t(posb, dev, True), t(tri, dev)
+        r, _ = dr.rasterize(ctx, tp, tt, [H, W])
+    col = t(rng.uniform(0, 1, size=((posb.shape[0], 2) if range_mode else (nimg, posb.shape[1], 2))).astype(np.float32), dev)
+    c, _ = dr.interpolate(col, r.detach(), tt)
+    th = dr.antialias_construct_topology_hash(tt)
+    aa = dr.antialias(c, r.detach(), tp, tt, topology_hash=th)
+    gy = t(rng.normal(size=tuple(aa.shape)).astype(np.float32), dev)
+    (g1,) = torch.autograd.grad((aa * gy).sum(), tp, retain_graph=True)
+    (g2,) = torch.autograd.grad((aa * gy).sum(), tp)
+    _, gp_ref = oracle.antialias_grad(c.cpu().numpy(), r.detach().cpu().numpy(), posb, tri if not range_mode else trib, gy.cpu().numpy())
+    scale = max(1.0, float(np.abs(gp_ref).max()))
+    assert np.abs(g1.cpu().numpy() - gp_ref).max() <= 1e-5 * scale
+    assert (g1 - g2).abs().max().item() <= 1e-5 * scale and g1.data_ptr() != g2.data_ptr()
+    with torch.no_grad():
+        aa_ng = dr.antialias(c, r.detach(), tp, tt, topology_hash=th)
+    assert torch.equal(aa_ng, aa.detach())
+    # pointer level: garbage in, zeros out, same image
+    lib = _lib.lib()
+    B = r.shape[0]
+    Vn, Tn, C = tp.shape[-2], tt.shape[0], c.shape[-1]
+    out = torch.empty_like(c)
+    work = torch.empty((lib.ehr_antialias_work_bytes(B, H, W),), dtype=torch.uint8, device=dev)
+    dirty = torch.full_like(tp.detach(), float("nan"))
+    _lib.check(lib.ehr_antialias_fwd_zg(_lib.ptr(c), _lib.ptr(r.detach()), _lib.ptr(tp.detach()), _lib.ptr(tt), _lib.ptr(th.opp),
+                                        int(range_mode), B, Vn, Tn, H, W, C, _lib.ptr(out), _lib.ptr(work), None,
+                                        _lib.ptr(dirty), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "aa")
+    torch.cuda.synchronize()
+    assert torch.equal(out, aa.detach()) and (dirty == 0).all()
