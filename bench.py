@@ -230,11 +230,13 @@ FRAC_NOTE = ("equivalent rate: ALGORITHMIC bytes (SURVEY 8d: 2 x geometry + 16 B
              "count budgets, so this can exceed 1; frac_hbm_actual beside it is the bandwidth the kernel really uses (PMC bytes)")
 
 
-def side_workload(name, dev, steps, warmup, min_ms=30.0):
+def side_workload(name, dev, steps, warmup, min_ms=30.0, graph=False):
     """One of the other BASELINE configs on this GPU (configs[1], [3] and [4]'s total on one device), timed exactly like the
-    headline: {ms_per_step, value, frac, frac_step, kernel_ms}.  Bounded: ~`min_ms` of timed work."""
+    headline -- the same launch form too (``graph``: the headline's --graph flag; until round 6 these were replayed from a
+    hipGraph whatever the headline did, which costs the three-launch chain 4 % at Franka 16 x 1080p):
+    {ms_per_step, value, frac, frac_step, kernel_ms}.  Bounded: ~`min_ms` of timed work."""
     from easyhec_amd import fused
-    p = build_problem(0, 1, dev, workload=name)
+    p = build_problem(0, 1, dev, graph=graph, workload=name)
     tr = p["trainer"]
 
     def barrier():
@@ -454,7 +456,7 @@ def main():
         for name in ("xarm7_640x480_1view", "franka_1920x1080_16view", "xarm7_1280x720_64view"):
             try:
                 # (its own step counts: a side measurement is bounded by time -- ~0.1-0.2 s of GPU work each --, not by the driver's --steps)
-                side[name] = side_workload(name, dev, 100, 30, min_ms=40.0)
+                side[name] = side_workload(name, dev, 100, 30, min_ms=40.0, graph=args.graph)
             except Exception as e:  # a side measurement must never cost the headline line
                 side[name] = {"error": f"{type(e).__name__}: {e}"}
 

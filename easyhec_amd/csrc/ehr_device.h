@@ -53,8 +53,9 @@ __device__ __forceinline__ bool same_sign(float a, float b) {
 __device__ __forceinline__ int snap_coord(float v, float w, float scale) {
     float s = v / w;
     float t = s * scale;
-    if (!(t < 1073741824.f)) t = 1073741824.f;
-    if (t < -1073741824.f) t = -1073741824.f;
+    // (fminf returns its other operand for a NaN: the same as "not below 2^30 -> 2^30"; one instruction each instead of a
+    //  compare and a select)
+    t = fmaxf(fminf(t, 1073741824.f), -1073741824.f);
     return (int)rintf(t);
 }
 
@@ -149,17 +150,18 @@ __device__ __forceinline__ Coverage setup_coverage(const float4& a, const float4
     }
     int xmin = min(cv.X[0], min(cv.X[1], cv.X[2])), xmax = max(cv.X[0], max(cv.X[1], cv.X[2]));
     int ymin = min(cv.Y[0], min(cv.Y[1], cv.Y[2])), ymax = max(cv.Y[0], max(cv.Y[1], cv.Y[2]));
-    const i64 cx = 8 - 8 * (i64)W, cy = 8 - 8 * (i64)H;
-    i64 ix0 = ((i64)xmin - cx + 15) >> 4, ix1 = ((i64)xmax - cx) >> 4;
-    i64 iy0 = ((i64)ymin - cy + 15) >> 4, iy1 = ((i64)ymax - cy) >> 4;
-    if (ix0 < 0) ix0 = 0;
-    if (iy0 < 0) iy0 = 0;
-    if (ix1 > W - 1) ix1 = W - 1;
-    if (iy1 > H - 1) iy1 = H - 1;
-    cv.ix0 = (int)ix0;
-    cv.ix1 = (int)ix1;
-    cv.iy0 = (int)iy0;
-    cv.iy1 = (int)iy1;
+    // (snapped coordinates lie within +-2^30 and |cx|, |cy| <= 8 * 65535: everything below fits 32 bits; >> is arithmetic)
+    const int cx = 8 - 8 * W, cy = 8 - 8 * H;
+    int ix0 = (xmin - cx + 15) >> 4, ix1 = (xmax - cx) >> 4;
+    int iy0 = (ymin - cy + 15) >> 4, iy1 = (ymax - cy) >> 4;
+    ix0 = max(ix0, 0);
+    iy0 = max(iy0, 0);
+    ix1 = min(ix1, W - 1);
+    iy1 = min(iy1, H - 1);
+    cv.ix0 = ix0;
+    cv.ix1 = ix1;
+    cv.iy0 = iy0;
+    cv.iy1 = iy1;
     if (ix0 > ix1 || iy0 > iy1) cv.valid = false;
     return cv;
 }

@@ -265,21 +265,22 @@ __device__ __forceinline__ VbEdges vb_edges(int X0, int Y0, int X1, int Y1, int 
     const int ox = 16 * bx0 + 8 - 8 * W, oy = 16 * by0 + 8 - 8 * H;
     X0 -= ox; X1 -= ox; X2 -= ox;
     Y0 -= oy; Y1 -= oy; Y2 -= oy;
+    // (every factor is below 2^14 in magnitude: v_mul_i32_i24 is exact here and runs at full rate, v_mul_lo_u32 at a quarter)
     {
         const int dX = X1 - X0, dY = Y1 - Y0;
-        r.e0 = dX * (0 - Y0) - dY * (0 - X0) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
+        r.e0 = __mul24(dX, 0 - Y0) - __mul24(dY, 0 - X0) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
         r.sx0 = -16 * dY;
         r.sy0 = 16 * dX;
     }
     {
         const int dX = X2 - X1, dY = Y2 - Y1;
-        r.e1 = dX * (0 - Y1) - dY * (0 - X1) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
+        r.e1 = __mul24(dX, 0 - Y1) - __mul24(dY, 0 - X1) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
         r.sx1 = -16 * dY;
         r.sy1 = 16 * dX;
     }
     {
         const int dX = X0 - X2, dY = Y0 - Y2;
-        r.e2 = dX * (0 - Y2) - dY * (0 - X2) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
+        r.e2 = __mul24(dX, 0 - Y2) - __mul24(dY, 0 - X2) - (((dY < 0) || (dY == 0 && dX < 0)) ? 0 : 1);
         r.sx2 = -16 * dY;
         r.sy2 = 16 * dX;
     }
@@ -311,21 +312,40 @@ struct VbRecs {
 // pos: the stricter class of the scoring op (mask = z/w of the nearest fragment > 0): every coverable pixel centre has
 // a depth in (0, 1], so that coverage alone decides the mask.
 __device__ __forceinline__ bool vb_depth_safe(const float4& p0, const float4& p1, const float4& p2, int W, int H, bool pos = false) {
-    const float z0 = p0.z / p0.w, z1 = p1.z / p1.w, z2 = p2.z / p2.w;
+    // (a classification, not a result: where it says "safe" the per-pixel depth-range test is skipped, and both ways draw the
+    //  same pixels as long as "safe" is never said wrongly -- so the ten quotients are products with hardware reciprocals
+    //  (1 ulp: 1e-7 of a depth near 1, absorbed by the margins below, which are a tenth wider than the bound they come from)
+    //  instead of ten IEEE divisions of ~10 instructions each in the busiest loop of the vertex kernel)
+    const float r0 = __builtin_amdgcn_rcpf(p0.w), r1 = __builtin_amdgcn_rcpf(p1.w), r2 = __builtin_amdgcn_rcpf(p2.w);
+    const float z0 = p0.z * r0, z1 = p1.z * r1, z2 = p2.z * r2;
     const float sx = (float)(8 * W), sy = (float)(8 * H);
-    const float x0 = p0.x / p0.w * sx, y0 = p0.y / p0.w * sy;
-    const float d1x = p1.x / p1.w * sx - x0, d1y = p1.y / p1.w * sy - y0;
-    const float d2x = p2.x / p2.w * sx - x0, d2y = p2.y / p2.w * sy - y0;
+    const float x0 = p0.x * r0 * sx, y0 = p0.y * r0 * sy;
+    const float d1x = p1.x * r1 * sx - x0, d1y = p1.y * r1 * sy - y0;
+    const float d2x = p2.x * r2 * sx - x0, d2y = p2.y * r2 * sy - y0;
     const float q1 = fabsf(z1 - z0), q2 = fabsf(z2 - z0);
     const float A = fabsf(d1x * d2y - d2x * d1y);
     const float l1 = fabsf(d1x) + fabsf(d1y), l2 = fabsf(d2x) + fabsf(d2y);
-    const float delta = 0.6f * (q1 * l2 + q2 * l1) / A + 0.25f * (q1 + q2);
+    const float delta = 0.66f * (q1 * l2 + q2 * l1) * __builtin_amdgcn_rcpf(A) + 0.275f * (q1 + q2);
     const float zmax = fmaxf(z0, fmaxf(z1, z2)), zmin = fminf(z0, fminf(z1, z2));
     const float wmax = fmaxf(p0.w, fmaxf(p1.w, p2.w)), wmin = fminf(p0.w, fminf(p1.w, p2.w));
-    return (A >= 0.05f * (l1 + l2) + 1e-3f) && (wmax <= 4.f * wmin) && (zmax + delta <= 1.f - 1e-5f) &&
-           (zmin - delta >= (pos ? 1e-5f : -1.f + 1e-5f));
+    return (A >= 0.055f * (l1 + l2) + 1.1e-3f) && (wmax <= 4.f * wmin) && (zmax + delta <= 1.f - 1.1e-5f) &&
+           (zmin - delta >= (pos ? 1.1e-5f : -1.f + 1.1e-5f));
 }
 
+// two 16-bit unsigned minima / maxima in one instruction (v_pk_min_u16 / v_pk_max_u16)
+typedef unsigned short vb_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vb_pk_min_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(vb_u16x2, a), __builtin_bit_cast(vb_u16x2, b)));
+}
+__device__ __forceinline__ unsigned vb_pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(vb_u16x2, a), __builtin_bit_cast(vb_u16x2, b)));
+}
+
+#ifndef VB_SMALL_BOX
+#define VB_SMALL_BOX 3  // boxes of up to this many pixel centres a side are tested exactly by the vertex kernel (4: the fourth
+                        // row and column cost the VALU-bound kernel 7 % at Franka 16 x 1080p and drop nothing the job kernel
+                        // notices; 2: the job kernel pays 2.3 us at 8 views for the 3 x 3 boxes that cover nothing)
+#endif
 #ifndef VB_VERTEX_WAVES
 #define VB_VERTEX_WAVES 5  // (five workgroups per CU stay resident: the launch deals the work accordingly)
 #endif
@@ -539,25 +559,26 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
             const Coverage cv = setup_coverage(p0, p1, p2, W, H);
             if (cv.valid) {
                 x0 = cv.ix0; y0 = cv.iy0; x1 = cv.ix1; y1 = cv.iy1;
-                const i64 ex = (i64)max(cv.X[0], max(cv.X[1], cv.X[2])) - min(cv.X[0], min(cv.X[1], cv.X[2]));
-                const i64 ey = (i64)max(cv.Y[0], max(cv.Y[1], cv.Y[2])) - min(cv.Y[0], min(cv.Y[1], cv.Y[2]));
+                // (snapped coordinates lie within +-2^30: the extent fits 32 unsigned bits)
+                const unsigned ex = (unsigned)max(cv.X[0], max(cv.X[1], cv.X[2])) - (unsigned)min(cv.X[0], min(cv.X[1], cv.X[2]));
+                const unsigned ey = (unsigned)max(cv.Y[0], max(cv.Y[1], cv.Y[2])) - (unsigned)min(cv.Y[0], min(cv.Y[1], cv.Y[2]));
                 if (ex > VB_FAST_EXTENT || ey > VB_FAST_EXTENT) {
                     r1.w = 1;
                 } else {
                     const VbEdges ed = vb_edges(cv.X[0], cv.Y[0], cv.X[1], cv.Y[1], cv.X[2], cv.Y[2], x0, y0, W, H);
-                    // A small box (<= 4 x 4 pixel centres: half of all triangles) is tested exactly, once, here: a fifth of
+                    // A small box (<= VB_SMALL_BOX pixel centres a side: nearly half of all triangles) is tested exactly, once, here: a fifth of
                     // the triangles with a non-empty box cover no pixel centre at all (70 % of the 1 x 1 boxes), and would
                     // otherwise be fetched, staged and walked by every job whose region their box touches.  The same
                     // integer edge functions as the rasterizer's walk, so nothing that could be drawn is dropped.
-                    if (x1 - x0 < 4 && y1 - y0 < 4) {
+                    if (x1 - x0 < VB_SMALL_BOX && y1 - y0 < VB_SMALL_BOX) {
                         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
                         bool any = false;
                         int q0 = ed.e0, q1 = ed.e1, q2 = ed.e2;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
+                        for (int j = 0; j < VB_SMALL_BOX; j++) {
                             int a0 = q0, a1 = q1, a2 = q2;
 #pragma unroll
-                            for (int i = 0; i < 4; i++) {
+                            for (int i = 0; i < VB_SMALL_BOX; i++) {
                                 any = any || (i < bw && j < bh && (a0 | a1 | a2) >= 0);
                                 a0 += ed.sx0;
                                 a1 += ed.sx1;
@@ -585,18 +606,18 @@ vb_vertex_kernel(const float* __restrict__ verts, const int32_t* __restrict__ ve
         rc.trec[2 * slot] = r0;  // (the two halves side by side: one 32-byte piece of a cache line per triangle)
         rc.trec[2 * slot + 1] = r1;
     }
-    const bool ne = x0 <= x1;
-    int a = ne ? x0 : INT_MAX, bq = ne ? y0 : INT_MAX, cc = ne ? x1 : -1, d = ne ? y1 : -1;
     // the cluster's box: a DPP reduction (four shifts inside the rows of 16 lanes, then the rows' results upwards: lane 63
-    // ends up with everything; integers, so the order is free), no LDS
-#define VB_BOX_STEP(ctrl, rows)                                                    \
-    a = min(a, __builtin_amdgcn_update_dpp(a, a, ctrl, rows, 0xf, false));        \
-    bq = min(bq, __builtin_amdgcn_update_dpp(bq, bq, ctrl, rows, 0xf, false));    \
-    cc = max(cc, __builtin_amdgcn_update_dpp(cc, cc, ctrl, rows, 0xf, false));    \
-    d = max(d, __builtin_amdgcn_update_dpp(d, d, ctrl, rows, 0xf, false));
+    // ends up with everything; integers, so the order is free), no LDS.  The two words of the packed box ARE the operands: two
+    // 16-bit minima / maxima per instruction (an empty box is (65535, 65535)-(0, 0): neutral both ways).
+    const uint2 pbox = vb_pack_box(x0, y0, x1, y1);
+    unsigned bmin = pbox.x, bmax = pbox.y;
+#define VB_BOX_STEP(ctrl, rows)                                                                       \
+    bmin = vb_pk_min_u16(bmin, (unsigned)__builtin_amdgcn_update_dpp((int)bmin, (int)bmin, ctrl, rows, 0xf, false)); \
+    bmax = vb_pk_max_u16(bmax, (unsigned)__builtin_amdgcn_update_dpp((int)bmax, (int)bmax, ctrl, rows, 0xf, false));
     VB_BOX_STEP(0x111, 0xf) VB_BOX_STEP(0x112, 0xf) VB_BOX_STEP(0x114, 0xf) VB_BOX_STEP(0x118, 0xf)
     VB_BOX_STEP(0x142, 0xa) VB_BOX_STEP(0x143, 0xc)
 #undef VB_BOX_STEP
+    const int a = (int)(bmin & 0xffffu), bq = (int)(bmin >> 16), cc = (int)(bmax & 0xffffu), d = (int)(bmax >> 16);
     if (lane == 63) {
         const bool cne = cvalid && a <= cc;
         if (cvalid) rc.cbox[(size_t)b * cl.NC + c] = cne ? vb_pack_box(a, bq, cc, d) : VB_BOX_EMPTY;
