@@ -3434,6 +3434,17 @@ int ehr::vbuf_meta_read(ehr_ctx* ctx, int* meta4) {
                         (x >> 20) & 0xfff, tx[0], tx[1], tx[2] & 0xffff, (tx[2] >> 16) & 0xffffff, tx[2] >> 40, tx[3] * 1e-3, tx[4] * 1e-3, tx[5] * 1e-3,
                         tx[6] * 1e-3, tx[10] * 1e-3, tx[8] * 1e-3, (tx[11] & 0xffffffffll) * 1e-3, (tx[11] >> 32) & 0xffff, (tx[11] >> 48) & 0xffff, (x >> 48) & 0xf, (hw >> 8) & 15, (hw >> 4) & 3);
             }
+            {   // where the waves' cycles go, all waves together (single-wave jobs; the phases nest as in the per-wave lines)
+                double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < nw; i++) {
+                    const long long* tx = &tl[4 * (size_t)nw + 12 * i];
+                    ph[0] += (double)tx[3]; ph[1] += (double)tx[4]; ph[2] += (double)tx[5]; ph[3] += (double)tx[6];
+                    ph[4] += (double)tx[10]; ph[5] += (double)tx[8]; ph[6] += (double)(tx[11] & 0xffffffffll);
+                    ph[7] += (double)tx[9];
+                }
+                fprintf(stderr, "[ehr timeline] all waves, Mcycles: stage %.1f search %.1f walk %.1f flush %.1f resolve %.1f total %.1f claim + cull %.1f (cull-wait %.1f) ; wave life %.1f\n",
+                        ph[0] * 1e-6, ph[1] * 1e-6, ph[2] * 1e-6, ph[3] * 1e-6, ph[4] * 1e-6, ph[5] * 1e-6, ph[7] * 1e-6, ph[6] * 1e-6, busy * 24.0 * 1e-6);
+            }
             {   // Where a late helper could still help: the last job of the waves the kernel ends on, against the moment the
                 // lists of jobs ran dry (task 1b: late sharing inside a workgroup)
                 std::vector<long long> dry;
